@@ -1,0 +1,251 @@
+// Flash-style multi-head attention forward for the ViT blocks (K4 of SURVEY.md §2.3), gfx950 only.
+//
+//   O[b, t, h*64:(h+1)*64] = softmax_keys( Q[b,t,h] · K[b,:,h]^T / 8 ) · V[b,:,h]
+//
+// Inputs come straight from the qkv GEMMs:
+//   QK : [B*npad, 2*D] bf16   (q | k, head h at columns h*64)
+//   Vt : [B, H, 64, npad] bf16 (V stored transposed per head by the FP_EPI_VT epilogue)
+// so both MFMA stages read K-contiguous 16-byte operands and no transpose is ever needed:
+//   S^T[key,q] = mfma(A = K rows,  B = Q rows)   -> a lane owns 16 keys of ONE query column:
+//                                                   softmax statistics stay (almost) lane-local
+//   O^T[d,q]   = mfma(A = V^T rows, B = P^T)      -> P^T fragments are built in registers from the
+//                                                   S^T accumulators; the contraction index is
+//                                                   re-labelled (key order inside a 32-key step) so
+//                                                   no cross-lane exchange is required
+// One workgroup = 4 waves x 32 queries = 128 queries of one (crop, head); K / V^T tiles of 64 keys are
+// DMA'd (global_load_lds) into a double-buffered, XOR-swizzled LDS ring shared by the 4 waves.
+// Sequence length is runtime (905 tokens @420^2, 1374 @518^2, 261 for ViT-S@224^2), keys >= n_tok are
+// masked; rows are padded per crop to npad (multiple of 16).
+//
+// Reference op replaced: the attention inside hub DINOv2 `blk(x)` (src/pipeline/retrieval/dino.py:18-19),
+// xformers memory_efficient_attention in the reference environment (environment_cuda.yaml:33).
+#include "internal.h"
+
+namespace {
+
+constexpr int HD = 64;      // head dim
+constexpr int KVB = 64;     // keys per tile
+constexpr int QW = 32;      // queries per wave
+constexpr int NWAVE = 4;
+constexpr int QB = QW * NWAVE;
+constexpr int ROWB = 128;   // bytes per LDS row (64 bf16)
+constexpr int TILE = KVB * ROWB;          // 8 KiB (K tile) == 64 d-rows * 128 B (V^T tile)
+constexpr int STAGE = 2 * TILE;
+
+struct AttnArgs {
+    const bf16_t* QK; int ldqk;  // elements
+    const bf16_t* Vt;
+    bf16_t* O; int ldo;
+    int B, H, n_tok, npad, D;
+    float scale_log2e;           // log2(e) / sqrt(hd)
+};
+
+__device__ __forceinline__ int key_plain(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int key_perm4(int row) {  // rows laid out 16a + 4f + b (a,b in 0..3)
+    const int rl = row & 63;
+    return (((rl >> 4) << 1) | ((rl & 3) >> 1)) & 7;
+}
+
+__global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB + wave * QW;
+
+    const size_t rowbase = (size_t)b * p.npad;
+    const char* gQK = (const char*)p.QK;
+    const char* gVt = (const char*)(p.Vt + ((size_t)b * p.H + h) * HD * p.npad);
+
+    // ---- Q fragments (B operand): lane (li -> query, lg -> 8-wide d slot) ---------------------
+    bf16x8_t qf[2][2];
+#pragma unroll
+    for (int fq = 0; fq < 2; ++fq) {
+        const int q = min(q0 + 16 * fq + li, p.npad - 1);
+        const char* src = gQK + ((rowbase + q) * p.ldqk + h * HD) * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qf[fq][kk] = *(const bf16x8_t*)(src + (kk * 4 + lg) * 16);
+    }
+
+    // ---- DMA source offsets: each wave moves 2 x 1 KiB of the K tile and 2 x 1 KiB of V^T ------
+    // K tile row r = key (plain map), V^T tile row r = d (perm map)
+    uint32_t offK[2];
+    int rowK[2];
+    uint32_t offV[2];
+    int slotV[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = (it * NWAVE + wave) * 8 + (lane >> 3);
+        rowK[it] = row;
+        offK[it] = (uint32_t)((p.D + h * HD) * 2 + (((lane & 7) ^ key_plain(row)) << 4));
+        slotV[it] = (lane & 7) ^ key_perm4(row);
+        offV[it] = (uint32_t)row * (uint32_t)p.npad * 2u;
+    }
+    auto stage = [&](int buf, int kv0) {
+        char* sb = smem + buf * STAGE;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int key = min(kv0 + rowK[it], p.npad - 1);
+            glds16(gQK + (rowbase + key) * (size_t)p.ldqk * 2 + offK[it], sb + (it * NWAVE + wave) * 1024);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k8 = min(kv0 + slotV[it] * 8, p.npad - 8);
+            glds16(gVt + offV[it] + (size_t)k8 * 2, sb + TILE + (it * NWAVE + wave) * 1024);
+        }
+    };
+
+    // ---- fragment read offsets -----------------------------------------------------------------
+    const int keyK = (li >> 1) & 7;                                // key_plain(16 f + li)
+    const int baseK = li * ROWB;                                   // + f*16*ROWB
+    const int keyV = (((li >> 2) << 1) | ((li & 3) >> 1)) & 7;     // key_perm4(row) for every f
+    const int baseV = TILE + ((li >> 2) * 16 + (li & 3)) * ROWB;   // + f*4*ROWB
+
+    f32x4_t o[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float mrow[2] = {-1e30f, -1e30f};
+    float lsum[2] = {0.f, 0.f};
+
+    const int ntile = (p.n_tok + KVB - 1) / KVB;
+    stage(0, 0);
+    for (int t = 0; t < ntile; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntile) stage((t + 1) & 1, (t + 1) * KVB);
+        const char* sb = smem + (t & 1) * STAGE;
+        const int kv0 = t * KVB;
+
+        // ---- S^T = K Q^T -------------------------------------------------------------------------
+        f32x4_t s[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = (((kk << 2) | lg) ^ keyK) << 4;
+#pragma unroll
+            for (int fk = 0; fk < 4; ++fk) {
+                const bf16x8_t kf = *(const bf16x8_t*)(sb + baseK + fk * 16 * ROWB + slot);
+#pragma unroll
+                for (int fq = 0; fq < 2; ++fq)
+                    s[fk][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[fq][kk], s[fk][fq], 0, 0, 0);
+            }
+        }
+        if (kv0 + KVB > p.n_tok) {  // wave-uniform: only the last tile masks
+#pragma unroll
+            for (int fk = 0; fk < 4; ++fk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kv0 + 16 * fk + 4 * lg + r >= p.n_tok) {
+                        s[fk][0][r] = -1e30f;
+                        s[fk][1][r] = -1e30f;
+                    }
+        }
+
+        // ---- online softmax (per query column; 4 lanes lg=0..3 share a query) --------------------
+        bf16x8_t pf[2][2];  // [fq][ks]  B-operand fragments of P^T
+#pragma unroll
+        for (int fq = 0; fq < 2; ++fq) {
+            float mx = s[0][fq][0];
+#pragma unroll
+            for (int fk = 0; fk < 4; ++fk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[fk][fq][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrow[fq], mx);
+            const float alpha = exp2f((mrow[fq] - mnew) * p.scale_log2e);
+            mrow[fq] = mnew;
+            const float mb = mnew * p.scale_log2e;
+            float rs = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int fk = 0; fk < 4; ++fk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[fk][r] = exp2f(fmaf(s[fk][fq][r], p.scale_log2e, -mb));
+                    rs += pv[fk][r];
+                }
+            lsum[fq] = lsum[fq] * alpha + rs;
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[fd][fq][r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 w;
+                w.x = pack_bf2(pv[2 * ks][0], pv[2 * ks][1]);
+                w.y = pack_bf2(pv[2 * ks][2], pv[2 * ks][3]);
+                w.z = pack_bf2(pv[2 * ks + 1][0], pv[2 * ks + 1][1]);
+                w.w = pack_bf2(pv[2 * ks + 1][2], pv[2 * ks + 1][3]);
+                pf[fq][ks] = __builtin_bit_cast(bf16x8_t, w);
+            }
+        }
+
+        // ---- O^T += V^T P^T ----------------------------------------------------------------------
+        // contraction slot (lg, j) <-> key 32 ks + 16 (j>>2) + 4 lg + (j&3): two 8-byte reads per fragment
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int s0 = ((((ks << 2) | (lg >> 1)) ^ keyV) << 4) + ((lg & 1) << 3);
+            const int s1 = ((((ks << 2) | 2 | (lg >> 1)) ^ keyV) << 4) + ((lg & 1) << 3);
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) {
+                const char* rp = sb + baseV + fd * 4 * ROWB;
+                const uint2 a0 = *(const uint2*)(rp + s0);
+                const uint2 a1 = *(const uint2*)(rp + s1);
+                const uint4 w = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, w);
+#pragma unroll
+                for (int fq = 0; fq < 2; ++fq)
+                    o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[fq][ks], o[fd][fq], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane owns 16 consecutive d (= 16 lg + 4 fd + r) of query li ---------
+#pragma unroll
+    for (int fq = 0; fq < 2; ++fq) {
+        float l = lsum[fq];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + 16 * fq + li;
+        if (q < p.npad) {
+            uint4 w0, w1;
+            w0.x = pack_bf2(o[0][fq][0] * inv, o[0][fq][1] * inv);
+            w0.y = pack_bf2(o[0][fq][2] * inv, o[0][fq][3] * inv);
+            w0.z = pack_bf2(o[1][fq][0] * inv, o[1][fq][1] * inv);
+            w0.w = pack_bf2(o[1][fq][2] * inv, o[1][fq][3] * inv);
+            w1.x = pack_bf2(o[2][fq][0] * inv, o[2][fq][1] * inv);
+            w1.y = pack_bf2(o[2][fq][2] * inv, o[2][fq][3] * inv);
+            w1.z = pack_bf2(o[3][fq][0] * inv, o[3][fq][1] * inv);
+            w1.w = pack_bf2(o[3][fq][2] * inv, o[3][fq][3] * inv);
+            uint4* dst = (uint4*)(p.O + (rowbase + q) * p.ldo + h * HD + lg * 16);
+            dst[0] = w0;
+            dst[1] = w1;
+        }
+    }
+}
+
+}  // namespace
+
+// QK [B*npad, 2D] (ldqk elements), Vt [B,H,64,npad], O [B*npad, D] (ldo elements)
+int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, int ldo, int B, int H,
+                     int n_tok, int npad, hipStream_t stream) {
+    FP_REQUIRE(B > 0 && H > 0 && n_tok > 0 && npad >= n_tok && npad % 16 == 0,
+               "attention: bad shape B=%d H=%d n_tok=%d npad=%d", B, H, n_tok, npad);
+    FP_REQUIRE(npad >= 8, "attention: npad too small");
+    AttnArgs a;
+    a.QK = QK; a.ldqk = ldqk; a.Vt = Vt; a.O = O; a.ldo = ldo;
+    a.B = B; a.H = H; a.n_tok = n_tok; a.npad = npad; a.D = H * HD;
+    a.scale_log2e = 1.4426950408889634f / 8.0f;
+    dim3 grid(cdiv(npad, QB), H, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}

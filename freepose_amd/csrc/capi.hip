@@ -1,0 +1,476 @@
+// C-ABI entry points of libfreepose_hip.so (see include/freepose_hip.h) + context / ViT forward driver.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cmath>
+
+#include "../../include/freepose_hip.h"
+#include "internal.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void fp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* fp_last_error(void) { return g_err; }
+extern "C" int fp_version(void) { return 100; }
+
+int fp_ctx::get(const char* name, size_t bytes, void** out) {
+    Buf& b = bufs[name];
+    if (b.bytes < bytes) {
+        if (b.p) FP_HIP(hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        FP_HIP(hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return FP_OK;
+}
+size_t fp_ctx::total() const {
+    size_t t = 0;
+    for (auto& kv : bufs) t += kv.second.bytes;
+    return t;
+}
+void fp_ctx::release() {
+    for (auto& kv : bufs)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    bufs.clear();
+}
+
+extern "C" int fp_ctx_create(int device, fp_ctx** out) {
+    FP_REQUIRE(out, "ctx_create: null out");
+    int n = 0;
+    FP_HIP(hipGetDeviceCount(&n));
+    FP_REQUIRE(device >= 0 && device < n, "ctx_create: device %d out of range (%d visible)", device, n);
+    FP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FP_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fp_set_error("ctx_create: device %d is %s; this library contains gfx950 (MI355X) code only", device,
+                     prop.gcnArchName);
+        return FP_ERR_STATE;
+    }
+    fp_ctx* c = new fp_ctx();
+    c->device = device;
+    *out = c;
+    return FP_OK;
+}
+extern "C" int fp_ctx_destroy(fp_ctx* ctx) {
+    if (!ctx) return FP_OK;
+    ctx->release();
+    delete ctx;
+    return FP_OK;
+}
+extern "C" size_t fp_ctx_workspace_bytes(const fp_ctx* ctx) { return ctx ? ctx->total() : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// ViT
+struct VitBlockW {
+    const bf16_t *n1w = nullptr, *n1b = nullptr, *qkvw = nullptr, *qkvb = nullptr, *projw = nullptr,
+                 *projb = nullptr, *ls1 = nullptr, *n2w = nullptr, *n2b = nullptr, *fc1w = nullptr, *fc1b = nullptr,
+                 *fc2w = nullptr, *fc2b = nullptr, *ls2 = nullptr;
+};
+struct fp_vit {
+    fp_ctx* ctx = nullptr;
+    fp_vit_arch a{};
+    int KP = 0;  // padded patch-embed K
+    const bf16_t *cls = nullptr, *pos = nullptr, *reg = nullptr, *pe_b = nullptr, *normw = nullptr, *normb = nullptr;
+    bf16_t* pe_w = nullptr;  // [dim, KP] private padded copy
+    bf16_t* ones = nullptr;  // LayerScale gamma = 1 for checkpoints without ls*
+    std::vector<VitBlockW> blk;
+    // pos-embed cache per (gh,gw)
+    std::map<std::pair<int, int>, bf16_t*> pos_cache;
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    float ms_gemm = 0, ms_attn = 0, ms_other = 0;
+    double gemm_flops = 0;
+};
+
+extern "C" int fp_vit_create(fp_ctx* ctx, const fp_vit_arch* arch, fp_vit** out) {
+    FP_REQUIRE(ctx && arch && out, "vit_create: null argument");
+    FP_REQUIRE(arch->dim % 64 == 0 && arch->heads * 64 == arch->dim, "vit_create: dim=%d heads=%d (head dim must be 64)",
+               arch->dim, arch->heads);
+    FP_REQUIRE(arch->mlp_dim % 64 == 0 && arch->depth > 0 && arch->patch > 0, "vit_create: bad arch");
+    fp_vit* v = new fp_vit();
+    v->ctx = ctx;
+    v->a = *arch;
+    v->blk.resize(arch->depth);
+    v->KP = cdiv(3 * arch->patch * arch->patch, 64) * 64;
+    if (hipMalloc((void**)&v->pe_w, (size_t)arch->dim * v->KP * 2) != hipSuccess ||
+        hipMalloc((void**)&v->ones, (size_t)arch->dim * 2) != hipSuccess) {
+        fp_set_error("vit_create: hipMalloc failed");
+        delete v;
+        return FP_ERR_HIP;
+    }
+    FP_HIP(hipMemset(v->pe_w, 0, (size_t)arch->dim * v->KP * 2));
+    std::vector<bf16_t> one(arch->dim, f2bf(1.0f));
+    FP_HIP(hipMemcpy(v->ones, one.data(), (size_t)arch->dim * 2, hipMemcpyHostToDevice));
+    *out = v;
+    return FP_OK;
+}
+extern "C" int fp_vit_destroy(fp_vit* v) {
+    if (!v) return FP_OK;
+    if (v->pe_w) (void)hipFree(v->pe_w);
+    if (v->ones) (void)hipFree(v->ones);
+    for (auto& kv : v->pos_cache) (void)hipFree(kv.second);
+    for (int i = 0; i < 2; ++i)
+        if (v->ev[i]) (void)hipEventDestroy(v->ev[i]);
+    delete v;
+    return FP_OK;
+}
+
+extern "C" int fp_vit_set_weight(fp_vit* v, const char* name, const void* d, size_t numel, void* stream) {
+    FP_REQUIRE(v && name && d, "vit_set_weight: null argument");
+    const fp_vit_arch& a = v->a;
+    const bf16_t* p = (const bf16_t*)d;
+    const size_t D = a.dim;
+    auto need = [&](size_t n) -> bool {
+        if (numel != n) { fp_set_error("vit_set_weight: %s has %zu elements, expected %zu", name, numel, n); return false; }
+        return true;
+    };
+    std::string s(name);
+    if (s == "cls_token") { if (!need(D)) return FP_ERR_INVALID; v->cls = p; return FP_OK; }
+    if (s == "pos_embed") {
+        if (!need((size_t)(1 + a.pos_grid * a.pos_grid) * D)) return FP_ERR_INVALID;
+        v->pos = p;
+        for (auto& kv : v->pos_cache) (void)hipFree(kv.second);
+        v->pos_cache.clear();
+        return FP_OK;
+    }
+    if (s == "register_tokens") { if (!need((size_t)a.n_reg * D)) return FP_ERR_INVALID; v->reg = p; return FP_OK; }
+    if (s == "mask_token") return FP_OK;  // unused at inference
+    if (s == "patch_embed.proj.weight") {
+        const int K = 3 * a.patch * a.patch;
+        if (!need(D * K)) return FP_ERR_INVALID;
+        FP_HIP(hipMemcpy2DAsync(v->pe_w, (size_t)v->KP * 2, p, (size_t)K * 2, (size_t)K * 2, D,
+                                hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return FP_OK;
+    }
+    if (s == "patch_embed.proj.bias") { if (!need(D)) return FP_ERR_INVALID; v->pe_b = p; return FP_OK; }
+    if (s == "norm.weight") { if (!need(D)) return FP_ERR_INVALID; v->normw = p; return FP_OK; }
+    if (s == "norm.bias") { if (!need(D)) return FP_ERR_INVALID; v->normb = p; return FP_OK; }
+    int bi = -1;
+    char rest[64] = {0};
+    if (sscanf(name, "blocks.%d.%63s", &bi, rest) == 2 && bi >= 0 && bi < a.depth) {
+        VitBlockW& w = v->blk[bi];
+        std::string r(rest);
+        const size_t M = a.mlp_dim;
+        struct Ent { const char* n; const bf16_t** slot; size_t numel; } tab[] = {
+            {"norm1.weight", &w.n1w, D}, {"norm1.bias", &w.n1b, D},
+            {"attn.qkv.weight", &w.qkvw, 3 * D * D}, {"attn.qkv.bias", &w.qkvb, 3 * D},
+            {"attn.proj.weight", &w.projw, D * D}, {"attn.proj.bias", &w.projb, D},
+            {"ls1.gamma", &w.ls1, D}, {"norm2.weight", &w.n2w, D}, {"norm2.bias", &w.n2b, D},
+            {"mlp.fc1.weight", &w.fc1w, M * D}, {"mlp.fc1.bias", &w.fc1b, M},
+            {"mlp.fc2.weight", &w.fc2w, D * M}, {"mlp.fc2.bias", &w.fc2b, D}, {"ls2.gamma", &w.ls2, D}};
+        for (auto& e : tab)
+            if (r == e.n) { if (!need(e.numel)) return FP_ERR_INVALID; *e.slot = p; return FP_OK; }
+    }
+    fp_set_error("vit_set_weight: unknown tensor name '%s'", name);
+    return FP_ERR_INVALID;
+}
+
+static int vit_pos(fp_vit* v, int gh, int gw, hipStream_t s, const bf16_t** out) {
+    const fp_vit_arch& a = v->a;
+    if (gh == a.pos_grid && gw == a.pos_grid) { *out = v->pos + a.dim; return FP_OK; }  // no resize needed
+    auto key = std::make_pair(gh, gw);
+    auto it = v->pos_cache.find(key);
+    if (it == v->pos_cache.end()) {
+        bf16_t* buf = nullptr;
+        FP_HIP(hipMalloc((void**)&buf, (size_t)gh * gw * a.dim * 2));
+        int rc = fp_posembed_aa(v->pos + a.dim, buf, a.pos_grid, gh, gw, a.dim, s);
+        if (rc) { (void)hipFree(buf); return rc; }
+        it = v->pos_cache.emplace(key, buf).first;
+    }
+    *out = it->second;
+    return FP_OK;
+}
+
+extern "C" double fp_vit_flops(const fp_vit* v, int B, int H, int W, int layer) {
+    const fp_vit_arch& a = v->a;
+    const double P = (double)(H / a.patch) * (W / a.patch), N = P + 1 + a.n_reg, D = a.dim;
+    const int L = std::min(layer, a.depth);
+    const double mlp_ratio = (double)a.mlp_dim / a.dim;
+    const double per_block = (8.0 + 4.0 * mlp_ratio) * N * D * D + 4.0 * N * N * D;  // 24 N D^2 + 4 N^2 D for ratio 4
+    return B * (L * per_block + 2.0 * P * (3.0 * a.patch * a.patch) * D);
+}
+
+namespace {
+struct ProfScope {
+    fp_vit* v; hipStream_t s; float* acc;
+    ProfScope(fp_vit* v_, hipStream_t s_, float* acc_) : v(v_), s(s_), acc(acc_) {
+        if (v->prof) (void)hipEventRecord(v->ev[0], s);
+    }
+    ~ProfScope() {
+        if (v->prof) {
+            (void)hipEventRecord(v->ev[1], s);
+            (void)hipEventSynchronize(v->ev[1]);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, v->ev[0], v->ev[1]);
+            *acc += ms;
+        }
+    }
+};
+}  // namespace
+
+extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int W, int layer, int feature_type,
+                              void* d_out, void* stream) {
+    FP_REQUIRE(v && d_images && d_out, "vit_forward: null argument");
+    const fp_vit_arch& a = v->a;
+    hipStream_t s = (hipStream_t)stream;
+    FP_REQUIRE(B > 0 && H % a.patch == 0 && W % a.patch == 0, "vit_forward: B=%d H=%d W=%d (patch %d)", B, H, W, a.patch);
+    FP_REQUIRE(feature_type >= 0 && feature_type <= 2, "vit_forward: feature_type %d", feature_type);
+    FP_REQUIRE(v->cls && v->pos && v->pe_b && v->normw && v->normb && (a.n_reg == 0 || v->reg),
+               "vit_forward: embedding / final-norm weights not set");
+    const int L = std::min(std::max(layer, 0), a.depth);  // layer > depth: loop never breaks (dino.py:18-21)
+    for (int i = 0; i < L; ++i) {
+        const VitBlockW& w = v->blk[i];
+        FP_REQUIRE(w.n1w && w.n1b && w.qkvw && w.qkvb && w.projw && w.projb && w.n2w && w.n2b && w.fc1w && w.fc1b &&
+                       w.fc2w && w.fc2b, "vit_forward: weights of block %d not set", i);
+    }
+    const int D = a.dim, gh = H / a.patch, gw = W / a.patch, P = gh * gw;
+    const int n_tok = P + 1 + a.n_reg;
+    const int npad = cdiv(n_tok, 16) * 16;
+    const size_t M = (size_t)B * npad;
+    FP_REQUIRE(M * (size_t)a.mlp_dim * 2 < 0xffffffffull, "vit_forward: batch too large for 32-bit tile offsets (B=%d)", B);
+
+    bf16_t *A0, *X, *Y, *QK, *Vt, *AO, *H1;
+    int rc;
+    if ((rc = v->ctx->get("vit.im2col", (size_t)B * P * v->KP * 2, (void**)&A0))) return rc;
+    if ((rc = v->ctx->get("vit.x", M * D * 2, (void**)&X))) return rc;
+    if ((rc = v->ctx->get("vit.y", M * D * 2, (void**)&Y))) return rc;
+    if ((rc = v->ctx->get("vit.qk", M * 2 * D * 2, (void**)&QK))) return rc;
+    if ((rc = v->ctx->get("vit.vt", M * D * 2 + 256, (void**)&Vt))) return rc;
+    if ((rc = v->ctx->get("vit.ao", M * D * 2, (void**)&AO))) return rc;
+    if ((rc = v->ctx->get("vit.h1", M * (size_t)a.mlp_dim * 2, (void**)&H1))) return rc;
+
+    const bf16_t* pos_patch;
+    if ((rc = vit_pos(v, gh, gw, s, &pos_patch))) return rc;
+
+    // ---- K0-K2: normalise + unfold, patch-embed GEMM scattering into the token buffer ----------
+    {
+        ProfScope ps(v, s, &v->ms_other);
+        if ((rc = fp_im2col_norm((const bf16_t*)d_images, A0, B, H, W, a.patch, v->KP, s))) return rc;
+        if ((rc = fp_token_init(X, v->cls, v->pos, v->reg, a.n_reg, B, n_tok, npad, D, s))) return rc;
+    }
+    {
+        ProfScope ps(v, s, &v->ms_gemm);
+        FpGemmArgs g{};
+        g.X = A0; g.ldx = v->KP; g.W = v->pe_w; g.ldw = v->KP; g.C = X; g.ldc = D; g.bias = v->pe_b;
+        g.M = B * P; g.N = D; g.K = v->KP; g.pos = pos_patch; g.P = P; g.npad = npad; g.tok_off = 1 + a.n_reg;
+        if ((rc = fp_gemm_bf16(g, FP_EPI_PATCH, s))) return rc;
+        v->gemm_flops += 2.0 * g.M * (3.0 * a.patch * a.patch) * D;
+    }
+    const int Mi = (int)M;
+    for (int i = 0; i < L; ++i) {
+        const VitBlockW& w = v->blk[i];
+        {
+            ProfScope ps(v, s, &v->ms_other);
+            if ((rc = fp_layernorm(X, Y, w.n1w, w.n1b, Mi, D, a.ln_eps, 0, 0, 0, s))) return rc;
+        }
+        {
+            ProfScope ps(v, s, &v->ms_gemm);
+            FpGemmArgs g{};
+            g.X = Y; g.ldx = D; g.W = w.qkvw; g.ldw = D; g.C = QK; g.ldc = 2 * D; g.bias = w.qkvb;
+            g.M = Mi; g.N = 2 * D; g.K = D;
+            if ((rc = fp_gemm_bf16(g, FP_EPI_BIAS, s))) return rc;
+            FpGemmArgs gv{};
+            gv.X = Y; gv.ldx = D; gv.W = w.qkvw + (size_t)2 * D * D; gv.ldw = D; gv.C = Vt; gv.ldc = 8;
+            gv.bias = w.qkvb + 2 * D; gv.M = Mi; gv.N = D; gv.K = D; gv.npad = npad; gv.heads = a.heads;
+            if ((rc = fp_gemm_bf16(gv, FP_EPI_VT, s))) return rc;
+            v->gemm_flops += 2.0 * Mi * 3.0 * D * D;
+        }
+        {
+            ProfScope ps(v, s, &v->ms_attn);
+            if ((rc = fp_attention_fwd(QK, 2 * D, Vt, AO, D, B, a.heads, n_tok, npad, s))) return rc;
+        }
+        {
+            ProfScope ps(v, s, &v->ms_gemm);
+            FpGemmArgs g{};
+            g.X = AO; g.ldx = D; g.W = w.projw; g.ldw = D; g.C = X; g.ldc = D; g.bias = w.projb;
+            g.gamma = w.ls1 ? w.ls1 : v->ones; g.resid = X; g.ldr = D; g.M = Mi; g.N = D; g.K = D;
+            if ((rc = fp_gemm_bf16(g, FP_EPI_BIAS_LS_RES, s))) return rc;
+            v->gemm_flops += 2.0 * Mi * (double)D * D;
+        }
+        {
+            ProfScope ps(v, s, &v->ms_other);
+            if ((rc = fp_layernorm(X, Y, w.n2w, w.n2b, Mi, D, a.ln_eps, 0, 0, 0, s))) return rc;
+        }
+        {
+            ProfScope ps(v, s, &v->ms_gemm);
+            FpGemmArgs g{};
+            g.X = Y; g.ldx = D; g.W = w.fc1w; g.ldw = D; g.C = H1; g.ldc = a.mlp_dim; g.bias = w.fc1b;
+            g.M = Mi; g.N = a.mlp_dim; g.K = D;
+            if ((rc = fp_gemm_bf16(g, FP_EPI_BIAS_GELU, s))) return rc;
+            FpGemmArgs g2{};
+            g2.X = H1; g2.ldx = a.mlp_dim; g2.W = w.fc2w; g2.ldw = a.mlp_dim; g2.C = X; g2.ldc = D; g2.bias = w.fc2b;
+            g2.gamma = w.ls2 ? w.ls2 : v->ones; g2.resid = X; g2.ldr = D; g2.M = Mi; g2.N = D; g2.K = a.mlp_dim;
+            if ((rc = fp_gemm_bf16(g2, FP_EPI_BIAS_LS_RES, s))) return rc;
+            v->gemm_flops += 4.0 * Mi * (double)D * a.mlp_dim;
+        }
+    }
+    // ---- K8: final norm + token slice (dino.py:23-30) ------------------------------------------------
+    {
+        ProfScope ps(v, s, &v->ms_other);
+        int rows_per_b, off;
+        if (feature_type == 0) { rows_per_b = 1; off = 0; }
+        else if (feature_type == 1) { rows_per_b = a.n_reg; off = 1; }
+        else { rows_per_b = P; off = 1 + a.n_reg; }
+        if (rows_per_b > 0)
+            if ((rc = fp_layernorm(X, (bf16_t*)d_out, v->normw, v->normb, B * rows_per_b, D, a.ln_eps, rows_per_b, npad,
+                                   off, s)))
+                return rc;
+    }
+    return FP_OK;
+}
+
+extern "C" int fp_vit_profile(fp_vit* v, int enable) {
+    FP_REQUIRE(v, "vit_profile: null");
+    if (enable && !v->ev[0]) {
+        FP_HIP(hipEventCreate(&v->ev[0]));
+        FP_HIP(hipEventCreate(&v->ev[1]));
+    }
+    v->prof = enable != 0;
+    v->ms_gemm = v->ms_attn = v->ms_other = 0;
+    v->gemm_flops = 0;
+    return FP_OK;
+}
+extern "C" int fp_vit_profile_read(fp_vit* v, float* g, float* at, float* o, double* fl) {
+    FP_REQUIRE(v, "vit_profile_read: null");
+    if (g) *g = v->ms_gemm;
+    if (at) *at = v->ms_attn;
+    if (o) *o = v->ms_other;
+    if (fl) *fl = v->gemm_flops;
+    return FP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FFA / retrieval / template score
+extern "C" int fp_ffa(fp_ctx* ctx, const void* d_feats, const uint8_t* d_mask, int B, int gh, int gw, int D, int cell,
+                      int normalize, void* d_out_bf16, float* d_out_f32, void* stream) {
+    FP_REQUIRE(ctx && d_feats && d_mask && (d_out_bf16 || d_out_f32), "ffa: null argument");
+    if (B == 0) return FP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    bf16_t* tmp = (bf16_t*)d_out_bf16;
+    int rc;
+    if (normalize || !tmp)
+        if ((rc = ctx->get("ffa.tmp", (size_t)B * D * 2, (void**)&tmp))) return rc;
+    if ((rc = fp_ffa_pool((const bf16_t*)d_feats, d_mask, tmp, normalize ? nullptr : d_out_f32, B, gh * gw, D, gh, gw,
+                          cell, s)))
+        return rc;
+    if (normalize) {
+        FP_REQUIRE(d_out_bf16, "ffa: normalize needs a bf16 output");
+        if ((rc = fp_l2norm_rows(tmp, (bf16_t*)d_out_bf16, B, D, s))) return rc;
+    }
+    return FP_OK;
+}
+
+extern "C" int fp_l2_normalize(fp_ctx* ctx, const void* x, int rows, int D, void* y, void* stream) {
+    FP_REQUIRE(ctx && x && y, "l2_normalize: null argument");
+    return fp_l2norm_rows((const bf16_t*)x, (bf16_t*)y, rows, D, (hipStream_t)stream);
+}
+
+extern "C" int fp_bank_prepare(fp_ctx* ctx, const float* d_bank_f32, int N, int D, void* d_bank_bf16, void* stream) {
+    FP_REQUIRE(ctx && d_bank_f32 && d_bank_bf16 && N > 0, "bank_prepare: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    bf16_t* tmp;
+    int rc;
+    if ((rc = ctx->get("bank.cast", (size_t)N * D * 2, (void**)&tmp))) return rc;
+    if ((rc = fp_cast_f32_bf16(d_bank_f32, tmp, (size_t)N * D, s))) return rc;
+    return fp_l2norm_rows(tmp, (bf16_t*)d_bank_bf16, N, D, s);
+}
+
+extern "C" int fp_bank_topk(fp_ctx* ctx, const void* d_bank, int N, int D, const void* d_queries, int Q, int k,
+                            int idx_offset, float* d_out_scores, int32_t* d_out_idx, void* stream) {
+    FP_REQUIRE(ctx && d_bank && d_queries && d_out_scores && d_out_idx, "bank_topk: null argument");
+    if (Q == 0) return FP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    uint16_t* keys;
+    int rc;
+    if ((rc = ctx->get("topk.keys", (size_t)Q * N * 2, (void**)&keys))) return rc;
+    if ((rc = fp_bank_scan((const bf16_t*)d_bank, (const bf16_t*)d_queries, keys, N, D, Q, s))) return rc;
+    return fp_topk_select(keys, N, Q, k, idx_offset, d_out_scores, d_out_idx, s);
+}
+
+extern "C" int fp_topk_merge(fp_ctx* ctx, const float* cs, const int32_t* ci, int Q, int C, int k, float* os,
+                             int32_t* oi, void* stream) {
+    FP_REQUIRE(ctx && cs && ci && os && oi, "topk_merge: null argument");
+    if (Q == 0) return FP_OK;
+    return fp_topk_merge_launch(cs, ci, Q, C, k, os, oi, (hipStream_t)stream);
+}
+
+extern "C" int fp_template_score(fp_ctx* ctx, const void* d_tmpl, const void* d_query, const float* d_weights, int T,
+                                 int P, int D, float* d_scores, void* stream) {
+    FP_REQUIRE(ctx && d_tmpl && d_query && d_scores, "template_score: null argument");
+    if (T == 0) return FP_OK;
+    float* dots;
+    int rc;
+    if ((rc = ctx->get("tmpl.dots", (size_t)T * P * 4, (void**)&dots))) return rc;
+    return fp_template_score_launch((const bf16_t*)d_tmpl, (const bf16_t*)d_query, d_weights, dots, d_scores, T, P, D,
+                                    (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel-level entry points
+extern "C" int fp_op_gemm(const void* X, int ldx, const void* W, int ldw, void* Cc, int ldc, const void* bias,
+                          const void* gamma, const void* resid, int ldr, int M, int N, int K, int epi, void* stream) {
+    FP_REQUIRE(X && W && Cc && bias, "op_gemm: null argument");
+    FP_REQUIRE(epi >= 0 && epi <= 2, "op_gemm: epi %d (0..2)", epi);
+    FpGemmArgs g{};
+    g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Cc; g.ldc = ldc;
+    g.bias = (const bf16_t*)bias; g.gamma = (const bf16_t*)gamma; g.resid = (const bf16_t*)resid; g.ldr = ldr;
+    g.M = M; g.N = N; g.K = K;
+    return fp_gemm_bf16(g, epi, (hipStream_t)stream);
+}
+extern "C" int fp_op_gemm_vt(const void* X, int ldx, const void* W, int ldw, void* Vt, const void* bias, int M, int N,
+                             int K, int npad, int heads, void* stream) {
+    FP_REQUIRE(X && W && Vt, "op_gemm_vt: null argument");
+    FpGemmArgs g{};
+    g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Vt; g.ldc = 8;
+    g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads;
+    return fp_gemm_bf16(g, FP_EPI_VT, (hipStream_t)stream);
+}
+extern "C" int fp_op_attention(const void* QK, int ldqk, const void* Vt, void* O, int ldo, int B, int H, int n_tok,
+                               int npad, void* stream) {
+    FP_REQUIRE(QK && Vt && O, "op_attention: null argument");
+    return fp_attention_fwd((const bf16_t*)QK, ldqk, (const bf16_t*)Vt, (bf16_t*)O, ldo, B, H, n_tok, npad,
+                            (hipStream_t)stream);
+}
+extern "C" int fp_op_layernorm(const void* X, void* Y, const void* g, const void* b, int rows, int D, float eps,
+                               void* stream) {
+    FP_REQUIRE(X && Y && g && b, "op_layernorm: null argument");
+    return fp_layernorm((const bf16_t*)X, (bf16_t*)Y, (const bf16_t*)g, (const bf16_t*)b, rows, D, eps, 0, 0, 0,
+                        (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// timers
+struct FpTimer { hipEvent_t a, b; };
+extern "C" int fp_timer_create(void** out) {
+    FP_REQUIRE(out, "timer_create: null");
+    FpTimer* t = new FpTimer();
+    FP_HIP(hipEventCreate(&t->a));
+    FP_HIP(hipEventCreate(&t->b));
+    *out = t;
+    return FP_OK;
+}
+extern "C" int fp_timer_start(void* t, void* s) { FP_HIP(hipEventRecord(((FpTimer*)t)->a, (hipStream_t)s)); return FP_OK; }
+extern "C" int fp_timer_stop(void* t, void* s) { FP_HIP(hipEventRecord(((FpTimer*)t)->b, (hipStream_t)s)); return FP_OK; }
+extern "C" int fp_timer_elapsed_ms(void* t, float* ms) {
+    FP_HIP(hipEventSynchronize(((FpTimer*)t)->b));
+    FP_HIP(hipEventElapsedTime(ms, ((FpTimer*)t)->a, ((FpTimer*)t)->b));
+    return FP_OK;
+}
+extern "C" int fp_timer_destroy(void* t) {
+    if (!t) return FP_OK;
+    (void)hipEventDestroy(((FpTimer*)t)->a);
+    (void)hipEventDestroy(((FpTimer*)t)->b);
+    delete (FpTimer*)t;
+    return FP_OK;
+}

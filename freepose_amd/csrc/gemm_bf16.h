@@ -1,0 +1,32 @@
+// bf16 MFMA GEMM for the ViT linear layers (K1,K3,K5,K6,K7 of SURVEY.md §2.3).
+//   C[M,N] = epilogue( X[M,K] · W[N,K]^T )      X, W, C bf16 row-major, fp32 accumulate.
+// W keeps the torch nn.Linear layout ([out,in]) so a DINOv2 state-dict tensor is used as-is.
+#pragma once
+#include "common.h"
+
+enum FpGemmEpi {
+    FP_EPI_BIAS = 0,        // C = acc + bias                           (QK part of qkv)
+    FP_EPI_BIAS_GELU = 1,   // C = gelu_erf(acc + bias)                 (fc1)
+    FP_EPI_BIAS_LS_RES = 2, // C = resid + gamma * (acc + bias)         (attn.proj / fc2 + LayerScale + residual)
+    FP_EPI_PATCH = 3,       // C[tokrow(m)] = bf16(acc + bias) + pos[p] (patch-embed -> token buffer)
+    FP_EPI_VT = 4           // Vt[b,h,d,t] = acc + bias                 (V part of qkv, stored transposed per head)
+};
+
+struct FpGemmArgs {
+    const bf16_t* X; int ldx;      // [M,K]
+    const bf16_t* W; int ldw;      // [N,K]
+    bf16_t* C; int ldc;            // [M,N] (or token buffer / Vt)
+    const bf16_t* bias;            // [N] or null
+    const bf16_t* gamma;           // [N] LayerScale
+    const bf16_t* resid; int ldr;  // [M,N]
+    int M, N, K;
+    // FP_EPI_PATCH: m = b*P + p  ->  row b*npad + tok_off + p ; pos is [P,N] bf16
+    const bf16_t* pos; int P; int npad; int tok_off;
+    // FP_EPI_VT: rows m = b*npad + t ; n = h*64 + d ; Vt is [B,H,64,npad]
+    int heads;
+};
+
+// Launch on `stream`. Returns FP_OK / error code (fp_last_error() has the text).
+int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream);
+// name of the kernel variant used for (epi) — for profiles / bench bookkeeping
+const char* fp_gemm_kernel_name(int epi);

@@ -1,0 +1,303 @@
+// bf16 MFMA GEMM with fused ViT epilogues, gfx950 only.
+//
+// Structure (one workgroup = BM x BN output tile, BK = 64 per pipeline stage):
+//   * both operand tiles are staged HBM -> LDS with global_load_lds (16 B/lane, no VGPR round trip);
+//     the LDS image is lane-linear, so the bank swizzle is applied to the per-lane SOURCE address and
+//     again on the ds_read address (same involution on both sides);
+//   * tiles are [rows][64 bf16] = 128-B rows; the 16-B slot index is XORed with a 3-bit key that is
+//     distinct for the rows one ds_read_b128 lane group touches -> conflict-free fragment reads;
+//   * MFMA is v_mfma_f32_16x16x32_bf16 in the SWAPPED form: the operand whose index must end up
+//     contiguous in a lane's accumulators (output features n for the normal epilogues, tokens m for
+//     the transposed V store) goes into the A slot with a PERMUTED row->fragment map, so one lane owns
+//     16 (or 32) consecutive outputs and the epilogue stores full 16-B vectors / 128-B lines;
+//   * double-buffered LDS, one barrier per K tile, next tile's DMA issued before the MFMA block;
+//   * XCD-aware tile order: consecutive tiles of one X row-panel stay on one XCD's L2.
+//
+// Reference op being replaced: the nn.Linear calls inside the hub DINOv2 blocks driven by
+// src/pipeline/retrieval/dino.py:16-23 (patch_embed.proj, attn.qkv, attn.proj, mlp.fc1, mlp.fc2).
+#include "gemm_bf16.h"
+
+namespace {
+
+constexpr int BK = 64;         // bf16 per K stage  (128-byte LDS rows)
+constexpr int ROWB = BK * 2;   // bytes per LDS row
+
+__device__ __forceinline__ int key_plain(int row) { return (row >> 1) & 7; }
+template <int T>
+__device__ __forceinline__ int key_perm(int row) {
+    const int rl = row % (16 * T);
+    const int a = rl / (4 * T);
+    const int b = rl & 3;
+    return ((a << 1) | (b >> 1)) & 7;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
+    constexpr bool TRANS = (EPI == FP_EPI_VT);
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 16;  // 16-row fragments of X per wave
+    constexpr int TN = BN / WN / 16;  // 16-row fragments of W per wave
+    // R operand = MFMA A slot (permuted rows, lane-contiguous outputs); C operand = B slot (plain)
+    constexpr int TR = TRANS ? TM : TN;
+    constexpr int TC = TRANS ? TN : TM;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int IX = BM / 8 / NW;  // glds instructions per wave per stage, X tile
+    constexpr int IW = BN / 8 / NW;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over waves");
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- XCD-aware tile order (bijective for any grid size) -----------------------------------
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
+    const int m0 = (bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+
+    // ---- per-lane DMA source offsets ------------------------------------------------------------
+    uint32_t offX[IX], offW[IW];
+#pragma unroll
+    for (int it = 0; it < IX; ++it) {
+        const int row = (it * NW + wave) * 8 + (lane >> 3);
+        const int key = TRANS ? key_perm<TM>(row) : key_plain(row);
+        const int ks = (lane & 7) ^ key;
+        const int rg = min(m0 + row, p.M - 1);
+        offX[it] = (uint32_t)rg * (uint32_t)p.ldx * 2u + ks * 16;
+    }
+#pragma unroll
+    for (int it = 0; it < IW; ++it) {
+        const int row = (it * NW + wave) * 8 + (lane >> 3);
+        const int key = TRANS ? key_plain(row) : key_perm<TN>(row);
+        const int ks = (lane & 7) ^ key;
+        const int rg = min(n0 + row, p.N - 1);
+        offW[it] = (uint32_t)rg * (uint32_t)p.ldw * 2u + ks * 16;
+    }
+    const char* gX = (const char*)p.X;
+    const char* gW = (const char*)p.W;
+
+    auto stage = [&](int buf, int kt) {
+        char* sb = smem + buf * STAGE;
+        const size_t kb = (size_t)kt * ROWB;
+#pragma unroll
+        for (int it = 0; it < IX; ++it)
+            glds16(gX + offX[it] + kb, sb + (it * NW + wave) * 1024);
+#pragma unroll
+        for (int it = 0; it < IW; ++it)
+            glds16(gW + offW[it] + kb, sb + BM * ROWB + (it * NW + wave) * 1024);
+    };
+
+    // ---- per-lane fragment read offsets (bytes inside a stage, before the k-step XOR) -----------
+    const int li = lane & 15, lg = lane >> 4;
+    // R operand rows: permuted  rl = (li>>2)*4*TR + 4*f + (li&3)
+    // C operand rows: plain     rl = 16*f + li
+    int rowR0, keyR, rowC0, keyC;
+    {
+        const int tile_r = TRANS ? wm * (16 * TM) : wn * (16 * TN);
+        const int tile_c = TRANS ? wn * (16 * TN) : wm * (16 * TM);
+        rowR0 = tile_r + (li >> 2) * 4 * TR + (li & 3);  // + 4*f
+        keyR = (((li >> 2) << 1) | ((li & 3) >> 1)) & 7;  // = key_perm(row) for every f
+        rowC0 = tile_c + li;                              // + 16*f
+        keyC = (li >> 1) & 7;                             // key_plain(16 f + li) = (li>>1)&7 | ((16f>>1)&7)=0
+    }
+    const int baseR = (TRANS ? 0 : BM * ROWB) + rowR0 * ROWB;
+    const int baseC = (TRANS ? BM * ROWB : 0) + rowC0 * ROWB;
+
+    f32x4_t acc[TC][TR];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        const char* sb = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fr[TR], fc[TC];
+            const int slotR = (((kk << 2) | lg) ^ keyR) << 4;
+            const int slotC = (((kk << 2) | lg) ^ keyC) << 4;
+#pragma unroll
+            for (int f = 0; f < TR; ++f)
+                fr[f] = *(const bf16x8_t*)(sb + baseR + f * 4 * ROWB + slotR);
+#pragma unroll
+            for (int f = 0; f < TC; ++f)
+                fc[f] = *(const bf16x8_t*)(sb + baseC + f * 16 * ROWB + slotC);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[j], fc[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    if constexpr (!TRANS) {
+        // lane owns, for each of its TM token rows, 4*TN consecutive output features
+        constexpr int RUN = 4 * TN;
+        static_assert(RUN == 16, "epilogue assumes 16 consecutive features per lane");
+        const int nb = n0 + wn * (16 * TN) + lg * RUN;
+        if (nb < p.N) {
+            float bias[RUN], gam[RUN];
+            {
+                const uint4* bp = (const uint4*)(p.bias + nb);
+                uint4 b0 = bp[0], b1 = bp[1];
+                const uint32_t w[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bias[2 * e] = lo_bf(w[e]); bias[2 * e + 1] = hi_bf(w[e]); }
+            }
+            if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
+                const uint4* gp = (const uint4*)(p.gamma + nb);
+                uint4 g0 = gp[0], g1 = gp[1];
+                const uint32_t w[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gam[2 * e] = lo_bf(w[e]); gam[2 * e + 1] = hi_bf(w[e]); }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * (16 * TM) + 16 * i + li;
+                if (m >= p.M) continue;
+                float v[RUN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
+                size_t orow = (size_t)m;
+                if constexpr (EPI == FP_EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < RUN; ++e) v[e] = gelu_erf(rbf(v[e]));
+                } else if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
+                    const uint4* rp = (const uint4*)(p.resid + (size_t)m * p.ldr + nb);
+                    uint4 r0 = rp[0], r1 = rp[1];
+                    const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        // reference rounding points: linear out -> bf16, *gamma -> bf16, +resid -> bf16
+                        v[2 * e] = lo_bf(w[e]) + rbf(gam[2 * e] * rbf(v[2 * e]));
+                        v[2 * e + 1] = hi_bf(w[e]) + rbf(gam[2 * e + 1] * rbf(v[2 * e + 1]));
+                    }
+                } else if constexpr (EPI == FP_EPI_PATCH) {
+                    const int b = m / p.P, pp = m - b * p.P;
+                    orow = (size_t)b * p.npad + p.tok_off + pp;
+                    const uint4* pp4 = (const uint4*)(p.pos + (size_t)pp * p.N + nb);
+                    uint4 q0 = pp4[0], q1 = pp4[1];
+                    const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[2 * e] = rbf(v[2 * e]) + lo_bf(w[e]);
+                        v[2 * e + 1] = rbf(v[2 * e + 1]) + hi_bf(w[e]);
+                    }
+                }
+                uint4 o0, o1;
+                o0.x = pack_bf2(v[0], v[1]);   o0.y = pack_bf2(v[2], v[3]);
+                o0.z = pack_bf2(v[4], v[5]);   o0.w = pack_bf2(v[6], v[7]);
+                o1.x = pack_bf2(v[8], v[9]);   o1.y = pack_bf2(v[10], v[11]);
+                o1.z = pack_bf2(v[12], v[13]); o1.w = pack_bf2(v[14], v[15]);
+                uint4* op = (uint4*)(p.C + orow * p.ldc + nb);
+                op[0] = o0;
+                op[1] = o1;
+            }
+        }
+    } else {
+        // transposed V store: lane owns, for each of its TN features, 4*TM consecutive tokens
+        constexpr int RUN = 4 * TM;
+        static_assert(RUN % 16 == 0, "token runs are stored in 16-token groups");
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + wn * (16 * TN) + 16 * i + li;
+            if (n >= p.N) continue;
+            const float bias = p.bias ? bf2f(p.bias[n]) : 0.f;
+            const int h = n >> 6, d = n & 63;
+#pragma unroll
+            for (int half = 0; half < RUN / 16; ++half) {
+                const int m16 = m0 + wm * (16 * TM) + lg * RUN + half * 16;
+                if (m16 >= p.M) continue;
+                const int b = m16 / p.npad, t = m16 - b * p.npad;
+                float v[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][half * 4 + j][r] + bias;
+                uint4 o0, o1;
+                o0.x = pack_bf2(v[0], v[1]);   o0.y = pack_bf2(v[2], v[3]);
+                o0.z = pack_bf2(v[4], v[5]);   o0.w = pack_bf2(v[6], v[7]);
+                o1.x = pack_bf2(v[8], v[9]);   o1.y = pack_bf2(v[10], v[11]);
+                o1.z = pack_bf2(v[12], v[13]); o1.w = pack_bf2(v[14], v[15]);
+                uint4* op = (uint4*)(p.C + (((size_t)b * p.heads + h) * 64 + d) * p.npad + t);
+                op[0] = o0;
+                op[1] = o1;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int SMEM = 2 * STAGE;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set = true;
+    }
+    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), SMEM, stream, a);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+template <int EPI>
+int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
+    // big tile once the grid can fill the chip with it, else the 128x128 tile
+    const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
+    if (tiles_big >= 192) return launch_cfg<256, 256, 2, 4, EPI>(a, stream);
+    return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
+}
+
+}  // namespace
+
+int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream) {
+    FP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    FP_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
+    FP_REQUIRE(a.N % 16 == 0, "gemm: N=%d must be a multiple of 16", a.N);
+    FP_REQUIRE(((size_t)a.M * a.ldx * 2) < 0xffffffffull && ((size_t)a.N * a.ldw * 2) < 0xffffffffull,
+               "gemm: operand larger than 4 GiB (M=%d ldx=%d)", a.M, a.ldx);
+    FP_REQUIRE((a.ldx % 8) == 0 && (a.ldw % 8) == 0 && (a.ldc % 8) == 0, "gemm: leading dims must be multiples of 8");
+    switch (epi) {
+        case FP_EPI_BIAS: return launch_epi<FP_EPI_BIAS>(a, stream);
+        case FP_EPI_BIAS_GELU: return launch_epi<FP_EPI_BIAS_GELU>(a, stream);
+        case FP_EPI_BIAS_LS_RES:
+            FP_REQUIRE(a.gamma && a.resid, "gemm: LS_RES epilogue needs gamma and resid");
+            return launch_epi<FP_EPI_BIAS_LS_RES>(a, stream);
+        case FP_EPI_PATCH:
+            FP_REQUIRE(a.pos && a.P > 0 && a.npad > 0, "gemm: PATCH epilogue needs pos/P/npad");
+            return launch_epi<FP_EPI_PATCH>(a, stream);
+        case FP_EPI_VT:
+            FP_REQUIRE(a.npad % 16 == 0 && a.M % 16 == 0 && a.heads > 0 && a.N == a.heads * 64,
+                       "gemm: VT epilogue needs npad%%16==0, M%%16==0, N==heads*64");
+            return launch_epi<FP_EPI_VT>(a, stream);
+        default: fp_set_error("gemm: unknown epilogue %d", epi); return FP_ERR_INVALID;
+    }
+}
+
+const char* fp_gemm_kernel_name(int epi) {
+    (void)epi;
+    return "gemm_bf16_kernel";
+}

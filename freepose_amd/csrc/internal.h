@@ -1,0 +1,42 @@
+// internal launcher prototypes shared by the C-ABI translation units
+#pragma once
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "gemm_bf16.h"
+
+struct fp_ctx {
+    int device = 0;
+    // named, grow-only workspaces (device memory).  One context per thread/GPU, no locking.
+    struct Buf { void* p = nullptr; size_t bytes = 0; };
+    std::map<std::string, Buf> bufs;
+    int get(const char* name, size_t bytes, void** out);
+    size_t total() const;
+    void release();
+};
+
+// attention.hip
+int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, int ldo, int B, int H, int n_tok,
+                     int npad, hipStream_t stream);
+// vit_misc.hip
+int fp_im2col_norm(const bf16_t* img, bf16_t* A, int B, int H, int W, int ps, int KP, hipStream_t s);
+int fp_token_init(bf16_t* X, const bf16_t* cls, const bf16_t* pos0, const bf16_t* reg, int nreg, int B, int n_tok,
+                  int npad, int D, hipStream_t s);
+int fp_layernorm(const bf16_t* X, bf16_t* Y, const bf16_t* gamma, const bf16_t* beta, int rows, int D, float eps,
+                 int rows_per_b, int in_stride_b, int in_off, hipStream_t s);
+int fp_posembed_aa(const bf16_t* src, bf16_t* dst, int G, int gh, int gw, int D, hipStream_t s);
+int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* out_f32, int B, int P, int D, int gh,
+                int gw, int cell, hipStream_t s);
+int fp_l2norm_rows(const bf16_t* X, bf16_t* Y, int rows, int D, hipStream_t s);
+// retrieval.hip
+int fp_cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s);
+int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int N, int D, int Q, hipStream_t s);
+int fp_topk_select(const uint16_t* keys, int N, int Q, int k, int idx_offset, float* out_scores, int* out_idx,
+                   hipStream_t s);
+int fp_topk_merge_launch(const float* cs, const int* ci, int Q, int C, int k, float* out_scores, int* out_idx,
+                         hipStream_t s);
+int fp_template_score_launch(const bf16_t* tmpl, const bf16_t* qn, const float* weights, float* dots, float* scores,
+                             int T, int P, int D, hipStream_t s);

@@ -1,0 +1,277 @@
+// Pose-side kernels (K14, K16, K17, K18 of SURVEY.md §2.3), gfx950 only.  Integer / byte streaming work.
+//   crop_resize_pad : CropResizePad.__call__ (src/utils/bbox_utils.py:20-56) with torch's nearest
+//                     index rule  src = min(floorf(dst * float(1/scale)), in-1)
+//   geodesic_select : DinoOnlinePoseEstimator.geodesic_distance + np.where(dists < n)
+//                     (src/pipeline/estimators/online_pose_estimator.py:25-34,55-56)
+//   depth_extents   : mask/bbox of a rendered depth map (renderer.py:112-119, template.py:73-78) and the
+//                     x/y extents of depthmap_to_pointcloud (src/pipeline/utils.py:122-145,157-158)
+#include "internal.h"
+
+namespace {
+
+struct CropParam {
+    int x0, y0, cw, ch;     // crop window (after extension / clipping)
+    int h1, w1;             // size after the first nearest resize
+    int pad_t, pad_l;       // centre padding (0 when the crop is square)
+    int S_h, S_w;           // size before the final resize
+    float inv1, inv2;       // float(1/scale) of both interpolate calls
+    int out;                // final side (must equal target)
+};
+
+// one thread per box: integer/float32/float64 arithmetic exactly as the Python reference evaluates it
+__global__ void crop_params_kernel(const int32_t* __restrict__ boxes, int n, int H, int W, float ext, int ext_is_zero,
+                                   int target, CropParam* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x0 = boxes[4 * i + 0], y0 = boxes[4 * i + 1], x1 = boxes[4 * i + 2], y1 = boxes[4 * i + 3];
+    const int bw = x1 - x0, bh = y1 - y0;
+    if (ext_is_zero) {  // int arithmetic: max(0, x0 - 0*bw) ...
+        x0 = max(0, x0); x1 = min(W, x1); y0 = max(0, y0); y1 = min(H, y1);
+    } else {            // float32 tensor arithmetic, assignment into an int tensor truncates toward zero
+        const float ew = ext * (float)bw, eh = ext * (float)bh;
+        const float fx0 = (float)x0 - ew, fx1 = (float)x1 + ew, fy0 = (float)y0 - eh, fy1 = (float)y1 + eh;
+        x0 = (fx0 > 0.f) ? (int)fx0 : 0;          // Python max(0, t): t only if t > 0
+        x1 = (fx1 < (float)W) ? (int)fx1 : W;     // Python min(w, t): t only if t < w
+        y0 = (fy0 > 0.f) ? (int)fy0 : 0;
+        y1 = (fy1 < (float)H) ? (int)fy1 : H;
+    }
+    CropParam p;
+    p.x0 = x0; p.y0 = y0; p.cw = x1 - x0; p.ch = y1 - y0;
+    const int side = max(p.cw, p.ch);
+    // `target_max / int_tensor` is Tensor.__rtruediv__ = reciprocal(tensor) * scalar in float32 (two roundings)
+    const float scale_f32 = __fmul_rn(__frcp_rn((float)side), (float)target);
+    const double scale = (double)scale_f32;               // .item()
+    p.h1 = (int)floor((double)p.ch * scale);
+    p.w1 = (int)floor((double)p.cw * scale);
+    p.inv1 = (float)(1.0 / scale);
+    const double ratio = (double)p.w1 / (double)p.h1;
+    if (ratio != 1.0) {
+        p.pad_t = max((target - p.h1) / 2, 0);   // Python // on non-negative values
+        p.pad_l = max((target - p.w1) / 2, 0);
+        if (target - p.h1 < 0) p.pad_t = 0;
+        if (target - p.w1 < 0) p.pad_l = 0;
+        p.S_h = target; p.S_w = target;
+    } else {
+        p.pad_t = 0; p.pad_l = 0; p.S_h = p.h1; p.S_w = p.w1;
+    }
+    const double scale2 = (double)target / (double)p.S_h;
+    p.out = (int)floor((double)p.S_h * scale2);
+    p.inv2 = (float)(1.0 / scale2);
+    out[i] = p;
+}
+
+template <int SRC_U8, int OUT_BF16>
+__global__ __launch_bounds__(256) void crop_kernel(const void* __restrict__ images, int n_img, int C, int H, int W,
+                                                   const CropParam* __restrict__ params, int target,
+                                                   const uint8_t* __restrict__ masks, int mask_mode,
+                                                   void* __restrict__ outp) {
+    const int i = blockIdx.z;
+    const CropParam p = params[i];
+    const int img = (n_img == 1) ? 0 : i;
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    const int oy = blockIdx.y;
+    if (ox >= target) return;
+    bool valid = (p.out == target) && p.cw > 0 && p.ch > 0;
+    int ys = 0, xs = 0;
+    if (valid) {
+        const int y2 = min((int)floorf((float)oy * p.inv2), p.S_h - 1);
+        const int x2 = min((int)floorf((float)ox * p.inv2), p.S_w - 1);
+        const int y1 = y2 - p.pad_t, x1 = x2 - p.pad_l;
+        if (y1 < 0 || y1 >= p.h1 || x1 < 0 || x1 >= p.w1) valid = false;
+        else {
+            ys = p.y0 + min((int)floorf((float)y1 * p.inv1), p.ch - 1);
+            xs = p.x0 + min((int)floorf((float)x1 * p.inv1), p.cw - 1);
+        }
+    }
+    float m = 1.f;
+    if (valid && masks && mask_mode != 0) m = masks[((size_t)i * H + ys) * W + xs] ? 1.f : 0.f;
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+        if (valid) {
+            if (mask_mode == 2) v = m;
+            else {
+                if (SRC_U8) v = (float)((double)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c] / 255.0);
+                else v = ((const float*)images)[(((size_t)img * C + c) * H + ys) * W + xs];
+                v *= m;
+            }
+        }
+        const size_t o = (((size_t)i * C + c) * target + oy) * target + ox;
+        if (OUT_BF16) ((bf16_t*)outp)[o] = f2bf(v);
+        else ((float*)outp)[o] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void geodesic_flags_kernel(const double* __restrict__ grid, int G, const double* __restrict__ Rp,
+                                      double thresh_deg, int32_t* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G) return;
+    double R[9], D[9];
+    for (int k = 0; k < 9; ++k) R[k] = grid[(size_t)i * 9 + k];
+    // D = R_i * Rp^T
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) D[3 * r + c] = R[3 * r] * Rp[3 * c] + R[3 * r + 1] * Rp[3 * c + 1] + R[3 * r + 2] * Rp[3 * c + 2];
+    const double cosv = 0.5 * (D[0] + D[4] + D[8] - 1.0);
+    const double a = D[7] - D[5], b = D[2] - D[6], c = D[3] - D[1];
+    const double sinv = 0.5 * sqrt(a * a + b * b + c * c);
+    const double ang = atan2(sinv, cosv) * 57.29577951308232;
+    flags[i] = ang < thresh_deg ? 1 : 0;
+}
+// single-block ordered compaction of flags -> ascending indices
+__global__ __launch_bounds__(1024) void compact_flags_kernel(const int32_t* __restrict__ flags, int G,
+                                                             int32_t* __restrict__ out_idx, int* __restrict__ out_n) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < G; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int f = (i < G) ? flags[i] : 0;
+        int x = f;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int pre = carry;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (f) out_idx[pre + x - 1] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; ++k) t += wsum[k]; carry += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_n = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one block per view: count, bbox of (depth > 0) with the <100 px fallback square, fp64 extents
+__global__ __launch_bounds__(256) void depth_extents_kernel(const float* __restrict__ depth, int Hh, int W, double fx,
+                                                            double fy, double cx, double cy, float* __restrict__ out) {
+    const int v = blockIdx.x;
+    const float* d = depth + (size_t)v * Hh * W;
+    int cnt = 0, xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1;
+    double Xmin = 1e300, Xmax = -1e300, Ymin = 1e300, Ymax = -1e300;
+    for (int i = threadIdx.x; i < Hh * W; i += blockDim.x) {
+        const float z = d[i];
+        if (z != 0.f) {  // depthmap_to_pointcloud keeps every row that is not all-zero
+            const int y = i / W, x = i - y * W;
+            const double X = ((double)x - cx) / fx * (double)z, Y = ((double)y - cy) / fy * (double)z;
+            Xmin = fmin(Xmin, X); Xmax = fmax(Xmax, X); Ymin = fmin(Ymin, Y); Ymax = fmax(Ymax, Y);
+            if (z > 0.f) { ++cnt; xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y); }
+        }
+    }
+    __shared__ int si[5][256];
+    __shared__ double sd[4][256];
+    const int t = threadIdx.x;
+    si[0][t] = cnt; si[1][t] = xmin; si[2][t] = ymin; si[3][t] = xmax; si[4][t] = ymax;
+    sd[0][t] = Xmin; sd[1][t] = Xmax; sd[2][t] = Ymin; sd[3][t] = Ymax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            si[0][t] += si[0][t + s];
+            si[1][t] = min(si[1][t], si[1][t + s]); si[2][t] = min(si[2][t], si[2][t + s]);
+            si[3][t] = max(si[3][t], si[3][t + s]); si[4][t] = max(si[4][t], si[4][t + s]);
+            sd[0][t] = fmin(sd[0][t], sd[0][t + s]); sd[1][t] = fmax(sd[1][t], sd[1][t + s]);
+            sd[2][t] = fmin(sd[2][t], sd[2][t + s]); sd[3][t] = fmax(sd[3][t], sd[3][t + s]);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        int c = si[0][0], bx0 = si[1][0], by0 = si[2][0], bx1 = si[3][0], by1 = si[4][0];
+        if (c < 100) {  // mask[105:315, 105:315] = True  (renderer.py:116-117, template.py:75-77)
+            const int lo = 105, hx = min(315, W) - 1, hy = min(315, Hh) - 1;
+            if (c == 0) { bx0 = lo; by0 = lo; bx1 = hx; by1 = hy; }
+            else { bx0 = min(bx0, lo); by0 = min(by0, lo); bx1 = max(bx1, hx); by1 = max(by1, hy); }
+        }
+        float* o = out + (size_t)v * 8;
+        o[0] = (float)bx0; o[1] = (float)by0; o[2] = (float)bx1; o[3] = (float)by1;
+        o[4] = c > 0 || sd[1][0] > -1e299 ? (float)(sd[1][0] - sd[0][0]) : 0.f;
+        o[5] = c > 0 || sd[3][0] > -1e299 ? (float)(sd[3][0] - sd[2][0]) : 0.f;
+        o[6] = (float)c; o[7] = 0.f;
+    }
+}
+
+}  // namespace
+
+int fp_crop_resize_pad_launch(const void* images, int src_u8, int n_img, int C, int H, int W, const int32_t* boxes,
+                              int n, float bbox_extend, int target, const uint8_t* masks, int mask_mode, void* out,
+                              int out_bf16, CropParam* params, hipStream_t s) {
+    hipLaunchKernelGGL(crop_params_kernel, dim3(cdiv(n, 64)), dim3(64), 0, s, boxes, n, H, W, bbox_extend,
+                       bbox_extend == 0.f ? 1 : 0, target, params);
+    FP_LAUNCH_CHECK();
+    dim3 grid(cdiv(target, 256), target, n), block(256);
+#define FP_CROP(U, O) hipLaunchKernelGGL((crop_kernel<U, O>), grid, block, 0, s, images, n_img, C, H, W, params, target, masks, mask_mode, out)
+    if (src_u8) { if (out_bf16) FP_CROP(1, 1); else FP_CROP(1, 0); }
+    else { if (out_bf16) FP_CROP(0, 1); else FP_CROP(0, 0); }
+#undef FP_CROP
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+#include "../../include/freepose_hip.h"
+
+extern "C" int fp_crop_resize_pad(fp_ctx* ctx, const void* d_images, int src_fmt, int n_img, int C, int H, int W,
+                                  const int32_t* d_boxes, int n, float bbox_extend, int target, const uint8_t* d_masks,
+                                  int mask_mode, void* d_out, int out_fmt, void* stream) {
+    FP_REQUIRE(ctx && d_images && d_boxes && d_out, "crop_resize_pad: null argument");
+    FP_REQUIRE(n_img == 1 || n_img == n, "crop_resize_pad: n_img must be 1 or n");
+    FP_REQUIRE(mask_mode == 0 || d_masks, "crop_resize_pad: mask_mode %d needs masks", mask_mode);
+    if (n == 0) return FP_OK;
+    CropParam* params;
+    int rc;
+    if ((rc = ctx->get("crop.params", (size_t)n * sizeof(CropParam), (void**)&params))) return rc;
+    return fp_crop_resize_pad_launch(d_images, src_fmt, n_img, C, H, W, d_boxes, n, bbox_extend, target, d_masks,
+                                     mask_mode, d_out, out_fmt, params, (hipStream_t)stream);
+}
+
+extern "C" int fp_geodesic_select(fp_ctx* ctx, const double* d_grid, int G, const double* h_R, double thresh_deg,
+                                  int32_t* d_out_idx, int* h_n, void* stream) {
+    FP_REQUIRE(ctx && d_grid && h_R && d_out_idx && h_n, "geodesic_select: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws;
+    int rc;
+    if ((rc = ctx->get("geo.ws", (size_t)G * 4 + 256, (void**)&ws))) return rc;
+    double* Rp = (double*)ws;             // 9 doubles
+    int* dn = (int*)(ws + 128);
+    int32_t* flags = (int32_t*)(ws + 256);
+    double Rd[9];
+    for (int i = 0; i < 9; ++i) Rd[i] = h_R[i];
+    FP_HIP(hipMemcpyAsync(Rp, Rd, sizeof(Rd), hipMemcpyHostToDevice, s));
+    FP_HIP(hipStreamSynchronize(s));  // Rd is a stack buffer
+    hipLaunchKernelGGL(geodesic_flags_kernel, dim3(cdiv(G, 256)), dim3(256), 0, s, d_grid, G, Rp, thresh_deg, flags);
+    FP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, s, flags, G, d_out_idx, dn);
+    FP_LAUNCH_CHECK();
+    FP_HIP(hipMemcpyAsync(h_n, dn, sizeof(int), hipMemcpyDeviceToHost, s));
+    FP_HIP(hipStreamSynchronize(s));
+    return FP_OK;
+}
+
+extern "C" int fp_depth_extents(fp_ctx* ctx, const float* d_depth, int Hn, int Hh, int W, float fx, float fy, float cx,
+                                float cy, float* d_out, void* stream) {
+    FP_REQUIRE(ctx && d_depth && d_out, "depth_extents: null argument");
+    if (Hn == 0) return FP_OK;
+    hipLaunchKernelGGL(depth_extents_kernel, dim3(Hn), dim3(256), 0, (hipStream_t)stream, d_depth, Hh, W, (double)fx,
+                       (double)fy, (double)cx, (double)cy, d_out);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+extern "C" int fp_generate_rotations(int n, double* out) {
+    FP_REQUIRE(n > 0 && out, "generate_rotations: bad argument");
+    // super-Fibonacci spiral on SO(3) (pose_estimator.py:121-147); scalar-last quaternion -> matrix
+    const double phi = sqrt(2.0), psi = 1.533751168755204288118041, PI = 3.14159265358979323846;
+    for (int i = 0; i < n; ++i) {
+        const double s = i + 0.5, r = sqrt(s / n), Rr = sqrt(1.0 - s / n);
+        const double al = 2.0 * PI * s / phi, be = 2.0 * PI * s / psi;
+        double x = r * sin(al), y = r * cos(al), z = Rr * sin(be), w = Rr * cos(be);
+        const double nn = sqrt(x * x + y * y + z * z + w * w);
+        x /= nn; y /= nn; z /= nn; w /= nn;
+        double* M = out + (size_t)i * 9;
+        const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w, xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+        M[0] = x2 - y2 - z2 + w2; M[1] = 2 * (xy - zw);      M[2] = 2 * (xz + yw);
+        M[3] = 2 * (xy + zw);     M[4] = -x2 + y2 - z2 + w2; M[5] = 2 * (yz - xw);
+        M[6] = 2 * (xz - yw);     M[7] = 2 * (yz + xw);      M[8] = -x2 - y2 + z2 + w2;
+    }
+    return FP_OK;
+}

@@ -1,0 +1,272 @@
+// Pose-hypothesis rasteriser (K15 of SURVEY.md §2.3), gfx950 only.  Replaces pyrender's OpenGL path used by
+// MeshRenderer.render_from_poses (src/pipeline/retrieval/renderer.py:70-95): one mesh, Hn poses, pinhole
+// intrinsics, ambient-only shading, no face culling, rgb u8 + metric eye-depth f32 (0 = background).
+//
+// Arithmetic contract (shared with oracle/fp_oracle.c, every step fp32 IEEE unless noted):
+//   vertex : s = scale*v ; Xc = fma(R00,sx, fma(R01,sy, fma(R02,sz, tx))) (same for Yc, Zc)
+//            iz = 1/Zc ; u = fma(fx, Xc*iz, cx) ; v = fma(fy, Yc*iz, cy)
+//            fixed point 24.8 : xi = rint(u*256), yi = rint(v*256)      (image coords, y down)
+//   a triangle with any Zc <= znear (0.05) is dropped (no clipping; objects sit at z ~ 1.1 m)
+//   coverage: sample (256 px + 128, 256 py + 128); int64 edge functions; orientation normalised by
+//            swapping v1,v2 when the doubled area is negative (SKIP_CULL_FACES); top-left rule on ties
+//   depth  : b_i = float(E_i)/float(area2) ; izp = fma(b2,iz2, fma(b1,iz1, b0*iz0)) ; depth = 1/izp
+//   visibility: 64-bit key (depth bits << 32 | triangle id), atomic MIN -> nearest depth, lowest id on
+//            exact ties; order independent, hence deterministic
+//   colour : per-vertex RGB, perspective-correct: c = fma(b2*iz2,c2, fma(b1*iz1,c1,(b0*iz0)*c0)) * depth
+//            out = (u8) min(255, 2*c + 0.5)        (ambient (2,2,2) saturates, renderer.py:53-55)
+// Launch shape: vertex kernel (Hn x V threads), triangle kernel (Hn x F threads; small triangles are
+// rasterised by their thread, large ones by a whole wave via a queue), resolve kernel (Hn x pixels).
+#include "../../include/freepose_hip.h"
+#include "internal.h"
+
+struct fp_mesh {
+    fp_ctx* ctx = nullptr;
+    float* verts = nullptr;    // [V,3]
+    int32_t* faces = nullptr;  // [F,3]
+    uint8_t* colors = nullptr; // [V,4] rgba (a unused)
+    int V = 0, F = 0;
+};
+
+namespace {
+
+struct SVert { int xi, yi; float iz, zc; };
+struct RasterView { float R[9]; float t[3]; };
+
+constexpr float ZNEAR = 0.05f;
+constexpr int BIG_AREA = 256;  // bbox pixels above which a triangle goes to the wave-per-triangle queue
+
+__global__ void raster_vertex_kernel(const float* __restrict__ verts, int V, const float* __restrict__ poses, int Hn,
+                                     float scale, float fx, float fy, float cx, float cy, SVert* __restrict__ sv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (i >= V) return;
+    const float* P = poses + (size_t)h * 16;
+    const float sx = scale * verts[3 * i], sy = scale * verts[3 * i + 1], sz = scale * verts[3 * i + 2];
+    const float Xc = fmaf(P[0], sx, fmaf(P[1], sy, fmaf(P[2], sz, P[3])));
+    const float Yc = fmaf(P[4], sx, fmaf(P[5], sy, fmaf(P[6], sz, P[7])));
+    const float Zc = fmaf(P[8], sx, fmaf(P[9], sy, fmaf(P[10], sz, P[11])));
+    SVert o;
+    o.zc = Zc;
+    if (Zc > ZNEAR) {
+        const float iz = 1.0f / Zc;
+        const float u = fmaf(fx, Xc * iz, cx), v = fmaf(fy, Yc * iz, cy);
+        // clamp far-off-screen coordinates so the fixed-point products stay inside int64
+        const float uc = fminf(fmaxf(u, -30000.f), 30000.f), vc = fminf(fmaxf(v, -30000.f), 30000.f);
+        o.xi = (int)rintf(uc * 256.0f);
+        o.yi = (int)rintf(vc * 256.0f);
+        o.iz = iz;
+    } else {
+        o.xi = 0; o.yi = 0; o.iz = 0.f;
+    }
+    sv[(size_t)h * V + i] = o;
+}
+
+struct TriSetup {
+    int x0, y0, x1, y1, x2, y2;
+    float iz0, iz1, iz2;
+    long long area2;
+    int bx0, by0, bx1, by1;  // pixel bbox, inclusive, clipped
+    int i0, i1, i2;          // vertex ids after orientation normalisation
+    bool ok;
+};
+
+__device__ __forceinline__ bool topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
+
+__device__ __forceinline__ TriSetup tri_setup(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, int f,
+                                              int W, int Hh) {
+    TriSetup t;
+    int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    SVert a = sv[i0], b = sv[i1], c = sv[i2];
+    t.ok = (a.zc > ZNEAR) && (b.zc > ZNEAR) && (c.zc > ZNEAR);
+    long long area2 = (long long)(b.xi - a.xi) * (c.yi - a.yi) - (long long)(b.yi - a.yi) * (c.xi - a.xi);
+    if (area2 < 0) {
+        SVert tmp = b; b = c; c = tmp;
+        int ti = i1; i1 = i2; i2 = ti;
+        area2 = -area2;
+    }
+    t.area2 = area2;
+    if (area2 == 0) t.ok = false;
+    t.x0 = a.xi; t.y0 = a.yi; t.x1 = b.xi; t.y1 = b.yi; t.x2 = c.xi; t.y2 = c.yi;
+    t.iz0 = a.iz; t.iz1 = b.iz; t.iz2 = c.iz;
+    t.i0 = i0; t.i1 = i1; t.i2 = i2;
+    const int mnx = min(a.xi, min(b.xi, c.xi)), mxx = max(a.xi, max(b.xi, c.xi));
+    const int mny = min(a.yi, min(b.yi, c.yi)), mxy = max(a.yi, max(b.yi, c.yi));
+    // pixel p is a candidate when its centre 256p+128 lies in [mn, mx]
+    t.bx0 = max(0, (mnx - 128 + 255) >> 8);
+    t.by0 = max(0, (mny - 128 + 255) >> 8);
+    t.bx1 = min(W - 1, (mxx - 128) >> 8);
+    t.by1 = min(Hh - 1, (mxy - 128) >> 8);
+    if (t.bx1 < t.bx0 || t.by1 < t.by0) t.ok = false;
+    return t;
+}
+
+// edge functions at the pixel centre; returns coverage and the three (non-negative) weights
+__device__ __forceinline__ bool tri_cover(const TriSetup& t, int px, int py, long long& w0, long long& w1, long long& w2) {
+    const long long sx = (long long)px * 256 + 128, sy = (long long)py * 256 + 128;
+    // E_ab(p) = (bx-ax)(py-ay) - (by-ay)(px-ax); positive inside for area2 > 0
+    w0 = (long long)(t.x2 - t.x1) * (sy - t.y1) - (long long)(t.y2 - t.y1) * (sx - t.x1);  // opposite v0
+    w1 = (long long)(t.x0 - t.x2) * (sy - t.y2) - (long long)(t.y0 - t.y2) * (sx - t.x2);  // opposite v1
+    w2 = (long long)(t.x1 - t.x0) * (sy - t.y0) - (long long)(t.y1 - t.y0) * (sx - t.x0);  // opposite v2
+    if (w0 < 0 || w1 < 0 || w2 < 0) return false;
+    if (w0 == 0 && !topleft(t.x2 - t.x1, t.y2 - t.y1)) return false;
+    if (w1 == 0 && !topleft(t.x0 - t.x2, t.y0 - t.y2)) return false;
+    if (w2 == 0 && !topleft(t.x1 - t.x0, t.y1 - t.y0)) return false;
+    return true;
+}
+
+__device__ __forceinline__ float tri_depth(const TriSetup& t, long long w0, long long w1, long long w2, float& b0,
+                                           float& b1, float& b2) {
+    const float fa = (float)t.area2;
+    b0 = (float)w0 / fa; b1 = (float)w1 / fa; b2 = (float)w2 / fa;
+    const float izp = fmaf(b2, t.iz2, fmaf(b1, t.iz1, b0 * t.iz0));
+    return 1.0f / izp;
+}
+
+__device__ __forceinline__ void tri_pixel(const TriSetup& t, int f, int px, int py, unsigned long long* __restrict__ zb,
+                                          int W) {
+    long long w0, w1, w2;
+    if (!tri_cover(t, px, py, w0, w1, w2)) return;
+    float b0, b1, b2;
+    const float d = tri_depth(t, w0, w1, w2, b0, b1, b2);
+    if (!(d > 0.f)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)f;
+    atomicMin(&zb[(size_t)py * W + px], key);
+}
+
+__global__ __launch_bounds__(256) void raster_tri_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
+                                                         int V, int F, int W, int Hh,
+                                                         unsigned long long* __restrict__ zb_all,
+                                                         int* __restrict__ queue, int* __restrict__ qcount, int qcap) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.y;
+    if (f >= F) return;
+    const SVert* sv = sv_all + (size_t)h * V;
+    unsigned long long* zb = zb_all + (size_t)h * W * Hh;
+    const TriSetup t = tri_setup(sv, faces, f, W, Hh);
+    if (!t.ok) return;
+    const int area = (t.bx1 - t.bx0 + 1) * (t.by1 - t.by0 + 1);
+    if (area > BIG_AREA) {
+        const int slot = atomicAdd(qcount, 1);
+        if (slot < qcap) { queue[2 * slot] = h; queue[2 * slot + 1] = f; return; }
+        // queue full: fall through and rasterise here (slow but correct)
+    }
+    for (int py = t.by0; py <= t.by1; ++py)
+        for (int px = t.bx0; px <= t.bx1; ++px) tri_pixel(t, f, px, py, zb, W);
+}
+
+// one wave per queued (view, triangle): lanes stride over the bbox pixels
+__global__ __launch_bounds__(256) void raster_big_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
+                                                         int V, int W, int Hh, unsigned long long* __restrict__ zb_all,
+                                                         const int* __restrict__ queue, const int* __restrict__ qcount,
+                                                         int qcap) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int n = min(*qcount, qcap);
+    for (int q = wave; q < n; q += nwave) {
+        const int h = queue[2 * q], f = queue[2 * q + 1];
+        const TriSetup t = tri_setup(sv_all + (size_t)h * V, faces, f, W, Hh);
+        unsigned long long* zb = zb_all + (size_t)h * W * Hh;
+        const int bw = t.bx1 - t.bx0 + 1, bh = t.by1 - t.by0 + 1;
+        for (int i = lane; i < bw * bh; i += 64) tri_pixel(t, f, t.bx0 + i % bw, t.by0 + i / bw, zb, W);
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __restrict__ sv_all,
+                                                             const int32_t* __restrict__ faces,
+                                                             const uint8_t* __restrict__ colors, int V, int W, int Hh,
+                                                             const unsigned long long* __restrict__ zb_all,
+                                                             uint8_t* __restrict__ rgb, float* __restrict__ depth) {
+    const int h = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= W * Hh) return;
+    const unsigned long long key = zb_all[(size_t)h * W * Hh + pix];
+    float d = 0.f;
+    uint8_t r = 0, g = 0, b = 0;
+    if (key != ~0ull) {
+        const int f = (int)(unsigned)(key & 0xffffffffu);
+        d = __uint_as_float((unsigned)(key >> 32));
+        const TriSetup t = tri_setup(sv_all + (size_t)h * V, faces, f, W, Hh);
+        long long w0, w1, w2;
+        const int py = pix / W, px = pix - py * W;
+        tri_cover(t, px, py, w0, w1, w2);
+        float b0, b1, b2;
+        const float dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
+        const float q0 = b0 * t.iz0, q1 = b1 * t.iz1, q2 = b2 * t.iz2;
+        uint8_t out[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float c0 = 255.f, c1 = 255.f, c2 = 255.f;
+            if (colors) { c0 = (float)colors[4 * t.i0 + c]; c1 = (float)colors[4 * t.i1 + c]; c2 = (float)colors[4 * t.i2 + c]; }
+            const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
+            const float amb = fminf(2.0f * cv + 0.5f, 255.0f);
+            out[c] = (uint8_t)fmaxf(amb, 0.f);
+        }
+        r = out[0]; g = out[1]; b = out[2];
+    }
+    depth[(size_t)h * W * Hh + pix] = d;
+    uint8_t* o = rgb + ((size_t)h * W * Hh + pix) * 3;
+    o[0] = r; o[1] = g; o[2] = b;
+}
+
+}  // namespace
+
+extern "C" int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F,
+                              const uint8_t* h_colors, fp_mesh** out) {
+    FP_REQUIRE(ctx && h_verts && h_faces && out && V > 0 && F > 0, "mesh_upload: bad argument");
+    for (int i = 0; i < 3 * F; ++i) FP_REQUIRE(h_faces[i] >= 0 && h_faces[i] < V, "mesh_upload: face index out of range");
+    fp_mesh* m = new fp_mesh();
+    m->ctx = ctx; m->V = V; m->F = F;
+    FP_HIP(hipMalloc((void**)&m->verts, (size_t)V * 12));
+    FP_HIP(hipMalloc((void**)&m->faces, (size_t)F * 12));
+    FP_HIP(hipMemcpy(m->verts, h_verts, (size_t)V * 12, hipMemcpyHostToDevice));
+    FP_HIP(hipMemcpy(m->faces, h_faces, (size_t)F * 12, hipMemcpyHostToDevice));
+    if (h_colors) {
+        std::vector<uint8_t> rgba((size_t)V * 4, 255);
+        for (int i = 0; i < V; ++i) { rgba[4 * i] = h_colors[3 * i]; rgba[4 * i + 1] = h_colors[3 * i + 1]; rgba[4 * i + 2] = h_colors[3 * i + 2]; }
+        FP_HIP(hipMalloc((void**)&m->colors, (size_t)V * 4));
+        FP_HIP(hipMemcpy(m->colors, rgba.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+    }
+    *out = m;
+    return FP_OK;
+}
+extern "C" int fp_mesh_destroy(fp_mesh* m) {
+    if (!m) return FP_OK;
+    if (m->verts) (void)hipFree(m->verts);
+    if (m->faces) (void)hipFree(m->faces);
+    if (m->colors) (void)hipFree(m->colors);
+    delete m;
+    return FP_OK;
+}
+
+extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx,
+                            float fy, float cx, float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, void* stream) {
+    FP_REQUIRE(ctx && mesh && d_poses && d_rgb && d_depth, "rasterize: null argument");
+    FP_REQUIRE(W > 0 && Hh > 0 && W <= 8192 && Hh <= 8192, "rasterize: bad image size");
+    if (Hn == 0) return FP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int V = mesh->V, F = mesh->F;
+    SVert* sv;
+    unsigned long long* zb;
+    int* queue;
+    int rc;
+    const int qcap = 1 << 20;
+    if ((rc = ctx->get("raster.sv", (size_t)Hn * V * sizeof(SVert), (void**)&sv))) return rc;
+    if ((rc = ctx->get("raster.zb", (size_t)Hn * W * Hh * 8, (void**)&zb))) return rc;
+    if ((rc = ctx->get("raster.queue", (size_t)qcap * 8 + 64, (void**)&queue))) return rc;
+    int* qcount = queue + 2 * qcap;
+    FP_HIP(hipMemsetAsync(zb, 0xff, (size_t)Hn * W * Hh * 8, s));
+    FP_HIP(hipMemsetAsync(qcount, 0, 4, s));
+    hipLaunchKernelGGL(raster_vertex_kernel, dim3(cdiv(V, 256), Hn), dim3(256), 0, s, mesh->verts, V, d_poses, Hn, scale,
+                       fx, fy, cx, cy, sv);
+    FP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(raster_tri_kernel, dim3(cdiv(F, 256), Hn), dim3(256), 0, s, sv, mesh->faces, V, F, W, Hh, zb,
+                       queue, qcount, qcap);
+    FP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(raster_big_kernel, dim3(1024), dim3(256), 0, s, sv, mesh->faces, V, W, Hh, zb, queue, qcount, qcap);
+    FP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3(cdiv(W * Hh, 256), Hn), dim3(256), 0, s, sv, mesh->faces, mesh->colors,
+                       V, W, Hh, zb, d_rgb, d_depth);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}

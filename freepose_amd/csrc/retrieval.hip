@@ -1,0 +1,370 @@
+// Retrieval kernels (K10, K12, K13 of SURVEY.md §2.3), gfx950 only.  All HBM-bound byte/row streaming:
+// coalesced 16-byte loads, one wave per row, wave-shuffle reductions, no MFMA.
+//
+// Canonical arithmetic ("dot64"), shared with oracle/fp_oracle.c so indices AND scores are bit-exact:
+//   lane l (0..63) owns elements (c*64 + l)*8 + e  (c = 0.., e = 0..7) of the D-vector,
+//   p_l = fmaf chain over (c, e) ascending; s = xor-butterfly sum over offsets 32,16,8,4,2,1;
+//   score = bf16_rne(s)  (the reference rounds bank@feature to bf16 before .float()/topk:
+//   scripts/extract_proposals_ground.py:137-140).
+// Ordering for top-k: score descending, then index ascending (torch.topk's tie order is unspecified;
+// this is the documented canonical rule).
+#include "internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t score_key16(float s_bf16_rounded) {
+    const uint32_t b = __float_as_uint(s_bf16_rounded) >> 16;
+    return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+}
+__device__ __forceinline__ float key16_to_float(uint32_t k) {
+    const uint32_t b = (k & 0x8000u) ? (k & 0x7fffu) : (~k & 0xffffu);
+    return __uint_as_float(b << 16);
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = f2bf(x[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bank scan: keys[q, r] = sortable16( bf16( bank[r] . query[q] ) )
+template <int NCH, int QT>
+__global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict__ bank,
+                                                        const bf16_t* __restrict__ queries,
+                                                        uint16_t* __restrict__ keys, int N, int D, int q_begin,
+                                                        int Q) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    float qv[QT][NCH][8];
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int base = (c * 64 + lane) * 8;
+            const bool ok = (q_begin + q < Q) && (base < D);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                qv[q][c][e] = ok ? bf2f(queries[(size_t)(q_begin + q) * D + base + e]) : 0.f;
+        }
+    constexpr int RU = 4;  // rows in flight per wave
+    for (int r0 = wave * RU; r0 < N; r0 += nwave * RU) {
+        uint4 raw[RU][NCH];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int r = min(r0 + u, N - 1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int base = (c * 64 + lane) * 8;
+                raw[u][c] = base < D ? *(const uint4*)(bank + (size_t)r * D + base) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            float acc[QT];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const uint32_t w[4] = {raw[u][c].x, raw[u][c].y, raw[u][c].z, raw[u][c].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = lo_bf(w[e]), x1 = hi_bf(w[e]);
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        acc[q] = __fmaf_rn(x0, qv[q][c][2 * e], acc[q]);
+                        acc[q] = __fmaf_rn(x1, qv[q][c][2 * e + 1], acc[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const float s = wave_sum(acc[q]);
+                if (lane == 0 && r0 + u < N && q_begin + q < Q)
+                    keys[(size_t)(q_begin + q) * N + r0 + u] = (uint16_t)score_key16(rbf(s));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact top-k of 16-bit keys with (key desc, index asc) order: two-level radix select + ordered
+// compaction + bitonic sort of the k survivors.  One workgroup per query.
+constexpr int SEL_T = 1024;
+constexpr int KMAX = 1024;
+
+__device__ __forceinline__ int block_excl_scan(int v, int* sh, int& total) {
+    // sh: SEL_T ints.  simple Hillis-Steele over waves: wave scan + wave totals
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) sh[w] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < SEL_T / 64; ++i) {
+        const int t = sh[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    total = tot;
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(SEL_T) void topk_select_kernel(const uint16_t* __restrict__ keys, int N, int k,
+                                                            int idx_offset, float* __restrict__ out_scores,
+                                                            int* __restrict__ out_idx) {
+    __shared__ int hist[256];
+    __shared__ int sh[SEL_T / 64 + 2];
+    __shared__ int s_hi, s_T, s_gt;
+    __shared__ unsigned long long cand[KMAX];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const uint16_t* kq = keys + (size_t)q * N;
+    const int per = (N + SEL_T - 1) / SEL_T;
+    const int lo = tid * per, hi = min(lo + per, N);
+
+    // pass 1: histogram of the high byte
+    for (int i = tid; i < 256; i += SEL_T) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += SEL_T) atomicAdd(&hist[kq[i] >> 8], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0, b = 255;
+        for (; b >= 0; --b) { if (c + hist[b] >= k) break; c += hist[b]; }
+        s_hi = b; s_gt = c;  // c keys strictly above bin b
+    }
+    __syncthreads();
+    const int hb = s_hi;
+    __syncthreads();
+    // pass 2: histogram of the low byte inside bin hb
+    for (int i = tid; i < 256; i += SEL_T) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += SEL_T) { const int key = kq[i]; if ((key >> 8) == hb) atomicAdd(&hist[key & 255], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int c = s_gt, b = 255;
+        for (; b >= 0; --b) { if (c + hist[b] >= k) break; c += hist[b]; }
+        s_T = (hb << 8) | b; s_gt = c;  // c keys strictly greater than T
+    }
+    __syncthreads();
+    const int T = s_T, ngt = s_gt, need_eq = k - ngt;
+    // ordered compaction (index order): first all > T, then the first need_eq == T
+    int cg = 0, ce = 0;
+    for (int i = lo; i < hi; ++i) { const int key = kq[i]; cg += key > T; ce += key == T; }
+    int tot;
+    int og = block_excl_scan(cg, sh, tot);
+    int oe = block_excl_scan(ce, sh, tot);
+    for (int i = lo; i < hi; ++i) {
+        const int key = kq[i];
+        if (key > T) { cand[og++] = ((unsigned long long)key << 32) | (unsigned)(0x7fffffff - i); }
+        else if (key == T) { if (oe < need_eq) cand[ngt + oe] = ((unsigned long long)key << 32) | (unsigned)(0x7fffffff - i); ++oe; }
+    }
+    // pad to a power of two and bitonic-sort descending on (key, -index)
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    for (int i = k + tid; i < n2; i += SEL_T) cand[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < n2; i += SEL_T) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = ((i & size) == 0);
+                    const unsigned long long a = cand[i], b = cand[j];
+                    if ((a < b) == desc) { cand[i] = b; cand[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k; i += SEL_T) {
+        const unsigned long long c = cand[i];
+        out_scores[(size_t)q * k + i] = key16_to_float((uint32_t)(c >> 32));
+        out_idx[(size_t)q * k + i] = idx_offset + (0x7fffffff - (int)(unsigned)(c & 0xffffffffu));
+    }
+}
+
+// merge C candidates (score f32 holding a bf16 value, global idx) per query down to k, same ordering
+__global__ __launch_bounds__(1024) void topk_merge_kernel(const float* __restrict__ cs, const int* __restrict__ ci,
+                                                           int C, int k, float* __restrict__ out_scores,
+                                                           int* __restrict__ out_idx) {
+    extern __shared__ unsigned long long mc[];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    int n2 = 1;
+    while (n2 < C) n2 <<= 1;
+    for (int i = tid; i < n2; i += blockDim.x) {
+        unsigned long long v = 0ull;
+        if (i < C) {
+            const float s = cs[(size_t)q * C + i];
+            // full 32-bit sortable key (scores are bf16 values, but keep it generic)
+            uint32_t b = __float_as_uint(s);
+            b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+            v = ((unsigned long long)b << 32) | (unsigned)(0x7fffffff - ci[(size_t)q * C + i]);
+        }
+        mc[i] = v;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < n2; i += blockDim.x) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = ((i & size) == 0);
+                    const unsigned long long a = mc[i], b = mc[j];
+                    if ((a < b) == desc) { mc[i] = b; mc[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k; i += blockDim.x) {
+        const unsigned long long c = mc[i];
+        uint32_t b = (uint32_t)(c >> 32);
+        b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
+        out_scores[(size_t)q * k + i] = __uint_as_float(b);
+        out_idx[(size_t)q * k + i] = 0x7fffffff - (int)(unsigned)(c & 0xffffffffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K13 patchwise template score (src/pipeline/estimators/pose_estimator.py:85-88,
+// online_pose_estimator.py:68-79) with the reference's bf16 rounding points:
+//   tn = bf16(t / max(bf16(||t||), eps)) per patch row;  d[t,p] = bf16( tn . qn[p] );
+//   score[t] = bf16( (sum_p d[t,p]) / P )
+// qn is the already-normalised (or, frame-0 quirk, raw) query [P, D]; weights optional [T,P] f32
+// (mask_scores variant: score = sum(d*w)/sum(w)).
+template <int NCH>
+__global__ __launch_bounds__(256) void template_dots_kernel(const bf16_t* __restrict__ tmpl,
+                                                            const bf16_t* __restrict__ qn, float* __restrict__ dots,
+                                                            int T, int P, int D) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwave = ((long)gridDim.x * blockDim.x) >> 6;
+    const long rows = (long)T * P;
+    for (long r = wave; r < rows; r += nwave) {
+        const int pidx = (int)(r % P);
+        float x[NCH][8], qq[NCH][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int base = (c * 64 + lane) * 8;
+            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+            if (base < D) {
+                a = *(const uint4*)(tmpl + (size_t)r * D + base);
+                b = *(const uint4*)(qn + (size_t)pidx * D + base);
+            }
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[c][2 * e] = lo_bf(aw[e]); x[c][2 * e + 1] = hi_bf(aw[e]);
+                qq[c][2 * e] = lo_bf(bw[e]); qq[c][2 * e + 1] = hi_bf(bw[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = __fmaf_rn(x[c][e], x[c][e], ss);
+        }
+        ss = wave_sum(ss);
+        const float nrm = fmaxf(rbf(__fsqrt_rn(ss)), 1e-12f);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __fmaf_rn(rbf(__fdiv_rn(x[c][e], nrm)), qq[c][e], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) dots[r] = rbf(acc);
+    }
+}
+
+__global__ __launch_bounds__(64) void template_mean_kernel(const float* __restrict__ dots,
+                                                           const float* __restrict__ weights,
+                                                           float* __restrict__ scores, int T, int P) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f, wacc = 0.f;
+    for (int pidx = lane; pidx < P; pidx += 64) {
+        const float d = dots[(size_t)t * P + pidx];
+        if (weights) {
+            const float w = weights[(size_t)t * P + pidx];
+            acc += d * w;  // bf16 score * fp32 mask promotes to fp32 in the reference (online :72-74)
+            wacc += w;
+        } else {
+            acc += d;
+        }
+    }
+    acc = wave_sum(acc);
+    if (weights) {
+        wacc = wave_sum(wacc);
+        if (lane == 0) scores[t] = acc / wacc;
+    } else if (lane == 0) {
+        scores[t] = rbf(acc / (float)P);
+    }
+}
+
+}  // namespace
+
+int fp_cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s) {
+    if (n == 0) return FP_OK;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, s, x, y, n);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+// keys: workspace [Q, N] u16
+int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int N, int D, int Q, hipStream_t s) {
+    FP_REQUIRE(N > 0 && Q > 0 && D % 8 == 0 && D <= 1536, "bank_scan: bad shape N=%d D=%d Q=%d", N, D, Q);
+    const int nch = cdiv(D, 512);
+    const int blocks = std::min(cdiv(N, 16), 256 * 8);  // 4 waves x 4 rows per block-iteration
+    for (int qb = 0; qb < Q;) {
+        const int left = Q - qb;
+#define FP_SCAN(NCHV, QTV)                                                                                   \
+    hipLaunchKernelGGL((bank_scan_kernel<NCHV, QTV>), dim3(blocks), dim3(256), 0, s, bank, queries, keys, N, D, \
+                       qb, Q)
+        if (left >= 4) {
+            if (nch == 1) FP_SCAN(1, 4); else if (nch == 2) FP_SCAN(2, 4); else FP_SCAN(3, 4);
+            qb += 4;
+        } else {
+            if (nch == 1) FP_SCAN(1, 1); else if (nch == 2) FP_SCAN(2, 1); else FP_SCAN(3, 1);
+            qb += 1;
+        }
+#undef FP_SCAN
+        FP_LAUNCH_CHECK();
+    }
+    return FP_OK;
+}
+
+int fp_topk_select(const uint16_t* keys, int N, int Q, int k, int idx_offset, float* out_scores, int* out_idx,
+                   hipStream_t s) {
+    FP_REQUIRE(k > 0 && k <= KMAX && k <= N, "topk: k=%d out of range (N=%d, max %d)", k, N, KMAX);
+    hipLaunchKernelGGL(topk_select_kernel, dim3(Q), dim3(SEL_T), 0, s, keys, N, k, idx_offset, out_scores, out_idx);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+int fp_topk_merge_launch(const float* cs, const int* ci, int Q, int C, int k, float* out_scores, int* out_idx,
+                  hipStream_t s) {
+    FP_REQUIRE(C > 0 && k > 0 && k <= C && C <= 8192, "topk_merge: bad C=%d k=%d", C, k);
+    int n2 = 1;
+    while (n2 < C) n2 <<= 1;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(Q), dim3(1024), n2 * sizeof(unsigned long long), s, cs, ci, C, k,
+                       out_scores, out_idx);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+// dots: workspace [T*P] f32
+int fp_template_score_launch(const bf16_t* tmpl, const bf16_t* qn, const float* weights, float* dots, float* scores, int T,
+                      int P, int D, hipStream_t s) {
+    FP_REQUIRE(T > 0 && P > 0 && D % 8 == 0 && D <= 1536, "template_score: bad shape");
+    const long rows = (long)T * P;
+    const int blocks = (int)std::min<long>((rows + 3) / 4, 256 * 16);
+    const int nch = cdiv(D, 512);
+    if (nch == 1) hipLaunchKernelGGL(template_dots_kernel<1>, dim3(blocks), dim3(256), 0, s, tmpl, qn, dots, T, P, D);
+    else if (nch == 2) hipLaunchKernelGGL(template_dots_kernel<2>, dim3(blocks), dim3(256), 0, s, tmpl, qn, dots, T, P, D);
+    else hipLaunchKernelGGL(template_dots_kernel<3>, dim3(blocks), dim3(256), 0, s, tmpl, qn, dots, T, P, D);
+    FP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(template_mean_kernel, dim3(T), dim3(64), 0, s, dots, weights, scores, T, P);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}

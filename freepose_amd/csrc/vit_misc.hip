@@ -1,0 +1,307 @@
+// HBM-bound helper kernels of the ViT path (K0, K2, K8, K9 of SURVEY.md §2.3), gfx950 only.
+//   im2col_norm   : ImageNet normalise (dino.py:12,16) + 14x14 patch unfold -> GEMM A operand
+//   token_init    : cls+pos / register tokens / zero pad rows of the token buffer
+//   layernorm     : LayerNorm(eps) over D, one wave per row, optional row gather (final norm + slice,
+//                   dino.py:23-30)
+//   posembed_aa   : bicubic antialias resize of the 37x37 pos-embed grid (hub DINOv2
+//                   interpolate_pos_encoding; public algorithm of torch upsample_bicubic2d_aa)
+//   ffa           : mask any-pool 14x14 -> masked mean over patches -> optional L2 normalise
+//                   (scripts/extract_retrieval_features.py:51-57, extract_proposals_ground.py:129-134)
+#include "internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// im2col + normalise.  images [B,3,H,W] bf16 in [0,1]  ->  A [B*P, KP] bf16, k = c*ps*ps + dy*ps + dx
+// Rounding points follow torchvision Normalize on a bf16 tensor: sub (round) then div (round).
+__global__ void im2col_norm_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ A, int B, int H,
+                                   int W, int ps, int KP, float m0, float m1, float m2, float s0, float s1,
+                                   float s2) {
+    const int gw = W / ps, gh = H / ps, P = gw * gh;
+    const int K = 3 * ps * ps;
+    const int chunks = KP / 8;
+    const long total = (long)B * P * chunks;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % chunks);
+        const long row = idx / chunks;
+        const int b = (int)(row / P), pp = (int)(row % P);
+        const int py = pp / gw, px = pp % gw;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = ch * 8 + e + u;
+                float val = 0.f;
+                if (k < K) {
+                    const int c = k / (ps * ps), rem = k % (ps * ps);
+                    const int dy = rem / ps, dx = rem % ps;
+                    const float x = bf2f(img[(((size_t)b * 3 + c) * H + (py * ps + dy)) * W + px * ps + dx]);
+                    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+                    const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                    val = rbf(rbf(x - mean) / sd);
+                }
+                v[u] = val;
+            }
+            w[e / 2] = pack_bf2(v[0], v[1]);
+        }
+        *(uint4*)(A + (size_t)row * KP + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// token buffer rows that the patch GEMM does not write: row 0 = cls + pos[0], rows 1..nreg = register
+// tokens (no pos-embed), rows [n_tok, npad) = 0
+__global__ void token_init_kernel(bf16_t* __restrict__ X, const bf16_t* __restrict__ cls,
+                                  const bf16_t* __restrict__ pos0, const bf16_t* __restrict__ reg, int nreg,
+                                  int n_tok, int npad, int D) {
+    const int b = blockIdx.y;
+    const int nrows = 1 + nreg + (npad - n_tok);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows * D; i += gridDim.x * blockDim.x) {
+        const int r = i / D, c = i % D;
+        int row;
+        bf16_t v;
+        if (r == 0) { row = 0; v = f2bf(bf2f(cls[c]) + bf2f(pos0[c])); }
+        else if (r <= nreg) { row = r; v = reg[(r - 1) * D + c]; }
+        else { row = n_tok + (r - 1 - nreg); v = 0; }
+        X[((size_t)b * npad + row) * D + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per output row. in_row = (r / rows_per_b) * in_stride_b + in_off + r % rows_per_b
+template <int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y,
+                                                        const bf16_t* __restrict__ gamma,
+                                                        const bf16_t* __restrict__ beta, int rows, int D,
+                                                        float eps, int rows_per_b, int in_stride_b, int in_off) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int nch = D / 8;
+    for (int r = wave; r < rows; r += nwave) {
+        const size_t ir = (size_t)(r / rows_per_b) * in_stride_b + in_off + (r % rows_per_b);
+        const bf16_t* xr = X + ir * D;
+        float v[MAXC][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                const uint4 q = *(const uint4*)(xr + ch * 8);
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[c][2 * e] = lo_bf(w[e]); v[c][2 * e + 1] = hi_bf(w[e]); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += v[c][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (lane + 64 * c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+        bf16_t* yr = Y + (size_t)r * D;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                const uint4 g = *(const uint4*)(gamma + ch * 8), bb = *(const uint4*)(beta + ch * 8);
+                const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, bw[4] = {bb.x, bb.y, bb.z, bb.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = (v[c][2 * e] - mean) * rstd * lo_bf(gw[e]) + lo_bf(bw[e]);
+                    const float b = (v[c][2 * e + 1] - mean) * rstd * hi_bf(gw[e]) + hi_bf(bw[e]);
+                    o[e] = pack_bf2(a, b);
+                }
+                *(uint4*)(yr + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bicubic (a = -0.5) antialias resize of the patch pos-embed grid, fp32 math, bf16 in/out.
+// src [G*G, D] (row-major grid, channel-last), dst [gh*gw, D]
+__device__ __forceinline__ float cubic_aa(float x) {
+    const float a = -0.5f;
+    x = fabsf(x);
+    if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+    if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+    return 0.f;
+}
+__device__ __forceinline__ void aa_window(int i, int in, int out, int& xmin, int& xsize, float& center,
+                                          float& invscale) {
+    const float scale = (float)in / (float)out;
+    const float support = scale >= 1.f ? 2.f * scale : 2.f;
+    invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    center = scale * ((float)i + 0.5f);
+    xmin = max((int)(center - support + 0.5f), 0);
+    xsize = min((int)(center + support + 0.5f), in) - xmin;
+}
+__global__ void posembed_aa_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int G, int gh,
+                                   int gw, int D) {
+    const int op = blockIdx.x;  // output patch
+    const int oy = op / gw, ox = op % gw;
+    int ymin, ysize, xmin, xsize;
+    float cy, iy, cx, ix;
+    aa_window(oy, G, gh, ymin, ysize, cy, iy);
+    aa_window(ox, G, gw, xmin, xsize, cx, ix);
+    float wy[16], wx[16];
+    float sy = 0.f, sx = 0.f;
+    for (int j = 0; j < ysize && j < 16; ++j) { wy[j] = cubic_aa(((float)(j + ymin) - cy + 0.5f) * iy); sy += wy[j]; }
+    for (int j = 0; j < xsize && j < 16; ++j) { wx[j] = cubic_aa(((float)(j + xmin) - cx + 0.5f) * ix); sx += wx[j]; }
+    for (int j = 0; j < ysize && j < 16; ++j) wy[j] /= sy;
+    for (int j = 0; j < xsize && j < 16; ++j) wx[j] /= sx;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        // horizontal pass first, then vertical (order of torch's separable CPU kernel)
+        float acc = 0.f;
+        for (int jy = 0; jy < ysize && jy < 16; ++jy) {
+            float row = 0.f;
+            for (int jx = 0; jx < xsize && jx < 16; ++jx)
+                row += wx[jx] * bf2f(src[((size_t)(ymin + jy) * G + xmin + jx) * D + c]);
+            acc += wy[jy] * row;
+        }
+        dst[(size_t)op * D + c] = f2bf(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FFA descriptor. feats [B,P,D] bf16, mask u8 [B,Hm,Wm] (Hm = gh*cell, Wm = gw*cell) or patch mask
+// u8 [B,P] when cell == 1.  out [B,D] bf16.  Summation order is fixed (ascending patch index, one
+// fp32 accumulator per channel) so the oracle reproduces it bit for bit.
+__global__ __launch_bounds__(128) void ffa_kernel(const bf16_t* __restrict__ feats,
+                                                  const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
+                                                  float* __restrict__ out_f32, int P, int D, int gh, int gw,
+                                                  int cell) {
+    extern __shared__ uint8_t pm[];  // [P]
+    __shared__ int cnt_s;
+    const int b = blockIdx.y;
+    const int Wm = gw * cell;
+    if (threadIdx.x == 0) cnt_s = 0;
+    __syncthreads();
+    int local = 0;
+    for (int pidx = threadIdx.x; pidx < P; pidx += blockDim.x) {
+        const int py = pidx / gw, px = pidx % gw;
+        const uint8_t* mp = mask + (size_t)b * (gh * cell) * Wm + (size_t)(py * cell) * Wm + px * cell;
+        int any = 0;
+        for (int dy = 0; dy < cell; ++dy)
+            for (int dx = 0; dx < cell; ++dx) any |= mp[dy * Wm + dx];
+        pm[pidx] = any ? 1 : 0;
+        local += any ? 1 : 0;
+    }
+    atomicAdd(&cnt_s, local);
+    __syncthreads();
+    const int cnt = cnt_s;
+    const int c2 = blockIdx.x * blockDim.x + threadIdx.x;  // pair of channels
+    if (c2 * 2 >= D) return;
+    const uint32_t* fp = (const uint32_t*)(feats + (size_t)b * P * D) + c2;
+    float a0 = 0.f, a1 = 0.f;
+    for (int pidx = 0; pidx < P; ++pidx) {
+        if (pm[pidx]) {
+            const uint32_t w = fp[(size_t)pidx * (D / 2)];
+            a0 += lo_bf(w);
+            a1 += hi_bf(w);
+        }
+    }
+    // mean of a bf16 tensor: fp32 accumulate, divide, round to bf16 (0/0 -> NaN like the reference)
+    const float m0 = a0 / (float)cnt, m1 = a1 / (float)cnt;
+    if (out) ((uint32_t*)(out + (size_t)b * D))[c2] = pack_bf2(m0, m1);
+    if (out_f32) { out_f32[(size_t)b * D + 2 * c2] = rbf(m0); out_f32[(size_t)b * D + 2 * c2 + 1] = rbf(m1); }
+}
+
+// F.normalize(x, dim=-1) on bf16 rows with the reference's rounding points:
+//   n = bf16(sqrt(sum x^2)) ; y = bf16(x / max(n, eps))
+// sum order: lane l takes elements (c*64 + l)*8 + e, fmaf chain, then xor-butterfly (canonical, see oracle)
+__global__ __launch_bounds__(64) void l2norm_rows_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y,
+                                                         int rows, int D) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= rows) return;
+    const bf16_t* xr = X + (size_t)r * D;
+    float acc = 0.f;
+    for (int base = lane * 8; base < D; base += 512) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = bf2f(xr[base + e]); acc = __fmaf_rn(v, v, acc); }
+    }
+    acc = wave_sum(acc);
+    const float n = fmaxf(rbf(__fsqrt_rn(acc)), 1e-12f);
+    for (int base = lane * 8; base < D; base += 512) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Y[(size_t)r * D + base + e] = f2bf(__fdiv_rn(bf2f(xr[base + e]), n));
+    }
+}
+
+}  // namespace
+
+int fp_im2col_norm(const bf16_t* img, bf16_t* A, int B, int H, int W, int ps, int KP, hipStream_t s) {
+    FP_REQUIRE(H % ps == 0 && W % ps == 0 && KP % 8 == 0 && KP >= 3 * ps * ps, "im2col: bad shape");
+    const long total = (long)B * (H / ps) * (W / ps) * (KP / 8);
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256 * 16);
+    // torchvision Normalize builds mean/std tensors in the image dtype (bf16)
+    hipLaunchKernelGGL(im2col_norm_kernel, dim3(blocks), dim3(256), 0, s, img, A, B, H, W, ps, KP, rbf(0.485f),
+                       rbf(0.456f), rbf(0.406f), rbf(0.229f), rbf(0.224f), rbf(0.225f));
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+int fp_token_init(bf16_t* X, const bf16_t* cls, const bf16_t* pos0, const bf16_t* reg, int nreg, int B,
+                  int n_tok, int npad, int D, hipStream_t s) {
+    const int nrows = 1 + nreg + (npad - n_tok);
+    hipLaunchKernelGGL(token_init_kernel, dim3(cdiv(nrows * D, 256), B), dim3(256), 0, s, X, cls, pos0, reg, nreg,
+                       n_tok, npad, D);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+int fp_layernorm(const bf16_t* X, bf16_t* Y, const bf16_t* gamma, const bf16_t* beta, int rows, int D, float eps,
+                 int rows_per_b, int in_stride_b, int in_off, hipStream_t s) {
+    FP_REQUIRE(D % 8 == 0 && D <= 8 * 64 * 3, "layernorm: D=%d unsupported", D);
+    if (rows_per_b <= 0) { rows_per_b = rows; in_stride_b = 0; in_off = 0; }
+    const int blocks = std::min(cdiv(rows, 4), 256 * 8);
+    if (D <= 512)
+        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, s, X, Y, gamma, beta, rows, D, eps,
+                           rows_per_b, in_stride_b, in_off);
+    else if (D <= 1024)
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, s, X, Y, gamma, beta, rows, D, eps,
+                           rows_per_b, in_stride_b, in_off);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, s, X, Y, gamma, beta, rows, D, eps,
+                           rows_per_b, in_stride_b, in_off);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+int fp_posembed_aa(const bf16_t* src, bf16_t* dst, int G, int gh, int gw, int D, hipStream_t s) {
+    FP_REQUIRE(G > 0 && gh > 0 && gw > 0, "posembed: bad grid");
+    FP_REQUIRE(4.0f * G / gh + 2 < 16 && 4.0f * G / gw + 2 < 16, "posembed: downscale factor too large");
+    hipLaunchKernelGGL(posembed_aa_kernel, dim3(gh * gw), dim3(256), 0, s, src, dst, G, gh, gw, D);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* out_f32, int B, int P, int D, int gh,
+                int gw, int cell, hipStream_t s) {
+    FP_REQUIRE(gh * gw == P && D % 2 == 0 && cell >= 1, "ffa: bad shape P=%d gh=%d gw=%d", P, gh, gw);
+    hipLaunchKernelGGL(ffa_kernel, dim3(cdiv(D / 2, 128), B), dim3(128), P, s, feats, mask, out, out_f32, P, D, gh, gw,
+                       cell);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+int fp_l2norm_rows(const bf16_t* X, bf16_t* Y, int rows, int D, hipStream_t s) {
+    FP_REQUIRE(D % 8 == 0, "l2norm: D must be a multiple of 8");
+    if (rows == 0) return FP_OK;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(rows), dim3(64), 0, s, X, Y, rows, D);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}

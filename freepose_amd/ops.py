@@ -1,0 +1,393 @@
+"""Tensor-level wrappers over the C ABI: torch provides device memory and the stream, libfreepose_hip.so does
+the work.  Every function raises if the library is missing or a call fails (no CPU fallback)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+_ctx = {}
+
+
+def context(device: Optional[int] = None):
+    """One fp_ctx per (process, device)."""
+    if device is None:
+        device = torch.cuda.current_device()
+    h = _ctx.get(device)
+    if h is None:
+        lib = _lib.load()
+        out = C.c_void_p()
+        check(lib.fp_ctx_create(int(device), C.byref(out)), "fp_ctx_create")
+        h = _ctx[device] = out
+    return h
+
+
+def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
+    if not t.is_cuda:
+        t = t.to("cuda", non_blocking=False)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+VIT_ARCHS = {
+    # name: (dim, depth, heads, n_reg)
+    "dinov2_vits14": (384, 12, 6, 0), "dinov2_vits14_reg": (384, 12, 6, 4),
+    "dinov2_vitb14": (768, 12, 12, 0), "dinov2_vitb14_reg": (768, 12, 12, 4),
+    "dinov2_vitl14": (1024, 24, 16, 0), "dinov2_vitl14_reg": (1024, 24, 16, 4),
+}
+FEATURE_TYPES = {"cls": 0, "reg": 1, "patch": 2}
+
+
+class ViT:
+    """Device-resident DINOv2 ViT (hub state-dict layout) driving fp_vit_forward."""
+
+    def __init__(self, model_name: str = "dinov2_vitl14_reg", state_dict: Optional[dict] = None, seed: int = 0,
+                 device: Optional[int] = None):
+        if model_name not in VIT_ARCHS:
+            raise ValueError(f"unknown DINOv2 model {model_name}")
+        dim, depth, heads, n_reg = VIT_ARCHS[model_name]
+        self.dim, self.depth, self.heads, self.n_reg, self.patch, self.pos_grid = dim, depth, heads, n_reg, 14, 37
+        self.lib = _lib.load()
+        self.ctx = context(device)
+        arch = _lib.VitArch(dim, depth, heads, 4 * dim, 14, n_reg, 37, 1e-6)
+        h = C.c_void_p()
+        check(self.lib.fp_vit_create(self.ctx, C.byref(arch), C.byref(h)), "fp_vit_create")
+        self.handle = h
+        self.weights = {}
+        if state_dict is None:
+            state_dict = random_state_dict(model_name, seed)
+        self.load_state_dict(state_dict)
+
+    def load_state_dict(self, sd: dict):
+        s = current_stream()
+        for name, t in sd.items():
+            if name == "mask_token":
+                continue
+            w = _dev(torch.as_tensor(t), torch.bfloat16)
+            self.weights[name] = w  # keep alive: the library stores raw pointers
+            check(self.lib.fp_vit_set_weight(self.handle, name.encode(), ptr(w), w.numel(), s), f"set_weight({name})")
+        torch.cuda.synchronize()
+
+    def forward(self, images: torch.Tensor, layer: int = 22, feature_type: str = "cls") -> torch.Tensor:
+        x = _dev(images, torch.bfloat16)
+        B, Cc, H, W = x.shape
+        assert Cc == 3
+        P = (H // self.patch) * (W // self.patch)
+        ft = FEATURE_TYPES[feature_type]
+        shape = {0: (B, self.dim), 1: (B, self.n_reg, self.dim), 2: (B, P, self.dim)}[ft]
+        out = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+        if B > 0:
+            check(self.lib.fp_vit_forward(self.handle, ptr(x), B, H, W, int(layer), ft, ptr(out), current_stream()),
+                  "fp_vit_forward")
+        return out
+
+    __call__ = forward
+
+    def flops(self, B, H, W, layer=22) -> float:
+        return float(self.lib.fp_vit_flops(self.handle, B, H, W, layer))
+
+    def profile(self, enable: bool):
+        check(self.lib.fp_vit_profile(self.handle, int(enable)))
+
+    def profile_read(self):
+        g, a, o, f = C.c_float(), C.c_float(), C.c_float(), C.c_double()
+        check(self.lib.fp_vit_profile_read(self.handle, C.byref(g), C.byref(a), C.byref(o), C.byref(f)))
+        return {"ms_gemm": g.value, "ms_attn": a.value, "ms_other": o.value, "gemm_flops": f.value}
+
+    def __del__(self):
+        try:
+            self.lib.fp_vit_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def random_state_dict(model_name: str, seed: int = 0) -> dict:
+    """Seeded random-init weights with the hub DINOv2 state-dict names/shapes (no checkpoints offline).
+    trunc-normal(0.02) linears, LayerScale gamma 1.0, LayerNorm (1, 0) — SURVEY.md §8d C2."""
+    dim, depth, heads, n_reg = VIT_ARCHS[model_name]
+    g = torch.Generator().manual_seed(seed)
+
+    def tn(*shape, std=0.02):
+        return torch.nn.init.trunc_normal_(torch.empty(*shape), std=std, a=-2 * std, b=2 * std, generator=g)
+
+    sd = {"cls_token": tn(1, 1, dim, std=1e-6) + 0.0, "pos_embed": tn(1, 1 + 37 * 37, dim),
+          "patch_embed.proj.weight": tn(dim, 3, 14, 14), "patch_embed.proj.bias": tn(dim),
+          "norm.weight": torch.ones(dim), "norm.bias": torch.zeros(dim)}
+    sd["cls_token"] = tn(1, 1, dim)
+    if n_reg:
+        sd["register_tokens"] = tn(1, n_reg, dim)
+    for i in range(depth):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"] = torch.ones(dim) + tn(dim, std=0.05)
+        sd[p + "norm1.bias"] = tn(dim)
+        sd[p + "attn.qkv.weight"] = tn(3 * dim, dim)
+        sd[p + "attn.qkv.bias"] = tn(3 * dim)
+        sd[p + "attn.proj.weight"] = tn(dim, dim)
+        sd[p + "attn.proj.bias"] = tn(dim)
+        sd[p + "ls1.gamma"] = torch.ones(dim)
+        sd[p + "norm2.weight"] = torch.ones(dim) + tn(dim, std=0.05)
+        sd[p + "norm2.bias"] = tn(dim)
+        sd[p + "mlp.fc1.weight"] = tn(4 * dim, dim)
+        sd[p + "mlp.fc1.bias"] = tn(4 * dim)
+        sd[p + "mlp.fc2.weight"] = tn(dim, 4 * dim)
+        sd[p + "mlp.fc2.bias"] = tn(dim)
+        sd[p + "ls2.gamma"] = torch.ones(dim)
+    return {k: v.to(torch.bfloat16) for k, v in sd.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+def ffa(feats: torch.Tensor, masks: torch.Tensor, cell: int = 14, normalize: bool = False, out_f32: bool = False):
+    """FFA descriptor.  feats bf16 [B,P,D]; masks bool/u8 [B,gh*cell,gw*cell] (or [B,P] with cell=1)."""
+    lib = _lib.load()
+    f = _dev(feats, torch.bfloat16)
+    B, Pn, D = f.shape
+    m = _dev(masks).to(torch.uint8).contiguous()
+    if cell == 1:
+        gh, gw = 1, Pn
+        m = m.reshape(B, 1, Pn)
+    else:
+        gh, gw = m.shape[1] // cell, m.shape[2] // cell
+        if m.shape[1] != gh * cell or m.shape[2] != gw * cell:
+            m = m[:, :gh * cell, :gw * cell].contiguous()
+    assert gh * gw == Pn, f"mask grid {gh}x{gw} != {Pn} patches"
+    ob = torch.empty((B, D), dtype=torch.bfloat16, device=f.device)
+    of = torch.empty((B, D), dtype=torch.float32, device=f.device) if out_f32 else None
+    if B:
+        check(lib.fp_ffa(context(), ptr(f), ptr(m), B, gh, gw, D, cell, int(normalize), ptr(ob), ptr(of), current_stream()),
+              "fp_ffa")
+    return of if out_f32 else ob
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    xb = _dev(x, torch.bfloat16)
+    D = xb.shape[-1]
+    rows = xb.numel() // D
+    y = torch.empty_like(xb)
+    if rows:
+        check(lib.fp_l2_normalize(context(), ptr(xb), rows, D, ptr(y), current_stream()), "fp_l2_normalize")
+    return y
+
+
+def bank_prepare(bank_f32: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    b = _dev(bank_f32, torch.float32)
+    N, D = b.shape
+    out = torch.empty((N, D), dtype=torch.bfloat16, device=b.device)
+    check(lib.fp_bank_prepare(context(), ptr(b), N, D, ptr(out), current_stream()), "fp_bank_prepare")
+    return out
+
+
+def bank_topk(bank_bf16: torch.Tensor, queries: torch.Tensor, k: int = 100, idx_offset: int = 0):
+    """(scores f32 [Q,k], idx i32 [Q,k]) ordered by (score desc, index asc)."""
+    lib = _lib.load()
+    b = _dev(bank_bf16, torch.bfloat16)
+    q = _dev(queries, torch.bfloat16)
+    if q.dim() == 1:
+        q = q[None]
+    N, D = b.shape
+    Q = q.shape[0]
+    s = torch.empty((Q, k), dtype=torch.float32, device=b.device)
+    i = torch.empty((Q, k), dtype=torch.int32, device=b.device)
+    if Q:
+        check(lib.fp_bank_topk(context(), ptr(b), N, D, ptr(q), Q, k, idx_offset, ptr(s), ptr(i), current_stream()),
+              "fp_bank_topk")
+    return s, i
+
+
+def topk_merge(cand_scores: torch.Tensor, cand_idx: torch.Tensor, k: int):
+    lib = _lib.load()
+    cs = _dev(cand_scores, torch.float32)
+    ci = _dev(cand_idx, torch.int32)
+    Q, Cn = cs.shape
+    s = torch.empty((Q, k), dtype=torch.float32, device=cs.device)
+    i = torch.empty((Q, k), dtype=torch.int32, device=cs.device)
+    if Q:
+        check(lib.fp_topk_merge(context(), ptr(cs), ptr(ci), Q, Cn, k, ptr(s), ptr(i), current_stream()), "fp_topk_merge")
+    return s, i
+
+
+def template_score(tmpl: torch.Tensor, query: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tmpl bf16 [T,P,D] raw, query bf16 [P,D] used as given -> scores f32 [T] (bf16-valued unless weighted)."""
+    lib = _lib.load()
+    t = _dev(tmpl, torch.bfloat16)
+    q = _dev(query, torch.bfloat16).reshape(-1, t.shape[-1])
+    T, Pn, D = t.shape
+    assert q.shape[0] == Pn
+    w = _dev(weights, torch.float32) if weights is not None else None
+    out = torch.empty((T,), dtype=torch.float32, device=t.device)
+    if T:
+        check(lib.fp_template_score(context(), ptr(t), ptr(q), ptr(w), T, Pn, D, ptr(out), current_stream()),
+              "fp_template_score")
+    return out
+
+
+def crop_resize_pad(images: torch.Tensor, boxes: torch.Tensor, target: int, bbox_extend: float = 0.0,
+                    masks: Optional[torch.Tensor] = None, mask_mode: int = 0, out_bf16: bool = False) -> torch.Tensor:
+    """images f32 [n_img,C,H,W] or u8 [n_img,H,W,C]; boxes int [n,4] xyxy."""
+    lib = _lib.load()
+    if images.dtype == torch.uint8:
+        img = _dev(images)
+        n_img, H, W, Cc = img.shape
+        src = 1
+    else:
+        img = _dev(images, torch.float32)
+        n_img, Cc, H, W = img.shape
+        src = 0
+    bx = _dev(boxes).to(torch.int32).contiguous()
+    n = bx.shape[0]
+    m = _dev(masks).to(torch.uint8).contiguous() if masks is not None else None
+    if mask_mode == 2:
+        Cc_out = 1
+    else:
+        Cc_out = Cc
+    out = torch.empty((n, Cc_out, target, target), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=img.device)
+    if n:
+        check(lib.fp_crop_resize_pad(context(), ptr(img), src, n_img, Cc_out if mask_mode == 2 else Cc, H, W, ptr(bx), n,
+                                     float(bbox_extend), int(target), ptr(m), int(mask_mode), ptr(out), int(out_bf16),
+                                     current_stream()), "fp_crop_resize_pad")
+    return out
+
+
+def generate_rotations(n: int) -> np.ndarray:
+    lib = _lib.load()
+    out = np.empty((n, 3, 3), dtype=np.float64)
+    check(lib.fp_generate_rotations(n, ptr(out)), "fp_generate_rotations")
+    return out
+
+
+def geodesic_select(grid_f64: torch.Tensor, R_prev: np.ndarray, thresh_deg: float) -> np.ndarray:
+    lib = _lib.load()
+    g = _dev(grid_f64, torch.float64)
+    G = g.shape[0]
+    idx = torch.empty((G,), dtype=torch.int32, device=g.device)
+    Rp = np.ascontiguousarray(np.asarray(R_prev, dtype=np.float64)[:3, :3])
+    n = C.c_int(0)
+    check(lib.fp_geodesic_select(context(), ptr(g), G, ptr(Rp), float(thresh_deg), ptr(idx), C.byref(n), current_stream()),
+          "fp_geodesic_select")
+    return idx[: n.value].cpu().numpy().astype(np.int64)
+
+
+class Mesh:
+    def __init__(self, vertices: np.ndarray, faces: np.ndarray, colors: Optional[np.ndarray] = None):
+        self.lib = _lib.load()
+        v = np.ascontiguousarray(vertices, dtype=np.float32)
+        f = np.ascontiguousarray(faces, dtype=np.int32)
+        c = np.ascontiguousarray(colors[:, :3], dtype=np.uint8) if colors is not None else None
+        h = C.c_void_p()
+        check(self.lib.fp_mesh_upload(context(), ptr(v), v.shape[0], ptr(f), f.shape[0], ptr(c), C.byref(h)), "fp_mesh_upload")
+        self.handle, self.V, self.F = h, v.shape[0], f.shape[0]
+
+    def __del__(self):
+        try:
+            self.lib.fp_mesh_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def rasterize(mesh: Mesh, poses: torch.Tensor, scale: float, fx: float, fy: float, cx: float, cy: float, W: int, H: int):
+    """poses [Hn,4,4] object->camera (OpenCV).  Returns (rgb u8 [Hn,H,W,3], depth f32 [Hn,H,W]) on device."""
+    lib = _lib.load()
+    p = _dev(torch.as_tensor(poses), torch.float32)
+    Hn = p.shape[0]
+    rgb = torch.empty((Hn, H, W, 3), dtype=torch.uint8, device=p.device)
+    depth = torch.empty((Hn, H, W), dtype=torch.float32, device=p.device)
+    if Hn:
+        check(lib.fp_rasterize(context(), mesh.handle, ptr(p), Hn, float(scale), float(fx), float(fy), float(cx), float(cy),
+                               int(W), int(H), ptr(rgb), ptr(depth), current_stream()), "fp_rasterize")
+    return rgb, depth
+
+
+def depth_extents(depth: torch.Tensor, fx: float, fy: float, cx: float, cy: float) -> torch.Tensor:
+    """[Hn,8] = xmin,ymin,xmax,ymax (mask bbox incl. <100 px fallback), dx, dy (m), count, 0"""
+    lib = _lib.load()
+    d = _dev(depth, torch.float32)
+    Hn, H, W = d.shape
+    out = torch.empty((Hn, 8), dtype=torch.float32, device=d.device)
+    if Hn:
+        check(lib.fp_depth_extents(context(), ptr(d), Hn, H, W, float(fx), float(fy), float(cx), float(cy), ptr(out),
+                                   current_stream()), "fp_depth_extents")
+    return out
+
+
+# ---- kernel-level ops (unit tests / microbenchmarks) ------------------------------------------------
+def gemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epi: int = 0, gamma=None, resid=None,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epi 0: x w^T + b ; 1: gelu(.) ; 2: resid + gamma*(.)   (all bf16, fp32 accumulate)"""
+    lib = _lib.load()
+    x, w, bias = _dev(x, torch.bfloat16), _dev(w, torch.bfloat16), _dev(bias, torch.bfloat16)
+    M, K = x.shape
+    N = w.shape[0]
+    g = _dev(gamma, torch.bfloat16) if gamma is not None else None
+    r = _dev(resid, torch.bfloat16) if resid is not None else None
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    check(lib.fp_op_gemm(ptr(x), K, ptr(w), K, ptr(out), N, ptr(bias), ptr(g), ptr(r), N, M, N, K, epi, current_stream()),
+          "fp_op_gemm")
+    return out
+
+
+def gemm_vt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, npad: int, heads: int) -> torch.Tensor:
+    lib = _lib.load()
+    x, w, bias = _dev(x, torch.bfloat16), _dev(w, torch.bfloat16), _dev(bias, torch.bfloat16)
+    M, K = x.shape
+    N = w.shape[0]
+    B = M // npad
+    vt = torch.zeros((B, heads, 64, npad), dtype=torch.bfloat16, device=x.device)
+    check(lib.fp_op_gemm_vt(ptr(x), K, ptr(w), K, ptr(vt), ptr(bias), M, N, K, npad, heads, current_stream()), "fp_op_gemm_vt")
+    return vt
+
+
+def attention(qk: torch.Tensor, vt: torch.Tensor, n_tok: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qk bf16 [B*npad, 2*H*64], vt bf16 [B,H,64,npad] -> o bf16 [B*npad, H*64]"""
+    lib = _lib.load()
+    qk, vt = _dev(qk, torch.bfloat16), _dev(vt, torch.bfloat16)
+    B, H, _, npad = vt.shape
+    if out is None:
+        out = torch.zeros((B * npad, H * 64), dtype=torch.bfloat16, device=qk.device)
+    check(lib.fp_op_attention(ptr(qk), 2 * H * 64, ptr(vt), ptr(out), H * 64, B, H, n_tok, npad, current_stream()),
+          "fp_op_attention")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    lib = _lib.load()
+    x, gamma, beta = _dev(x, torch.bfloat16), _dev(gamma, torch.bfloat16), _dev(beta, torch.bfloat16)
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    check(lib.fp_op_layernorm(ptr(x), ptr(y), ptr(gamma), ptr(beta), rows, D, float(eps), current_stream()), "fp_op_layernorm")
+    return y
+
+
+class Timer:
+    """HIP-event timer on the current stream (bench.py)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.fp_timer_create(C.byref(h)))
+        self.h = h
+
+    def start(self):
+        check(self.lib.fp_timer_start(self.h, current_stream()))
+
+    def stop(self):
+        check(self.lib.fp_timer_stop(self.h, current_stream()))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float()
+        check(self.lib.fp_timer_elapsed_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            self.lib.fp_timer_destroy(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,155 @@
+/* freepose_hip.h — C ABI of libfreepose_hip.so, the MI355X (gfx950) implementation of FreePose's
+ * per-proposal 6D-pose hot path.  Plain pointers and sizes only; every pointer named `d_*` or documented
+ * "device" is a HIP device pointer owned by the caller, every call takes the HIP stream to enqueue on
+ * (void* = hipStream_t; NULL = default stream) and returns 0 on success or an FP_ERR_* code, with
+ * fp_last_error() giving the text.  No exceptions cross this boundary.  Nothing here touches torch.
+ *
+ * Each entry names the reference interface it replaces (file:line relative to ponimatkin/freepose).
+ * bf16 tensors are raw uint16 bit patterns.
+ */
+#ifndef FREEPOSE_HIP_H
+#define FREEPOSE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP_OK 0
+#define FP_ERR_INVALID 1
+#define FP_ERR_HIP 2
+#define FP_ERR_STATE 3
+
+typedef struct fp_ctx fp_ctx; /* one per (thread, GPU): owns workspaces, no hidden globals */
+typedef struct fp_vit fp_vit; /* ViT weights table + per-resolution pos-embed cache         */
+typedef struct fp_mesh fp_mesh; /* device copy of a triangle mesh for the rasteriser         */
+
+const char* fp_last_error(void);
+int fp_version(void);
+int fp_ctx_create(int device, fp_ctx** out);
+int fp_ctx_destroy(fp_ctx* ctx);
+/* bytes currently held in the context's workspaces (diagnostics) */
+size_t fp_ctx_workspace_bytes(const fp_ctx* ctx);
+
+/* ---- a1/a2: DINOv2FeatureExtractor (src/pipeline/retrieval/dino.py:8-32; hub dinov2 ViT) -------------- */
+typedef struct {
+    int dim;       /* 1024 (ViT-L), 384 (ViT-S), 768 (ViT-B)            */
+    int depth;     /* 24 / 12 / 12                                     */
+    int heads;     /* dim / 64                                         */
+    int mlp_dim;   /* 4 * dim                                          */
+    int patch;     /* 14                                               */
+    int n_reg;     /* 4 register tokens (0 for non-reg checkpoints)    */
+    int pos_grid;  /* 37 (pos_embed is [1 + 37*37, dim])               */
+    float ln_eps;  /* 1e-6                                             */
+} fp_vit_arch;
+
+int fp_vit_create(fp_ctx* ctx, const fp_vit_arch* arch, fp_vit** out);
+int fp_vit_destroy(fp_vit* vit);
+/* Register one state-dict tensor by its DINOv2 name (dino.py:10 loads exactly this checkpoint layout):
+ *   cls_token, pos_embed, register_tokens, patch_embed.proj.{weight,bias}, blocks.{i}.norm1.{weight,bias},
+ *   blocks.{i}.attn.qkv.{weight,bias}, blocks.{i}.attn.proj.{weight,bias}, blocks.{i}.ls1.gamma,
+ *   blocks.{i}.norm2.{weight,bias}, blocks.{i}.mlp.fc1.{weight,bias}, blocks.{i}.mlp.fc2.{weight,bias},
+ *   blocks.{i}.ls2.gamma, norm.{weight,bias}
+ * d_bf16 is a device pointer to the bf16 tensor in its native layout; the caller keeps it alive.
+ * patch_embed.proj.weight is copied into a K-padded private buffer. */
+int fp_vit_set_weight(fp_vit* vit, const char* name, const void* d_bf16, size_t numel, void* stream);
+/* feature_type: 0 = cls [B,dim], 1 = reg [B,n_reg,dim], 2 = patch [B,P,dim]  (dino.py:25-30).
+ * d_images: bf16 [B,3,H,W] in [0,1] (ImageNet normalisation is fused, dino.py:12,16);
+ * runs blocks 0..layer-1 (all blocks if layer > depth, dino.py:18-21) then the final norm. */
+int fp_vit_forward(fp_vit* vit, const void* d_images, int B, int H, int W, int layer, int feature_type,
+                   void* d_out_bf16, void* stream);
+/* algorithmic FLOPs of one fp_vit_forward call (SURVEY §8d formula) */
+double fp_vit_flops(const fp_vit* vit, int B, int H, int W, int layer);
+
+/* ---- a3: FFA descriptor (scripts/extract_retrieval_features.py:49-57, extract_proposals_ground.py:126-134) */
+/* d_feats bf16 [B,P,D]; d_mask u8 [B, gh*cell, gw*cell] (cell=14: any-pool == cv2 INTER_AREA > 0) or
+ * [B,P] with cell=1.  d_out_bf16 [B,D] (may be NULL), d_out_f32 [B,D] (bf16 values widened, may be NULL);
+ * normalize != 0 applies F.normalize(dim=-1) with bf16 rounding points to d_out_bf16. */
+int fp_ffa(fp_ctx* ctx, const void* d_feats, const uint8_t* d_mask, int B, int gh, int gw, int D, int cell,
+           int normalize, void* d_out_bf16, float* d_out_f32, void* stream);
+
+/* ---- a4: cosine top-k retrieval (scripts/extract_proposals_ground.py:39-41,136-140) ------------------- */
+/* bank prep: fp32 [N,D] -> bf16 -> row L2-normalise in bf16 (ground.py:40-41).  d_bank_bf16 out [N,D]. */
+int fp_bank_prepare(fp_ctx* ctx, const float* d_bank_f32, int N, int D, void* d_bank_bf16, void* stream);
+/* scores = bf16(bank @ q).float(); top-k by (score desc, index asc).  d_queries bf16 [Q,D].
+ * idx_offset is added to every returned index (bank-row sharding across ranks). */
+int fp_bank_topk(fp_ctx* ctx, const void* d_bank_bf16, int N, int D, const void* d_queries, int Q, int k,
+                 int idx_offset, float* d_out_scores, int32_t* d_out_idx, void* stream);
+/* merge per-shard candidates [Q,C] down to [Q,k] with the same ordering (after an RCCL all-gather). */
+int fp_topk_merge(fp_ctx* ctx, const float* d_cand_scores, const int32_t* d_cand_idx, int Q, int C, int k,
+                  float* d_out_scores, int32_t* d_out_idx, void* stream);
+/* F.normalize(x, dim=-1) on bf16 rows with the reference's rounding points. */
+int fp_l2_normalize(fp_ctx* ctx, const void* d_x_bf16, int rows, int D, void* d_y_bf16, void* stream);
+
+/* ---- a7/a10: patchwise template score (pose_estimator.py:85-88, online_pose_estimator.py:68-79) ------- */
+/* d_tmpl bf16 [T,P,D] raw template features (normalised on the fly), d_query bf16 [P,D] used AS GIVEN
+ * (callers pass F.normalize'd or raw features exactly where the reference does).  d_weights f32 [T,P] or
+ * NULL (mask_scores variant).  d_scores f32 [T]. */
+int fp_template_score(fp_ctx* ctx, const void* d_tmpl, const void* d_query, const float* d_weights, int T, int P,
+                      int D, float* d_scores, void* stream);
+
+/* ---- a5: CropResizePad (src/utils/bbox_utils.py:20-56) as used by Proposals (src/pipeline/utils.py:32-52)
+ * and MeshRenderer.generate_proposals (renderer.py:109-130) -------------------------------------------- */
+/* d_images: src_fmt 0 = f32 [n_img,C,H,W] in [0,1]; 1 = u8 [n_img,H,W,C] (divided by 255 like
+ * renderer.py:121).  n_img is 1 (all boxes crop the same image, Proposals) or n (one image per box, renders).
+ * d_boxes i32 [n,4] xyxy BEFORE extension.  d_masks u8 [n,H,W] or NULL; mask_mode 0 = ignore,
+ * 1 = multiply pixels by the mask (mask_rgb=True, utils.py:39-40), 2 = output the mask itself as 0/1
+ * (utils.py:35-37,48-51).  d_out: out_fmt 0 = f32, 1 = bf16, shape [n,C,target,target].
+ * Nearest-neighbour index rules replicate F.interpolate exactly (bbox_utils.py:29-35,52-54). */
+int fp_crop_resize_pad(fp_ctx* ctx, const void* d_images, int src_fmt, int n_img, int C, int H, int W,
+                       const int32_t* d_boxes, int n, float bbox_extend, int target, const uint8_t* d_masks,
+                       int mask_mode, void* d_out, int out_fmt, void* stream);
+
+/* ---- a8/a10: rotation grids and neighbourhood (pose_estimator.py:121-147, online_pose_estimator.py:25-34,55-56) */
+/* super-Fibonacci rotations, fp64 [n,3,3] row-major written to HOST memory (one-off setup, n=600/20000). */
+int fp_generate_rotations(int n, double* h_out);
+/* indices i with geodesic(R_i, R_prev) < thresh_deg; d_grid f64 [G,3,3] (device), h_Rprev9 f64 row-major
+ * (host); out idx ascending (np.where order), count in *h_n.  Synchronises the stream (the count decides
+ * how many hypotheses are rendered next). */
+int fp_geodesic_select(fp_ctx* ctx, const double* d_grid, int G, const double* h_Rprev9, double thresh_deg,
+                       int32_t* d_out_idx, int* h_n, void* stream);
+
+/* ---- a11: MeshRenderer (src/pipeline/retrieval/renderer.py:43-95; pyrender/OpenGL semantics) ---------- */
+/* vertices f32 [V,3], faces i32 [F,3], per-vertex colours u8 [V,3] or NULL (white).  All host pointers. */
+int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F,
+                   const uint8_t* h_colors, fp_mesh** out);
+int fp_mesh_destroy(fp_mesh* mesh);
+/* poses f32 [Hn,4,4] (OpenCV camera frame, object->camera), intrinsics fx,fy,cx,cy, image W x Hh.
+ * scale multiplies the vertices (rendering_scale 0.25).  Outputs rgb u8 [Hn,Hh,W,3], depth f32 [Hn,Hh,W]
+ * (metric eye depth, 0 = background).  Ambient-only shading, no culling (renderer.py:53-55,66). */
+int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx, float fy,
+                 float cx, float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, void* stream);
+/* a9/K17: per view, bbox of depth>0 (with the <100 px fallback square) and metric extents of the
+ * back-projected cloud: out f32 [Hn,8] = {xmin,ymin,xmax,ymax (px), dx, dy (m), count, 0}. */
+int fp_depth_extents(fp_ctx* ctx, const float* d_depth, int Hn, int Hh, int W, float fx, float fy, float cx,
+                     float cy, float* d_out, void* stream);
+
+/* ---- kernel-level entry points (unit parity tests, microbenchmarks; the ViT forward is built from these) */
+/* C[M,N] = epi(X[M,K] W[N,K]^T + bias): epi 0 = bias, 1 = bias+GELU(erf), 2 = resid + gamma*(.) ; bf16, ld* in
+ * elements (multiples of 8), K % 64 == 0, N % 16 == 0. */
+int fp_op_gemm(const void* d_X, int ldx, const void* d_W, int ldw, void* d_C, int ldc, const void* d_bias,
+               const void* d_gamma, const void* d_resid, int ldr, int M, int N, int K, int epi, void* stream);
+/* V part of qkv stored transposed per head: Vt[b,h,d,t] for rows m = b*npad + t, n = h*64 + d */
+int fp_op_gemm_vt(const void* d_X, int ldx, const void* d_W, int ldw, void* d_Vt, const void* d_bias, int M, int N,
+                  int K, int npad, int heads, void* stream);
+/* flash attention forward on QK [B*npad, 2*H*64] (ldqk elements) + Vt [B,H,64,npad] -> O [B*npad, H*64] */
+int fp_op_attention(const void* d_QK, int ldqk, const void* d_Vt, void* d_O, int ldo, int B, int H, int n_tok,
+                    int npad, void* stream);
+int fp_op_layernorm(const void* d_X, void* d_Y, const void* d_gamma, const void* d_beta, int rows, int D, float eps,
+                    void* stream);
+
+/* ---- measurement helpers (bench.py: HIP-event timing on the launch stream) ----------------------------- */
+int fp_timer_create(void** out);
+int fp_timer_start(void* timer, void* stream);
+int fp_timer_stop(void* timer, void* stream);
+int fp_timer_elapsed_ms(void* timer, float* h_ms); /* synchronises on the stop event */
+int fp_timer_destroy(void* timer);
+/* toggles per-kernel-class event timing inside fp_vit_forward (gemm / attention / other), read back in ms */
+int fp_vit_profile(fp_vit* vit, int enable);
+int fp_vit_profile_read(fp_vit* vit, float* h_ms_gemm, float* h_ms_attn, float* h_ms_other, double* h_gemm_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREEPOSE_HIP_H */

@@ -1,0 +1,409 @@
+/* fp_oracle.c — CPU restatement of FreePose's per-proposal hot path (scalar C, one thread).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under freepose_amd/ imports, links or executes this file; it is used by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker / reported CPU baseline.
+ *
+ * Each function names the reference lines (ponimatkin/freepose) whose behaviour it restates.  Where the
+ * reference leaves floating-point evaluation order to a library (torch matmul / mean on bf16 tensors) this
+ * file FIXES one order — "dot64", below — and the HIP kernels implement the same order, so indices and
+ * scores compare bit for bit.  The reference's own bf16 rounding points are kept.
+ *
+ * Build: gcc -O2 -std=c11 -fPIC -shared -ffp-contract=off -o libfp_oracle.so fp_oracle.c -lm
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint16_t bf16;
+
+static inline float bf2f(bf16 h) { uint32_t u = ((uint32_t)h) << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline bf16 f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16)(u >> 16);
+}
+static inline float rbf(float f) { return bf2f(f2bf(f)); }
+
+/* ---- dot64: the canonical 64-lane summation order ------------------------------------------------
+ * lane l owns elements (c*64 + l)*8 + e ; per-lane fmaf chain over (c,e) ascending ; then a xor-butterfly
+ * over offsets 32,16,8,4,2,1 (every lane adds its partner: all lanes end with the same value).          */
+static float butterfly64(float* p) {
+    float t[64];
+    for (int off = 32; off > 0; off >>= 1) {
+        for (int l = 0; l < 64; ++l) t[l] = p[l] + p[l ^ off];
+        memcpy(p, t, sizeof(t));
+    }
+    return p[0];
+}
+static float dot64_bf(const bf16* a, const bf16* b, int D) {
+    float p[64];
+    for (int l = 0; l < 64; ++l) {
+        float acc = 0.f;
+        for (int base = l * 8; base < D; base += 512)
+            for (int e = 0; e < 8; ++e) acc = fmaf(bf2f(a[base + e]), bf2f(b[base + e]), acc);
+        p[l] = acc;
+    }
+    return butterfly64(p);
+}
+static float dot64_ff(const float* a, const float* b, int D) {
+    float p[64];
+    for (int l = 0; l < 64; ++l) {
+        float acc = 0.f;
+        for (int base = l * 8; base < D; base += 512)
+            for (int e = 0; e < 8; ++e) acc = fmaf(a[base + e], b[base + e], acc);
+        p[l] = acc;
+    }
+    return butterfly64(p);
+}
+
+/* F.normalize(x, dim=-1) on a bf16 row (scripts/extract_proposals_ground.py:41,134; pose_estimator.py:88):
+ * n = bf16(sqrt(sum x^2)), y = bf16(x / max(n, 1e-12)) */
+void fpo_l2norm_rows(const bf16* x, bf16* y, int rows, int D) {
+    for (int r = 0; r < rows; ++r) {
+        const bf16* xr = x + (size_t)r * D;
+        float n = rbf(sqrtf(dot64_bf(xr, xr, D)));
+        if (n < 1e-12f) n = 1e-12f;
+        for (int i = 0; i < D; ++i) y[(size_t)r * D + i] = f2bf(bf2f(xr[i]) / n);
+    }
+}
+
+/* bank prep: fp32 -> bf16 -> normalise (extract_proposals_ground.py:39-41) */
+void fpo_bank_prepare(const float* bank, bf16* out, int N, int D) {
+    bf16* tmp = (bf16*)malloc((size_t)N * D * 2);
+    for (size_t i = 0; i < (size_t)N * D; ++i) tmp[i] = f2bf(bank[i]);
+    fpo_l2norm_rows(tmp, out, N, D);
+    free(tmp);
+}
+
+/* scores = bf16(bank @ q).float()  (extract_proposals_ground.py:137) */
+void fpo_bank_scores(const bf16* bank, const bf16* q, float* scores, int N, int D) {
+    for (int r = 0; r < N; ++r) scores[r] = rbf(dot64_bf(bank + (size_t)r * D, q, D));
+}
+
+/* top-k with the canonical order (score desc, index asc); extract_proposals_ground.py:140 (torch.topk,
+ * whose tie order is unspecified). */
+typedef struct { float s; int i; } cand_t;
+static int cand_cmp(const void* a, const void* b) {
+    const cand_t* x = (const cand_t*)a; const cand_t* y = (const cand_t*)b;
+    if (x->s > y->s) return -1;
+    if (x->s < y->s) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+void fpo_topk(const float* scores, int N, int k, int idx_offset, float* out_s, int32_t* out_i) {
+    cand_t* c = (cand_t*)malloc((size_t)N * sizeof(cand_t));
+    for (int r = 0; r < N; ++r) { c[r].s = scores[r]; c[r].i = r; }
+    qsort(c, N, sizeof(cand_t), cand_cmp);
+    for (int j = 0; j < k; ++j) { out_s[j] = c[j].s; out_i[j] = c[j].i + idx_offset; }
+    free(c);
+}
+void fpo_bank_topk(const bf16* bank, int N, int D, const bf16* queries, int Q, int k, int idx_offset, float* out_s,
+                   int32_t* out_i) {
+    float* sc = (float*)malloc((size_t)N * 4);
+    for (int q = 0; q < Q; ++q) {
+        fpo_bank_scores(bank, queries + (size_t)q * D, sc, N, D);
+        fpo_topk(sc, N, k, idx_offset, out_s + (size_t)q * k, out_i + (size_t)q * k);
+    }
+    free(sc);
+}
+/* merge of per-shard candidate lists: same ordering on (score, global index) */
+void fpo_topk_merge(const float* cs, const int32_t* ci, int C, int k, float* out_s, int32_t* out_i) {
+    cand_t* c = (cand_t*)malloc((size_t)C * sizeof(cand_t));
+    for (int r = 0; r < C; ++r) { c[r].s = cs[r]; c[r].i = ci[r]; }
+    qsort(c, C, sizeof(cand_t), cand_cmp);
+    for (int j = 0; j < k; ++j) { out_s[j] = c[j].s; out_i[j] = c[j].i; }
+    free(c);
+}
+
+/* FFA (scripts/extract_retrieval_features.py:51-57; extract_proposals_ground.py:129-134):
+ * mask -> cv2.resize(INTER_AREA) > 0 == any pixel of the cell x cell block; feat[mask].mean(0) in bf16
+ * (fp32 accumulate in ascending patch order, divide, round). out_bf may be NULL; out_f32 gets the bf16
+ * value widened (the .float() of :57). */
+void fpo_ffa(const bf16* feats, const uint8_t* mask, int B, int gh, int gw, int D, int cell, bf16* out_bf,
+             float* out_f32) {
+    const int P = gh * gw, Wm = gw * cell;
+    uint8_t* pm = (uint8_t*)malloc(P);
+    float* acc = (float*)malloc((size_t)D * 4);
+    for (int b = 0; b < B; ++b) {
+        int cnt = 0;
+        for (int p = 0; p < P; ++p) {
+            const int py = p / gw, px = p % gw;
+            int any = 0;
+            for (int dy = 0; dy < cell; ++dy)
+                for (int dx = 0; dx < cell; ++dx)
+                    any |= mask[(size_t)b * gh * cell * Wm + (size_t)(py * cell + dy) * Wm + px * cell + dx];
+            pm[p] = any ? 1 : 0;
+            cnt += pm[p];
+        }
+        for (int d = 0; d < D; ++d) acc[d] = 0.f;
+        for (int p = 0; p < P; ++p)
+            if (pm[p])
+                for (int d = 0; d < D; ++d) acc[d] += bf2f(feats[((size_t)b * P + p) * D + d]);
+        for (int d = 0; d < D; ++d) {
+            const float m = acc[d] / (float)cnt;
+            if (out_bf) out_bf[(size_t)b * D + d] = f2bf(m);
+            if (out_f32) out_f32[(size_t)b * D + d] = rbf(m);
+        }
+    }
+    free(pm); free(acc);
+}
+
+/* patchwise template score (src/pipeline/estimators/pose_estimator.py:85-88; online_pose_estimator.py:68-79):
+ * einsum(F.normalize(T), q, 'b n d, b n d -> b n').mean(-1), all tensors bf16.  q is used as given.
+ * weights != NULL: (scores*masks).sum(-1)/masks.sum(-1) in fp32 (online :69-74). */
+void fpo_template_score(const bf16* tmpl, const bf16* q, const float* weights, int T, int P, int D, float* scores) {
+    float* tn = (float*)malloc((size_t)D * 4);
+    float* qf = (float*)malloc((size_t)D * 4);
+    float* dots = (float*)malloc((size_t)P * 4);
+    for (int t = 0; t < T; ++t) {
+        for (int p = 0; p < P; ++p) {
+            const bf16* x = tmpl + ((size_t)t * P + p) * D;
+            float n = rbf(sqrtf(dot64_bf(x, x, D)));
+            if (n < 1e-12f) n = 1e-12f;
+            for (int i = 0; i < D; ++i) { tn[i] = rbf(bf2f(x[i]) / n); qf[i] = bf2f(q[(size_t)p * D + i]); }
+            dots[p] = rbf(dot64_ff(tn, qf, D));
+        }
+        /* mean over patches: lane l sums p = l, l+64, ... then butterfly */
+        float pl[64], wl[64];
+        for (int l = 0; l < 64; ++l) {
+            float a = 0.f, w = 0.f;
+            for (int p = l; p < P; p += 64) {
+                if (weights) { a += dots[p] * weights[(size_t)t * P + p]; w += weights[(size_t)t * P + p]; }
+                else a += dots[p];
+            }
+            pl[l] = a; wl[l] = w;
+        }
+        const float s = butterfly64(pl);
+        if (weights) scores[t] = s / butterfly64(wl);
+        else scores[t] = rbf(s / (float)P);
+    }
+    free(tn); free(qf); free(dots);
+}
+
+/* CropResizePad.__call__ (src/utils/bbox_utils.py:20-56).  images f32 [n_img,C,H,W] (src_u8=0) or
+ * u8 [n_img,H,W,C] (src_u8=1, value/255 as in renderer.py:121); out f32 [n,C,target,target].
+ * mask_mode as in include/freepose_hip.h.  Returns 0, or 1+i if box i does not resize to `target`. */
+int fpo_crop_resize_pad(const void* images, int src_u8, int n_img, int C, int H, int W, const int32_t* boxes, int n,
+                        float ext, int target, const uint8_t* masks, int mask_mode, float* out) {
+    for (int i = 0; i < n; ++i) {
+        int x0 = boxes[4 * i], y0 = boxes[4 * i + 1], x1 = boxes[4 * i + 2], y1 = boxes[4 * i + 3];
+        const int bw = x1 - x0, bh = y1 - y0;
+        if (ext == 0.f) {                        /* :22-28 with integer bbox_extend */
+            if (x0 < 0) x0 = 0; if (x1 > W) x1 = W; if (y0 < 0) y0 = 0; if (y1 > H) y1 = H;
+        } else {                                 /* float32 tensor arithmetic, truncating assignment */
+            const float ew = ext * (float)bw, eh = ext * (float)bh;
+            const float fx0 = (float)x0 - ew, fx1 = (float)x1 + ew, fy0 = (float)y0 - eh, fy1 = (float)y1 + eh;
+            x0 = fx0 > 0.f ? (int)fx0 : 0; x1 = fx1 < (float)W ? (int)fx1 : W;
+            y0 = fy0 > 0.f ? (int)fy0 : 0; y1 = fy1 < (float)H ? (int)fy1 : H;
+        }
+        const int cw = x1 - x0, ch = y1 - y0;
+        const int side = cw > ch ? cw : ch;
+        /* :30  `self.target_max / torch.max(...)` is Tensor.__rtruediv__ = reciprocal(tensor) * scalar in
+         * float32 (two roundings, not one division); then .item() widens to double (:34) */
+        const float recip = 1.0f / (float)side;
+        const double scale = (double)(recip * (float)target);
+        const int h1 = (int)floor((double)ch * scale), w1 = (int)floor((double)cw * scale);
+        const float inv1 = (float)(1.0 / scale);                          /* nearest: float(1/scale_factor) */
+        int pad_t = 0, pad_l = 0, S_h = h1, S_w = w1;
+        if ((double)w1 / (double)h1 != 1.0) {                             /* :41-48 */
+            pad_t = (target - h1) / 2; if (pad_t < 0 || target - h1 < 0) pad_t = 0;
+            pad_l = (target - w1) / 2; if (pad_l < 0 || target - w1 < 0) pad_l = 0;
+            S_h = target; S_w = target;
+        }
+        const double scale2 = (double)target / (double)S_h;               /* :52-54 */
+        const int outsz = (int)floor((double)S_h * scale2);
+        const float inv2 = (float)(1.0 / scale2);
+        if (outsz != target || cw <= 0 || ch <= 0) return 1 + i;
+        const int img = n_img == 1 ? 0 : i;
+        for (int oy = 0; oy < target; ++oy)
+            for (int ox = 0; ox < target; ++ox) {
+                int y2 = (int)floorf((float)oy * inv2); if (y2 > S_h - 1) y2 = S_h - 1;
+                int x2 = (int)floorf((float)ox * inv2); if (x2 > S_w - 1) x2 = S_w - 1;
+                const int yy = y2 - pad_t, xx = x2 - pad_l;
+                const int valid = !(yy < 0 || yy >= h1 || xx < 0 || xx >= w1);
+                int ys = 0, xs = 0;
+                if (valid) {
+                    ys = (int)floorf((float)yy * inv1); if (ys > ch - 1) ys = ch - 1; ys += y0;
+                    xs = (int)floorf((float)xx * inv1); if (xs > cw - 1) xs = cw - 1; xs += x0;
+                }
+                float m = 1.f;
+                if (valid && masks && mask_mode) m = masks[((size_t)i * H + ys) * W + xs] ? 1.f : 0.f;
+                for (int c = 0; c < C; ++c) {
+                    float v = 0.f;
+                    if (valid) {
+                        if (mask_mode == 2) v = m;
+                        else {
+                            if (src_u8) v = (float)((double)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c] / 255.0);
+                            else v = ((const float*)images)[(((size_t)img * C + c) * H + ys) * W + xs];
+                            v *= m;
+                        }
+                    }
+                    out[(((size_t)i * C + c) * target + oy) * target + ox] = v;
+                }
+            }
+    }
+    return 0;
+}
+
+/* super-Fibonacci rotation grid (src/pipeline/estimators/pose_estimator.py:121-147, renderer.py:12-35):
+ * scalar-last quaternion -> matrix as scipy Rotation.from_quat(q).as_matrix() */
+void fpo_generate_rotations(int n, double* out) {
+    const double phi = sqrt(2.0), psi = 1.533751168755204288118041, PI = 3.14159265358979323846;
+    for (int i = 0; i < n; ++i) {
+        const double s = i + 0.5, r = sqrt(s / n), R = sqrt(1.0 - s / n);
+        const double al = 2.0 * PI * s / phi, be = 2.0 * PI * s / psi;
+        double x = r * sin(al), y = r * cos(al), z = R * sin(be), w = R * cos(be);
+        const double nn = sqrt(x * x + y * y + z * z + w * w);
+        x /= nn; y /= nn; z /= nn; w /= nn;
+        double* M = out + (size_t)i * 9;
+        M[0] = x * x - y * y - z * z + w * w; M[1] = 2 * (x * y - z * w); M[2] = 2 * (x * z + y * w);
+        M[3] = 2 * (x * y + z * w); M[4] = -x * x + y * y - z * z + w * w; M[5] = 2 * (y * z - x * w);
+        M[6] = 2 * (x * z - y * w); M[7] = 2 * (y * z + x * w); M[8] = -x * x - y * y + z * z + w * w;
+    }
+}
+
+/* geodesic neighbourhood (online_pose_estimator.py:25-34,55-56): angle of R_i R_prev^T in degrees < thresh */
+int fpo_geodesic_select(const double* grid, int G, const double* Rp, double thresh_deg, int32_t* out_idx) {
+    int n = 0;
+    for (int i = 0; i < G; ++i) {
+        const double* R = grid + (size_t)i * 9;
+        double D[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) D[3 * r + c] = R[3 * r] * Rp[3 * c] + R[3 * r + 1] * Rp[3 * c + 1] + R[3 * r + 2] * Rp[3 * c + 2];
+        const double cosv = 0.5 * (D[0] + D[4] + D[8] - 1.0);
+        const double a = D[7] - D[5], b = D[2] - D[6], c = D[3] - D[1];
+        const double ang = atan2(0.5 * sqrt(a * a + b * b + c * c), cosv) * 57.29577951308232;
+        if (ang < thresh_deg) out_idx[n++] = i;
+    }
+    return n;
+}
+
+/* depth>0 mask bbox with the <100 px fallback (renderer.py:112-119; template.py:73-78) and the x/y extents of
+ * depthmap_to_pointcloud (src/pipeline/utils.py:122-145,157-158).  out [Hn,8] as in freepose_hip.h */
+void fpo_depth_extents(const float* depth, int Hn, int Hh, int W, double fx, double fy, double cx, double cy, float* out) {
+    for (int v = 0; v < Hn; ++v) {
+        const float* d = depth + (size_t)v * Hh * W;
+        int cnt = 0, xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1, any = 0;
+        double Xmin = 1e300, Xmax = -1e300, Ymin = 1e300, Ymax = -1e300;
+        for (int y = 0; y < Hh; ++y)
+            for (int x = 0; x < W; ++x) {
+                const float z = d[y * W + x];
+                if (z != 0.f) {
+                    any = 1;
+                    const double X = ((double)x - cx) / fx * (double)z, Y = ((double)y - cy) / fy * (double)z;
+                    if (X < Xmin) Xmin = X; if (X > Xmax) Xmax = X; if (Y < Ymin) Ymin = Y; if (Y > Ymax) Ymax = Y;
+                    if (z > 0.f) { ++cnt; if (x < xmin) xmin = x; if (x > xmax) xmax = x; if (y < ymin) ymin = y; if (y > ymax) ymax = y; }
+                }
+            }
+        if (cnt < 100) {
+            const int lo = 105, hx = (315 < W ? 315 : W) - 1, hy = (315 < Hh ? 315 : Hh) - 1;
+            if (cnt == 0) { xmin = lo; ymin = lo; xmax = hx; ymax = hy; }
+            else { if (lo < xmin) xmin = lo; if (lo < ymin) ymin = lo; if (hx > xmax) xmax = hx; if (hy > ymax) ymax = hy; }
+        }
+        float* o = out + (size_t)v * 8;
+        o[0] = (float)xmin; o[1] = (float)ymin; o[2] = (float)xmax; o[3] = (float)ymax;
+        o[4] = any ? (float)(Xmax - Xmin) : 0.f; o[5] = any ? (float)(Ymax - Ymin) : 0.f;
+        o[6] = (float)cnt; o[7] = 0.f;
+    }
+}
+
+/* ---- rasteriser: restatement of the arithmetic contract in freepose_amd/csrc/raster.hip's header
+ * (pyrender/OpenGL is not in /root/reference: renderer.py:37-41,53-55,66 fix K, flip, ambient, no-cull;
+ * bop_toolkit_lib/renderer_py.py:186-231 the K->projection convention).  Scan order here is triangle-major
+ * with an explicit (depth, id) min — the same total order the atomic 64-bit min realises on the GPU. */
+typedef struct { int xi, yi; float iz, zc; } svert_t;
+static int topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
+
+void fpo_rasterize(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
+                   const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
+                   uint8_t* rgb, float* depth) {
+    const float ZNEAR = 0.05f;
+    svert_t* sv = (svert_t*)malloc((size_t)V * sizeof(svert_t));
+    uint64_t* zb = (uint64_t*)malloc((size_t)W * Hh * 8);
+    for (int h = 0; h < Hn; ++h) {
+        const float* P = poses + (size_t)h * 16;
+        for (int i = 0; i < V; ++i) {
+            const float sx = scale * verts[3 * i], sy = scale * verts[3 * i + 1], sz = scale * verts[3 * i + 2];
+            const float Xc = fmaf(P[0], sx, fmaf(P[1], sy, fmaf(P[2], sz, P[3])));
+            const float Yc = fmaf(P[4], sx, fmaf(P[5], sy, fmaf(P[6], sz, P[7])));
+            const float Zc = fmaf(P[8], sx, fmaf(P[9], sy, fmaf(P[10], sz, P[11])));
+            sv[i].zc = Zc; sv[i].xi = 0; sv[i].yi = 0; sv[i].iz = 0.f;
+            if (Zc > ZNEAR) {
+                const float iz = 1.0f / Zc;
+                float u = fmaf(fx, Xc * iz, cx), v = fmaf(fy, Yc * iz, cy);
+                u = fminf(fmaxf(u, -30000.f), 30000.f); v = fminf(fmaxf(v, -30000.f), 30000.f);
+                sv[i].xi = (int)rintf(u * 256.0f); sv[i].yi = (int)rintf(v * 256.0f); sv[i].iz = iz;
+            }
+        }
+        for (size_t i = 0; i < (size_t)W * Hh; ++i) zb[i] = ~0ull;
+        for (int f = 0; f < F; ++f) {
+            int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+            svert_t a = sv[i0], b = sv[i1], c = sv[i2];
+            if (!(a.zc > ZNEAR && b.zc > ZNEAR && c.zc > ZNEAR)) continue;
+            int64_t area2 = (int64_t)(b.xi - a.xi) * (c.yi - a.yi) - (int64_t)(b.yi - a.yi) * (c.xi - a.xi);
+            if (area2 < 0) { svert_t t = b; b = c; c = t; area2 = -area2; }
+            if (area2 == 0) continue;
+            int mnx = a.xi < b.xi ? a.xi : b.xi; if (c.xi < mnx) mnx = c.xi;
+            int mxx = a.xi > b.xi ? a.xi : b.xi; if (c.xi > mxx) mxx = c.xi;
+            int mny = a.yi < b.yi ? a.yi : b.yi; if (c.yi < mny) mny = c.yi;
+            int mxy = a.yi > b.yi ? a.yi : b.yi; if (c.yi > mxy) mxy = c.yi;
+            int bx0 = (int)floor((double)(mnx - 128 + 255) / 256.0), by0 = (int)floor((double)(mny - 128 + 255) / 256.0);
+            int bx1 = (int)floor((double)(mxx - 128) / 256.0), by1 = (int)floor((double)(mxy - 128) / 256.0);
+            if (bx0 < 0) bx0 = 0; if (by0 < 0) by0 = 0; if (bx1 > W - 1) bx1 = W - 1; if (by1 > Hh - 1) by1 = Hh - 1;
+            for (int py = by0; py <= by1; ++py)
+                for (int px = bx0; px <= bx1; ++px) {
+                    const int64_t sx = (int64_t)px * 256 + 128, sy = (int64_t)py * 256 + 128;
+                    const int64_t w0 = (int64_t)(c.xi - b.xi) * (sy - b.yi) - (int64_t)(c.yi - b.yi) * (sx - b.xi);
+                    const int64_t w1 = (int64_t)(a.xi - c.xi) * (sy - c.yi) - (int64_t)(a.yi - c.yi) * (sx - c.xi);
+                    const int64_t w2 = (int64_t)(b.xi - a.xi) * (sy - a.yi) - (int64_t)(b.yi - a.yi) * (sx - a.xi);
+                    if (w0 < 0 || w1 < 0 || w2 < 0) continue;
+                    if (w0 == 0 && !topleft(c.xi - b.xi, c.yi - b.yi)) continue;
+                    if (w1 == 0 && !topleft(a.xi - c.xi, a.yi - c.yi)) continue;
+                    if (w2 == 0 && !topleft(b.xi - a.xi, b.yi - a.yi)) continue;
+                    const float fa = (float)area2;
+                    const float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
+                    const float izp = fmaf(b2, c.iz, fmaf(b1, b.iz, b0 * a.iz));
+                    const float d = 1.0f / izp;
+                    if (!(d > 0.f)) continue;
+                    uint32_t db; memcpy(&db, &d, 4);
+                    const uint64_t key = ((uint64_t)db << 32) | (uint32_t)f;
+                    if (key < zb[(size_t)py * W + px]) zb[(size_t)py * W + px] = key;
+                }
+        }
+        for (int py = 0; py < Hh; ++py)
+            for (int px = 0; px < W; ++px) {
+                const uint64_t key = zb[(size_t)py * W + px];
+                float d = 0.f; uint8_t col[3] = {0, 0, 0};
+                if (key != ~0ull) {
+                    const int f = (int)(uint32_t)(key & 0xffffffffu);
+                    uint32_t db = (uint32_t)(key >> 32); memcpy(&d, &db, 4);
+                    int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+                    svert_t a = sv[i0], b = sv[i1], c = sv[i2];
+                    int64_t area2 = (int64_t)(b.xi - a.xi) * (c.yi - a.yi) - (int64_t)(b.yi - a.yi) * (c.xi - a.xi);
+                    if (area2 < 0) { svert_t t = b; b = c; c = t; int ti = i1; i1 = i2; i2 = ti; area2 = -area2; }
+                    const int64_t sx = (int64_t)px * 256 + 128, sy = (int64_t)py * 256 + 128;
+                    const int64_t w0 = (int64_t)(c.xi - b.xi) * (sy - b.yi) - (int64_t)(c.yi - b.yi) * (sx - b.xi);
+                    const int64_t w1 = (int64_t)(a.xi - c.xi) * (sy - c.yi) - (int64_t)(a.yi - c.yi) * (sx - c.xi);
+                    const int64_t w2 = (int64_t)(b.xi - a.xi) * (sy - a.yi) - (int64_t)(b.yi - a.yi) * (sx - a.xi);
+                    const float fa = (float)area2;
+                    const float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
+                    const float izp = fmaf(b2, c.iz, fmaf(b1, b.iz, b0 * a.iz));
+                    const float dd = 1.0f / izp;
+                    const float q0 = b0 * a.iz, q1 = b1 * b.iz, q2 = b2 * c.iz;
+                    for (int ch = 0; ch < 3; ++ch) {
+                        float c0 = 255.f, c1 = 255.f, c2 = 255.f;
+                        if (colors) { c0 = (float)colors[3 * i0 + ch]; c1 = (float)colors[3 * i1 + ch]; c2 = (float)colors[3 * i2 + ch]; }
+                        const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
+                        float amb = fminf(2.0f * cv + 0.5f, 255.0f);
+                        if (amb < 0.f) amb = 0.f;
+                        col[ch] = (uint8_t)amb;
+                    }
+                }
+                depth[((size_t)h * Hh + py) * W + px] = d;
+                uint8_t* o = rgb + (((size_t)h * Hh + py) * W + px) * 3;
+                o[0] = col[0]; o[1] = col[1]; o[2] = col[2];
+            }
+    }
+    free(sv); free(zb);
+}

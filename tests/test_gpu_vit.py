@@ -1,0 +1,68 @@
+"""End-to-end ViT parity on the MI355X: fp_vit_forward (HIP, bf16 storage / fp32 accumulate) vs the torch-fp32
+CPU restatement oracle/vit_ref.py on identical seeded weights and images.
+
+Tolerance (stated here): per-patch cosine >= 0.999 and relative L2 <= 2e-2 against the fp32
+oracle — the same distance class the reference's own bf16 model (oracle run in bf16) shows against fp32."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(B, H, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    # smooth-ish synthetic crops in [0,1] (pure white noise would be a degenerate ViT input)
+    low = rng.random((B, 3, H // 14, H // 14)).astype(np.float32)
+    img = torch.nn.functional.interpolate(torch.from_numpy(low), size=(H, H), mode="bilinear")
+    img = 0.8 * img + 0.2 * torch.from_numpy(rng.random((B, 3, H, H)).astype(np.float32))
+    return img.to(torch.bfloat16)
+
+
+def _metrics(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    return cos.min().item(), rel
+
+
+@pytest.mark.parametrize("model,H,layer,B", [("dinov2_vits14_reg", 224, 22, 2), ("dinov2_vitl14_reg", 420, 22, 2),
+                                             ("dinov2_vitl14_reg", 518, 2, 1), ("dinov2_vits14", 224, 5, 3)])
+def test_vit_forward_vs_fp32_oracle(model, H, layer, B):
+    from freepose_amd import ops
+    from oracle import vit_ref
+    sd = ops.random_state_dict(model, seed=3)
+    img = _images(B, H, 7)
+    vit = ops.ViT(model, sd)
+    sdf = {k: v.float() for k, v in sd.items()}
+    for ft in ("patch", "cls", "reg"):
+        if ft == "reg" and vit.n_reg == 0:
+            continue
+        got = vit(img, layer=layer, feature_type=ft)
+        torch.cuda.synchronize()
+        ref = vit_ref.vit_forward(sdf, img.float(), layer=layer, feature_type=ft, dtype=torch.float32)
+        assert got.shape == ref.shape
+        cmin, rel = _metrics(got, ref)
+        print(f"{model} {H} layer={layer} {ft}: min cos {cmin:.5f} rel {rel:.4f}")
+        assert cmin >= 0.999 and rel <= 2e-2, (model, ft, cmin, rel)
+    if model == "dinov2_vits14_reg":
+        # distance of the reference's own precision regime (torch CPU bf16 model) to fp32, for context
+        ref32 = vit_ref.vit_forward(sdf, img.float(), layer=layer, feature_type="patch", dtype=torch.float32)
+        ref16 = vit_ref.vit_forward(sdf, img.float(), layer=layer, feature_type="patch", dtype=torch.bfloat16)
+        c16, r16 = _metrics(ref16, ref32)
+        got = vit(img, layer=layer, feature_type="patch")
+        cg, rg = _metrics(got, ref32)
+        print(f"torch-bf16 vs fp32: cos {c16:.5f} rel {r16:.4f} | hip vs fp32: cos {cg:.5f} rel {rg:.4f}")
+        assert rg <= 2.0 * r16 + 2e-3
+
+
+def test_vit_batch_invariance_and_layer_semantics():
+    from freepose_amd import ops
+    vit = ops.ViT("dinov2_vits14_reg", seed=1)
+    img = _images(5, 224, 9)
+    full = vit(img, layer=22, feature_type="patch")
+    one = vit(img[2:3], layer=22, feature_type="patch")
+    assert torch.equal(full[2:3], one), "a crop's features must not depend on its batch neighbours"
+    # layer > depth runs every block (dino.py:18-21) == layer == depth
+    assert torch.equal(vit(img[:1], layer=12, feature_type="cls"), vit(img[:1], layer=99, feature_type="cls"))
+    assert not torch.equal(vit(img[:1], layer=11, feature_type="cls"), vit(img[:1], layer=12, feature_type="cls"))

@@ -60,6 +60,15 @@ __global__ void crop_params_kernel(const int32_t* __restrict__ boxes, int n, int
     out[i] = p;
 }
 
+// torch's CPU nearest source index for F.interpolate(scale_factor=s): ATen uses its nearest_idx kernel (identity when
+// out == in, idx >> 1 when out == 2*in) only when out_h + out_w <= 128 (`small`); the generic kernel used otherwise —
+// always, at the pipeline's 420 px — applies  min(floorf(dst * float(1/s)), in - 1)  unconditionally.
+__device__ __forceinline__ int nearest_src(int dst, int in, int out, float inv_scale, bool small) {
+    if (small && out == in) return dst;
+    if (small && out == 2 * in) return dst >> 1;
+    return min((int)floorf((float)dst * inv_scale), in - 1);
+}
+
 template <int SRC_U8, int OUT_BF16>
 __global__ __launch_bounds__(256) void crop_kernel(const void* __restrict__ images, int n_img, int C, int H, int W,
                                                    const CropParam* __restrict__ params, int target,
@@ -74,13 +83,14 @@ __global__ __launch_bounds__(256) void crop_kernel(const void* __restrict__ imag
     bool valid = (p.out == target) && p.cw > 0 && p.ch > 0;
     int ys = 0, xs = 0;
     if (valid) {
-        const int y2 = min((int)floorf((float)oy * p.inv2), p.S_h - 1);
-        const int x2 = min((int)floorf((float)ox * p.inv2), p.S_w - 1);
+        const bool small1 = (p.h1 + p.w1) <= 128, small2 = (2 * p.out) <= 128;
+        const int y2 = nearest_src(oy, p.S_h, p.out, p.inv2, small2);
+        const int x2 = nearest_src(ox, p.S_w, p.out, p.inv2, small2);
         const int y1 = y2 - p.pad_t, x1 = x2 - p.pad_l;
         if (y1 < 0 || y1 >= p.h1 || x1 < 0 || x1 >= p.w1) valid = false;
         else {
-            ys = p.y0 + min((int)floorf((float)y1 * p.inv1), p.ch - 1);
-            xs = p.x0 + min((int)floorf((float)x1 * p.inv1), p.cw - 1);
+            ys = p.y0 + nearest_src(y1, p.ch, p.h1, p.inv1, small1);
+            xs = p.x0 + nearest_src(x1, p.cw, p.w1, p.inv1, small1);
         }
     }
     float m = 1.f;
@@ -90,7 +100,8 @@ __global__ __launch_bounds__(256) void crop_kernel(const void* __restrict__ imag
         if (valid) {
             if (mask_mode == 2) v = m;
             else {
-                if (SRC_U8) v = (float)((double)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c] / 255.0);
+                if (SRC_U8 == 1) v = (float)((double)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c] / 255.0);
+                else if (SRC_U8 == 2) v = __fdiv_rn((float)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c], 255.0f);
                 else v = ((const float*)images)[(((size_t)img * C + c) * H + ys) * W + xs];
                 v *= m;
             }
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(1024) void compact_flags_kernel(const int32_t* __re
 // ---------------------------------------------------------------------------------------------
 // one block per view: count, bbox of (depth > 0) with the <100 px fallback square, fp64 extents
 __global__ __launch_bounds__(256) void depth_extents_kernel(const float* __restrict__ depth, int Hh, int W, double fx,
-                                                            double fy, double cx, double cy, float* __restrict__ out) {
+                                                            double fy, double cx, double cy, double* __restrict__ out) {
     const int v = blockIdx.x;
     const float* d = depth + (size_t)v * Hh * W;
     int cnt = 0, xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1;
@@ -183,11 +194,11 @@ __global__ __launch_bounds__(256) void depth_extents_kernel(const float* __restr
             if (c == 0) { bx0 = lo; by0 = lo; bx1 = hx; by1 = hy; }
             else { bx0 = min(bx0, lo); by0 = min(by0, lo); bx1 = max(bx1, hx); by1 = max(by1, hy); }
         }
-        float* o = out + (size_t)v * 8;
-        o[0] = (float)bx0; o[1] = (float)by0; o[2] = (float)bx1; o[3] = (float)by1;
-        o[4] = c > 0 || sd[1][0] > -1e299 ? (float)(sd[1][0] - sd[0][0]) : 0.f;
-        o[5] = c > 0 || sd[3][0] > -1e299 ? (float)(sd[3][0] - sd[2][0]) : 0.f;
-        o[6] = (float)c; o[7] = 0.f;
+        double* o = out + (size_t)v * 8;
+        o[0] = (double)bx0; o[1] = (double)by0; o[2] = (double)bx1; o[3] = (double)by1;
+        o[4] = sd[1][0] > -1e299 ? sd[1][0] - sd[0][0] : 0.0;
+        o[5] = sd[3][0] > -1e299 ? sd[3][0] - sd[2][0] : 0.0;
+        o[6] = (double)c; o[7] = 0.0;
     }
 }
 
@@ -201,7 +212,8 @@ int fp_crop_resize_pad_launch(const void* images, int src_u8, int n_img, int C, 
     FP_LAUNCH_CHECK();
     dim3 grid(cdiv(target, 256), target, n), block(256);
 #define FP_CROP(U, O) hipLaunchKernelGGL((crop_kernel<U, O>), grid, block, 0, s, images, n_img, C, H, W, params, target, masks, mask_mode, out)
-    if (src_u8) { if (out_bf16) FP_CROP(1, 1); else FP_CROP(1, 0); }
+    if (src_u8 == 1) { if (out_bf16) FP_CROP(1, 1); else FP_CROP(1, 0); }
+    else if (src_u8 == 2) { if (out_bf16) FP_CROP(2, 1); else FP_CROP(2, 0); }
     else { if (out_bf16) FP_CROP(0, 1); else FP_CROP(0, 0); }
 #undef FP_CROP
     FP_LAUNCH_CHECK();
@@ -248,7 +260,7 @@ extern "C" int fp_geodesic_select(fp_ctx* ctx, const double* d_grid, int G, cons
 }
 
 extern "C" int fp_depth_extents(fp_ctx* ctx, const float* d_depth, int Hn, int Hh, int W, float fx, float fy, float cx,
-                                float cy, float* d_out, void* stream) {
+                                float cy, double* d_out, void* stream) {
     FP_REQUIRE(ctx && d_depth && d_out, "depth_extents: null argument");
     if (Hn == 0) return FP_OK;
     hipLaunchKernelGGL(depth_extents_kernel, dim3(Hn), dim3(256), 0, (hipStream_t)stream, d_depth, Hh, W, (double)fx,

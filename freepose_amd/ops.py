@@ -230,13 +230,15 @@ def template_score(tmpl: torch.Tensor, query: torch.Tensor, weights: Optional[to
 
 
 def crop_resize_pad(images: torch.Tensor, boxes: torch.Tensor, target: int, bbox_extend: float = 0.0,
-                    masks: Optional[torch.Tensor] = None, mask_mode: int = 0, out_bf16: bool = False) -> torch.Tensor:
-    """images f32 [n_img,C,H,W] or u8 [n_img,H,W,C]; boxes int [n,4] xyxy."""
+                    masks: Optional[torch.Tensor] = None, mask_mode: int = 0, out_bf16: bool = False,
+                    u8_float_div: bool = False) -> torch.Tensor:
+    """images f32 [n_img,C,H,W] or u8 [n_img,H,W,C]; boxes int [n,4] xyxy.  u8 pixels become
+    float(double(x)/255) (renderer.py:121) or, with u8_float_div, float(x)/255.f (utils.py:20)."""
     lib = _lib.load()
     if images.dtype == torch.uint8:
         img = _dev(images)
         n_img, H, W, Cc = img.shape
-        src = 1
+        src = 2 if u8_float_div else 1
     else:
         img = _dev(images, torch.float32)
         n_img, Cc, H, W = img.shape
@@ -310,7 +312,7 @@ def depth_extents(depth: torch.Tensor, fx: float, fy: float, cx: float, cy: floa
     lib = _lib.load()
     d = _dev(depth, torch.float32)
     Hn, H, W = d.shape
-    out = torch.empty((Hn, 8), dtype=torch.float32, device=d.device)
+    out = torch.empty((Hn, 8), dtype=torch.float64, device=d.device)
     if Hn:
         check(lib.fp_depth_extents(context(), ptr(d), Hn, H, W, float(fx), float(fy), float(cx), float(cy), ptr(out),
                                    current_stream()), "fp_depth_extents")

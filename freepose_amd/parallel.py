@@ -1,0 +1,100 @@
+"""Single-node multi-GPU layer: one process per GPU over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm;
+"gloo" in the CPU tests).  The hot path shards without a data-path exchange (proposals / frames / meshes are
+independent: SURVEY §8e); the only collectives are tiny all-gathers of results:
+
+  * bank-row sharding:  every rank scans its rows for all Q queries, all-gathers Q*k (score f32, index i32) pairs
+    and merges them with the canonical (score desc, index asc) rule -> identical top-k on every rank;
+  * proposal / frame / object sharding: ranks own disjoint work items and all-gather fixed-size result rows.
+
+The reference has no counterpart (its parallelism is SLURM array jobs + files: scripts/extract_retrieval_features.py:32-34,
+scripts/dino_inference.py:51-54, merge_results.py).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank); initialises the default process group when launched by torch.distributed.run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """contiguous, balanced [lo, hi) slice of n items (bank rows, meshes)"""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_items(n: int, rank: int, world_size: int) -> List[int]:
+    """round-robin item ids (proposals, frames, objects): balances cost that grows with the index"""
+    return list(range(rank, n, world_size))
+
+
+def all_gather_cat(t: torch.Tensor, dim: int = 0) -> torch.Tensor:
+    """all-gather equally-shaped tensors and concatenate along `dim` (rank order)."""
+    rank, ws = world()
+    if ws == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(ws)]
+    dist.all_gather(parts, t.contiguous())
+    return torch.cat(parts, dim=dim)
+
+
+def all_gather_rows(rows: torch.Tensor, counts: Sequence[int] | None = None) -> torch.Tensor:
+    """all-gather a variable number of fixed-width rows per rank (pads to the max count)."""
+    rank, ws = world()
+    if ws == 1:
+        return rows
+    n = torch.tensor([rows.shape[0]], device=rows.device, dtype=torch.int64)
+    ns = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(ns, n)
+    ns = [int(x.item()) for x in ns]
+    mx = max(ns)
+    pad = torch.zeros((mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    pad[: rows.shape[0]] = rows
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:k] for p, k in zip(parts, ns)], dim=0)
+
+
+def merge_topk(cand_scores: torch.Tensor, cand_idx: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """canonical (score desc, index asc) merge of candidate lists [Q, C] -> [Q, k].  GPU tensors go through the HIP
+    kernel (fp_topk_merge); CPU tensors (gloo tests) through a stable numpy sort with the same ordering."""
+    if cand_scores.is_cuda:
+        from freepose_amd import ops
+        return ops.topk_merge(cand_scores, cand_idx, k)
+    s, i = cand_scores.numpy(), cand_idx.numpy()
+    order = np.lexsort((i, -s), axis=1)[:, :k]
+    return torch.from_numpy(np.take_along_axis(s, order, 1)), torch.from_numpy(np.take_along_axis(i, order, 1))
+
+
+def sharded_bank_topk(local_topk_fn, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bank-row sharding: `local_topk_fn(queries, k)` returns this rank's (scores, GLOBAL indices); one all-gather
+    of Q*k pairs, then the same merge on every rank."""
+    s, i = local_topk_fn(queries, k)
+    return merge_topk(all_gather_cat(s, dim=1), all_gather_cat(i, dim=1), k)

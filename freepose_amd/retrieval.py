@@ -1,0 +1,61 @@
+"""Mesh retrieval against the template bank (reference: scripts/extract_proposals_ground.py:39-44,136-160 and
+scripts/extract_proposals_ground_video.py:149-190).  The bank stays resident in HBM as normalised bf16 rows; a query
+batch is one coalesced scan (fp_bank_topk).  With world_size > 1 the bank rows are sharded across ranks and the per-rank
+top-k lists are all-gathered over RCCL and merged (freepose_amd.parallel)."""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from freepose_amd import ops, parallel
+
+
+class TemplateBank:
+    def __init__(self, bank_f32: np.ndarray | torch.Tensor, mesh_ids: Optional[Sequence[str]] = None, shard: bool = False):
+        """bank_f32 [N,D] fp32 (data/<folder>.npy); row i <-> mesh_ids[i] (data/mesh_cache.txt)."""
+        bank = torch.as_tensor(bank_f32, dtype=torch.float32)
+        self.N, self.D = bank.shape
+        self.mesh_ids = list(mesh_ids) if mesh_ids is not None else None
+        if self.mesh_ids is not None and len(self.mesh_ids) != self.N:
+            raise ValueError(f"bank has {self.N} rows but the file list has {len(self.mesh_ids)} ids (SURVEY App. A-5)")
+        rank, ws = parallel.world()
+        self.lo, self.hi = parallel.shard_range(self.N, rank, ws) if (shard and ws > 1) else (0, self.N)
+        self.sharded = shard and ws > 1
+        self.rows = ops.bank_prepare(bank[self.lo:self.hi])   # cast -> bf16 -> bf16 row normalise (ground.py:40-41)
+
+    @classmethod
+    def from_files(cls, npy_path, filelist_path=None, shard=False):
+        ids = Path(filelist_path).read_text().splitlines() if filelist_path else None
+        return cls(np.load(npy_path), ids, shard)
+
+    def _local_topk(self, queries, k):
+        kk = min(k, self.hi - self.lo)
+        return ops.bank_topk(self.rows, queries, kk, idx_offset=self.lo)
+
+    def topk(self, queries: torch.Tensor, k: int = 100):
+        """queries bf16 [Q,D] (already F.normalize'd FFA descriptors) -> (scores f32 [Q,k], idx i32 [Q,k])"""
+        if self.sharded:
+            return parallel.sharded_bank_topk(self._local_topk, queries, k)
+        return self._local_topk(queries, k)
+
+    def retrieve(self, queries: torch.Tensor):
+        """topk == 0 path of the reference: (mesh id, score) of the best row per query (ground.py:142-145)."""
+        s, i = self.topk(queries, min(100, self.N))
+        s, i = s[:, 0].cpu().numpy(), i[:, 0].cpu().numpy()
+        names = [self.mesh_ids[j] if self.mesh_ids else int(j) for j in i]
+        return names, s.tolist(), i
+
+    def soft_vote(self, per_frame_queries: List[torch.Tensor], k: int = 100):
+        """video soft-vote (ground_video.py:154-159,186-190): dense [N] score vectors with only each frame's top-k
+        filled, mean over frames, per-object arg-max.  per_frame_queries[f] is bf16 [n_obj, D]."""
+        n_obj = per_frame_queries[0].shape[0]
+        acc = torch.zeros((n_obj, self.N), dtype=torch.float32, device="cuda")
+        for q in per_frame_queries:
+            s, i = self.topk(q, min(k, self.N))
+            acc.scatter_add_(1, i.long(), s)
+        acc /= len(per_frame_queries)
+        best = acc.max(dim=1)
+        return best.indices.cpu().numpy(), best.values.cpu().numpy()

@@ -1,0 +1,98 @@
+"""python -m scripts.dino_inference --dataset ycbv --proposals <props>.json
+
+Drop-in for the reference CLI (scripts/dino_inference.py:22-130): proposals JSON in, pose CSV out
+(`scene_id,im_id,obj_id,score,R,t,bbox_visib,scale,time`; t in millimetres :124; same output path :38-40).  Same flags.
+Images are sliced by SLURM_ARRAY_TASK_ID (30 per task, :37,51-54) and — new — additionally round-robin over the ranks of
+a torch.distributed.run launch; each rank writes its own CSV like the reference's per-task files (merge_results.py
+concatenates them)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import torch
+
+from freepose_amd import parallel
+from freepose_amd.src.dataloader.bop import BOPDataset
+from freepose_amd.src.dataloader.template import WebTemplateDataset
+from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
+from freepose_amd.src.pipeline.utils import Proposals, rle_to_mask
+
+CSV_COLUMNS = ["scene_id", "im_id", "obj_id", "score", "R", "t", "bbox_visib", "scale", "time"]
+
+
+def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, scales, layer, batch_size, bbox_extend,
+                  t_scale=1000.0, time_value=0.2):
+    """pose rows for the proposals of ONE image (the per-proposal hot loop, reference :104-127)."""
+    masks = torch.from_numpy(np.stack([rle_to_mask(p["segmentation"]) for p in scene_props]))
+    boxes = torch.from_numpy(np.stack([np.array(p["bbox"]) for p in scene_props]))
+    boxes[:, 2:] += boxes[:, :2]                         # xywh -> xyxy (:102)
+    proposals = Proposals(image, {"boxes": boxes, "masks": masks}, 420, bbox_extend=bbox_extend)
+    rows = []
+    for i, prop in enumerate(proposals.proposals):
+        mesh = scene_props[i]["mesh"]
+        out = model(prop, templates.get_template_by_name(mesh), K, boxes[i], scales[i], layer=layer, batch_size=batch_size)
+        TCO = out["TCO"][0]
+        b = out["bbox"].cpu().numpy()
+        rows.append({"scene_id": int(scene_id), "im_id": int(frame_id), "obj_id": mesh, "score": out["scores"][0],
+                     "R": " ".join(str(x) for x in TCO[:3, :3].flatten().tolist()),
+                     "t": " ".join(str(x * t_scale) for x in TCO[:3, 3].tolist()),
+                     "bbox_visib": " ".join(str(x) for x in [b[0], b[1], b[2] - b[0], b[3] - b[1]]),
+                     "scale": scales[i], "time": time_value})
+    return rows
+
+
+def run(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", type=str)
+    ap.add_argument("--split", type=str, default="test")
+    ap.add_argument("--proposals", type=str)
+    ap.add_argument("--layer", type=int, default=22)
+    ap.add_argument("--depth_method", type=str, default="zoedepth")
+    ap.add_argument("--bbox_extend", type=float, default=0.05)
+    ap.add_argument("--batch_size", type=int, default=128)
+    ap.add_argument("--cache_size", type=int, default=50)
+    ap.add_argument("--save_all_cache", action="store_true")
+    args = ap.parse_args(argv)
+
+    rank, world, _ = parallel.init_from_env()
+    task = int(os.getenv("SLURM_ARRAY_TASK_ID", 0))
+    res_dir = Path("./data/results").resolve() / args.dataset
+    out_dir = res_dir / args.proposals.replace(
+        ".json", f"_dinopose_layer_{args.layer}_bbext_{args.bbox_extend}_depth_{args.depth_method}_cache_{args.cache_size}")
+    out_dir.mkdir(parents=True, exist_ok=True)
+    out_csv = out_dir / (f"pose_outputs_{task}.csv" if world == 1 else f"pose_outputs_{task}_r{rank}.csv")
+
+    dataset = BOPDataset(f"data/datasets/{args.dataset}/", args.split)
+    templates = WebTemplateDataset("data/datasets/objaverse_shards", "data/mesh_cache.csv", bbox_extend=args.bbox_extend)
+    model = DinoPoseEstimator(n_poses=600, cache_size=args.cache_size, save_all=args.save_all_cache,
+                              cache_dir=f"./data/cache_{task}_{args.dataset}_r{rank}")
+    props = json.loads((res_dir / args.proposals).read_text())
+
+    per_task = 30
+    images = list(range(task * per_task, min((task + 1) * per_task, len(dataset))))[rank::world]
+    rows = []
+    for idx in images:
+        entry = dataset[idx]
+        sid, fid = int(entry["scene_id"]), int(entry["frame_id"])
+        sp = [p for p in props if p["scene_id"] == sid and p["image_id"] == fid]
+        if not sp:
+            continue
+        if args.depth_method == "zoedepth":
+            scales = [float(np.clip(p["scale"], a_min=0.01, a_max=None)) for p in sp]
+        elif args.depth_method.startswith("const-"):
+            scales = [float(args.depth_method.split("-")[1])] * len(sp)
+        else:
+            raise NotImplementedError(f"depth_method {args.depth_method}: the depth-map scale estimator is upstream of "
+                                      "this path (SURVEY §2 row 14); supply scales in the proposals JSON")
+        rows += proposal_rows(model, templates, entry["image"], entry["intrinsic"], sid, fid, sp, scales, args.layer,
+                              args.batch_size, args.bbox_extend)
+    pd.DataFrame(rows, columns=CSV_COLUMNS).to_csv(out_csv, index=False, header=True)
+
+
+if __name__ == "__main__":
+    run()

@@ -1,0 +1,143 @@
+"""python -m scripts.dino_inference_video --video <name> --proposals <props>.json
+
+Drop-in for the reference CLI (scripts/dino_inference_video.py:43-182, flags :230-241): per frame and object, online
+render-and-compare with `prev_pose` chaining; pose CSV out (t in metres, scene_id 0, time -1).
+
+Multi-GPU (new): frames of one object are sequentially dependent through prev_pose (reference :122,155-156), so a
+torch.distributed.run launch shards OBJECTS across ranks — exact w.r.t. the reference — and all-gathers the 13-float pose rows.
+`--no_rescore` (coarse pose per frame, frames independent) shards FRAMES instead; the reference's own --no_rescore reads
+a key the coarse estimator never returns, here it simply emits the coarse top-1 pose.
+"""
+from __future__ import annotations
+
+import argparse
+import functools
+import json
+import os
+from itertools import takewhile
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import torch
+from PIL import Image
+
+from freepose_amd import parallel
+from freepose_amd.mesh_io import load_obj
+from freepose_amd.src.dataloader.template import WebTemplateDataset
+from freepose_amd.src.pipeline.estimators.online_pose_estimator import DinoOnlinePoseEstimator
+from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
+from freepose_amd.src.pipeline.utils import Proposals, rle_to_mask
+from freepose_amd.scripts.dino_inference import CSV_COLUMNS
+
+
+def guessed_intrinsics(h: int, w: int) -> np.ndarray:
+    f = np.sqrt(h ** 2 + w ** 2)                     # reference :115-118
+    return np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1]]).astype(float)
+
+
+def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, obj_ids, args, rescoring=True,
+                  frame_ids=None):
+    """pose rows [(frame, obj, score, TCO, bbox)] for the given objects over the given frames (all by default)."""
+    prev = {o: None for o in obj_ids}
+    rows = []
+    for f in (range(len(frames)) if frame_ids is None else frame_ids):
+        sp = props[f]
+        img = np.asarray(Image.open(frames[f]).convert("RGB"), dtype=np.uint8)
+        masks = torch.from_numpy(np.stack([rle_to_mask(p["segmentation"]) for p in sp]))
+        boxes = torch.from_numpy(np.stack([np.array(p["bbox"]) for p in sp]))
+        boxes[:, 2:] += boxes[:, :2]
+        proposals = Proposals(img, {"boxes": boxes, "masks": masks}, 420, bbox_extend=args.bbox_extend)
+        for o in obj_ids:
+            entry = templates.get_template_by_name(mesh_ids[o])
+            with torch.inference_mode():
+                if rescoring:
+                    out = model(proposals.proposals[o], proposals.proposals_masks[o], entry, meshes[o], K, boxes[o], scales[o],
+                                prev_pose=prev[o], neighborhood=15, layer=args.layer, batch_size=args.batch_size)
+                    prev[o] = out["TCO"][0]
+                else:
+                    out = model(proposals.proposals[o], entry, K, boxes[o], scales[o], layer=args.layer, batch_size=args.batch_size)
+            rows.append((f, o, float(out["scores"][0]), out["TCO"][0], boxes[o].numpy()))
+    return rows
+
+
+def main(args):
+    rank, world, _ = parallel.init_from_env()
+    video_dir = (Path("data") / "datasets" / "videos" / args.video).resolve()
+    frames = sorted(p for p in video_dir.iterdir() if p.suffix.lower() in (".jpg", ".jpeg"))
+    results_dir = (Path("data") / "results" / "videos" / args.video).resolve()
+    out_csv = results_dir / args.proposals.replace(
+        ".json", f"_dinopose_layer_{args.layer}_bbext_{args.bbox_extend}_depth_{args.depth_method}.csv")
+
+    templates = WebTemplateDataset("data/datasets/objaverse_shards", "data/mesh_cache.csv", bbox_extend=args.bbox_extend)
+    templates.get_template_by_name = functools.lru_cache(maxsize=args.template_cache_size)(templates.get_template_by_name)
+    cache_dir = Path("data") / f"cache_{os.environ.get('SLURM_JOB_ID', 0)}_{args.video}_r{rank}"
+    if args.no_rescore:
+        model = DinoPoseEstimator(n_poses=600, cache_size=args.cache_size, save_all=args.save_all_cache, cache_dir=cache_dir)
+    else:
+        model = DinoOnlinePoseEstimator(n_coarse_poses=600, n_fine_poses=20000, cache_size=args.cache_size,
+                                        save_all=args.save_all_cache, cache_dir=cache_dir)
+
+    props = json.loads((results_dir / args.proposals).read_text())
+    n_objects = len(list(takewhile(lambda x: x["image_id"] == 0, props)))
+    n_frames = len(frames)
+    assert n_objects * n_frames == len(props)
+    props = [props[i:i + n_objects] for i in range(0, len(props), n_objects)]
+    if args.depth_method.startswith("const-"):
+        scales = [float(args.depth_method.split("-")[1])] * n_objects
+    elif args.depth_method == "zoedepth":
+        scales = [props[0][o]["scale"] for o in range(n_objects)]
+        for o in range(n_objects):
+            assert all(props[f][o]["scale"] == scales[o] for f in range(n_frames)), f"Object {o} has different scales"
+    else:
+        raise NotImplementedError()
+    mesh_ids, meshes = [], []
+    for o in range(n_objects):
+        mid = props[0][o]["mesh"]
+        assert all(props[f][o]["mesh"] == mid for f in range(n_frames)), f"Object {o} has different meshes"
+        meshes.append(load_obj(Path("data").resolve() / "mesh_cache" / mid / f"{mid}.obj"))
+        mesh_ids.append(mid)
+    h, w = np.asarray(Image.open(frames[0])).shape[:2]
+    K = guessed_intrinsics(h, w)
+
+    if args.no_rescore:   # frames independent -> shard frames
+        rows = track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, list(range(n_objects)), args,
+                             rescoring=False, frame_ids=parallel.shard_items(n_frames, rank, world))
+    else:                 # prev_pose chains frames -> shard objects
+        rows = track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K,
+                             parallel.shard_items(n_objects, rank, world), args)
+    packed = torch.tensor([[f, o, s, *T[:3, :3].flatten(), *T[:3, 3], *b] for f, o, s, T, b in rows], dtype=torch.float64)
+    if world > 1:
+        packed = parallel.all_gather_rows(packed.reshape(-1, 19).cuda()).cpu()
+    if rank == 0:
+        packed = packed[np.lexsort((packed[:, 1].numpy(), packed[:, 0].numpy()))] if len(packed) else packed
+        recs = []
+        for r in packed.numpy():
+            f, o = int(r[0]), int(r[1])
+            b = r[15:19]
+            recs.append({"scene_id": 0, "im_id": f, "obj_id": mesh_ids[o], "score": np.float32(r[2]),
+                         "R": " ".join(str(x) for x in r[3:12].tolist()), "t": " ".join(str(x) for x in r[12:15].tolist()),
+                         "bbox_visib": " ".join(str(int(x)) for x in [b[0], b[1], b[2] - b[0], b[3] - b[1]]),
+                         "scale": scales[o], "time": -1})
+        results_dir.mkdir(parents=True, exist_ok=True)
+        pd.DataFrame(recs, columns=CSV_COLUMNS).to_csv(out_csv, index=False, header=True)
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--video", type=str, required=True)
+    ap.add_argument("--proposals", type=str, required=True)
+    ap.add_argument("--layer", type=int, default=22)
+    ap.add_argument("--depth_method", type=str, default="zoedepth")
+    ap.add_argument("--bbox_extend", type=float, default=0.05)
+    ap.add_argument("--batch_size", type=int, default=128)
+    ap.add_argument("--template_cache_size", type=int, default=21)
+    ap.add_argument("--viz", action="store_true", help="accepted for CLI parity; visualisation is out of scope")
+    ap.add_argument("--no_rescore", action="store_true")
+    ap.add_argument("--cache_size", type=int, default=50)
+    ap.add_argument("--save_all_cache", action="store_true")
+    return ap
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

@@ -1,0 +1,76 @@
+"""python -m scripts.extract_retrieval_features --feature ffa --layer 22 --batch_size 256
+
+Drop-in for the reference CLI (scripts/extract_retrieval_features.py:12-75): per mesh, 600 template views -> ViT patch
+features -> per-view FFA (masked mean over the any-pooled 30x30 mask) -> data/datasets/<shards>_<feature>_<layer>/<mesh>.npy
+([<=600, 1024] fp32, NaN views dropped).  Same flags; the job slice comes from SLURM_ARRAY_TASK_ID like the reference,
+or — new — from RANK/WORLD_SIZE when launched with torch.distributed.run (meshes round-robin over the GPUs of a node).
+The 600 per-view device->host copies of the reference (:57) become one copy per mesh.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from freepose_amd import ops, parallel
+from freepose_amd.src.dataloader.template import WebTemplateDataset
+from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+
+
+def mesh_descriptors(model, sample, feature: str, layer: int, batch_size: int) -> np.ndarray:
+    """[<=T, D] fp32 per-view descriptors of one mesh (FFA) or [T, D] cls features."""
+    templates = sample["templates"]
+    ftype = "cls" if feature == "cls" else "patch"
+    feats = torch.cat([model(templates[i:i + batch_size], layer=layer, feature_type=ftype)
+                       for i in range(0, len(templates), batch_size)], dim=0)
+    if feature != "ffa":
+        return feats.float().cpu().numpy()
+    desc = ops.ffa(feats, sample["masks"], cell=14, out_f32=True).cpu().numpy()
+    keep = ~np.isnan(desc).any(axis=1)          # a view with an empty mask yields NaN and is skipped (:59-65)
+    return desc[keep]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shards_folder", type=str, default="objaverse_shards")
+    ap.add_argument("--filelist", type=str, default="mesh_cache.csv")
+    ap.add_argument("--feature", type=str, default="ffa", choices=["ffa", "cls"])
+    ap.add_argument("--layer", type=int, default=22)
+    ap.add_argument("--mesh_per_job", type=int, default=100)
+    ap.add_argument("--batch_size", type=int, default=128)
+    args = ap.parse_args(argv)
+
+    shards_path = Path("data/datasets").resolve() / args.shards_folder
+    features_path = Path("data/datasets").resolve() / f"{args.shards_folder}_{args.feature}_{args.layer}"
+    features_path.mkdir(parents=True, exist_ok=True)
+    filelist_path = Path("data").resolve() / args.filelist
+
+    rank, world, _ = parallel.init_from_env()
+    model = DINOv2FeatureExtractor()
+    dataset = WebTemplateDataset(shards_path.as_posix(), filelist_path.as_posix(), crop=False)
+
+    if "SLURM_ARRAY_TASK_ID" in os.environ:
+        job = int(os.environ["SLURM_ARRAY_TASK_ID"])
+        start, end = job * args.mesh_per_job, min((job + 1) * args.mesh_per_job, len(dataset))
+        todo = list(range(start, end))[rank::world]
+    elif world > 1:
+        todo = parallel.shard_items(len(dataset), rank, world)
+    else:
+        raise KeyError("SLURM_ARRAY_TASK_ID")   # the reference requires it (:32)
+
+    for idx in todo:
+        print(f"[rank {rank}] processing {idx + 1} / {len(dataset)}", flush=True)
+        sample = dataset[idx]
+        if sample["templates"] is None:
+            print(f"skipping {sample['model_name']}", flush=True)
+            continue
+        desc = mesh_descriptors(model, sample, args.feature, args.layer, args.batch_size)
+        np.save((features_path / f"{sample['model_name']}.npy").as_posix(), desc)
+    print("Done", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Drop-in for the reference's `src/pipeline/retrieval/dino.py` (DINOv2FeatureExtractor :7-32).
+
+The reference pulls `facebookresearch/dinov2` through torch.hub (dino.py:10) and runs it with cuBLAS/xformers; here the
+same forward (normalise -> tokens -> first `layer` blocks -> final norm -> cls/reg/patch slice) is one call into
+libfreepose_hip.so (fp_vit_forward): hand-written gfx950 MFMA GEMMs with fused epilogues, LDS-tiled attention, fused
+LayerNorm.  Weights use the official hub state-dict layout, so `dinov2_vitl14_reg4_pretrain.pth` loads unchanged.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from pathlib import Path
+
+import torch
+
+from freepose_amd import ops
+
+_CKPT_NAMES = {
+    "dinov2_vits14": "dinov2_vits14_pretrain.pth", "dinov2_vits14_reg": "dinov2_vits14_reg4_pretrain.pth",
+    "dinov2_vitb14": "dinov2_vitb14_pretrain.pth", "dinov2_vitb14_reg": "dinov2_vitb14_reg4_pretrain.pth",
+    "dinov2_vitl14": "dinov2_vitl14_pretrain.pth", "dinov2_vitl14_reg": "dinov2_vitl14_reg4_pretrain.pth",
+}
+
+
+def _find_checkpoint(model_name: str):
+    """FREEPOSE_DINOV2_WEIGHTS (file or directory), then the torch.hub checkpoint cache."""
+    cand = []
+    env = os.environ.get("FREEPOSE_DINOV2_WEIGHTS")
+    if env:
+        p = Path(env)
+        cand.append(p / _CKPT_NAMES[model_name] if p.is_dir() else p)
+    cand.append(Path(torch.hub.get_dir()) / "checkpoints" / _CKPT_NAMES[model_name])
+    for c in cand:
+        if c.is_file():
+            return c
+    return None
+
+
+class DINOv2FeatureExtractor:
+    """Same surface as the reference nn.Module: construct, `.to(...)`, `.eval()`, call with
+    (images, layer=22, feature_type='cls'|'reg'|'patch')."""
+
+    def __init__(self, model_name: str = "dinov2_vitl14_reg", state_dict: dict | None = None, seed: int = 0):
+        self.model_name = model_name
+        if state_dict is None:
+            ckpt = _find_checkpoint(model_name)
+            if ckpt is not None:
+                state_dict = torch.load(ckpt, map_location="cpu")
+            else:
+                warnings.warn(
+                    f"no {_CKPT_NAMES[model_name]} found (set FREEPOSE_DINOV2_WEIGHTS); using seeded random-init weights "
+                    "with the DINOv2 shapes — features are NOT meaningful for real images", RuntimeWarning)
+        self.model = ops.ViT(model_name, state_dict, seed=seed)
+        self.num_register_tokens = self.model.n_reg
+
+    # nn.Module surface used by the reference call sites (pose_estimator.py:21, scripts/*.py)
+    def to(self, *args, **kwargs):
+        return self
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    def forward(self, images, layer=22, feature_type="cls"):
+        with torch.inference_mode():
+            return self.model.forward(images, layer=layer, feature_type=feature_type)
+
+    __call__ = forward

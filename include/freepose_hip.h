@@ -91,8 +91,8 @@ int fp_template_score(fp_ctx* ctx, const void* d_tmpl, const void* d_query, cons
 
 /* ---- a5: CropResizePad (src/utils/bbox_utils.py:20-56) as used by Proposals (src/pipeline/utils.py:32-52)
  * and MeshRenderer.generate_proposals (renderer.py:109-130) -------------------------------------------- */
-/* d_images: src_fmt 0 = f32 [n_img,C,H,W] in [0,1]; 1 = u8 [n_img,H,W,C] (divided by 255 like
- * renderer.py:121).  n_img is 1 (all boxes crop the same image, Proposals) or n (one image per box, renders).
+/* d_images: src_fmt 0 = f32 [n_img,C,H,W] in [0,1]; 1 = u8 [n_img,H,W,C] -> float(double(x)/255) like
+ * renderer.py:121; 2 = u8 [n_img,H,W,C] -> float(x)/255.f like Proposals (utils.py:20).  n_img is 1 (all boxes crop the same image, Proposals) or n (one image per box, renders).
  * d_boxes i32 [n,4] xyxy BEFORE extension.  d_masks u8 [n,H,W] or NULL; mask_mode 0 = ignore,
  * 1 = multiply pixels by the mask (mask_rgb=True, utils.py:39-40), 2 = output the mask itself as 0/1
  * (utils.py:35-37,48-51).  d_out: out_fmt 0 = f32, 1 = bf16, shape [n,C,target,target].
@@ -121,9 +121,10 @@ int fp_mesh_destroy(fp_mesh* mesh);
 int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx, float fy,
                  float cx, float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, void* stream);
 /* a9/K17: per view, bbox of depth>0 (with the <100 px fallback square) and metric extents of the
- * back-projected cloud: out f32 [Hn,8] = {xmin,ymin,xmax,ymax (px), dx, dy (m), count, 0}. */
+ * back-projected cloud (float64 like utils.py:122-145): out f64 [Hn,8] = {xmin,ymin,xmax,ymax (px), dx, dy (m),
+ * count, 0}. */
 int fp_depth_extents(fp_ctx* ctx, const float* d_depth, int Hn, int Hh, int W, float fx, float fy, float cx,
-                     float cy, float* d_out, void* stream);
+                     float cy, double* d_out, void* stream);
 
 /* ---- kernel-level entry points (unit parity tests, microbenchmarks; the ViT forward is built from these) */
 /* C[M,N] = epi(X[M,K] W[N,K]^T + bias): epi 0 = bias, 1 = bias+GELU(erf), 2 = resid + gamma*(.) ; bf16, ld* in

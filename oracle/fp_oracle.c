@@ -181,6 +181,18 @@ void fpo_template_score(const bf16* tmpl, const bf16* q, const float* weights, i
     free(tn); free(qf); free(dots);
 }
 
+/* torch's CPU nearest-neighbour source index for F.interpolate(scale_factor=s) on the NCHW (C=3) tensors of
+ * bbox_utils.py:35,52.  ATen picks one of two kernels per call: when out_h + out_w <= 128 the one built on
+ * nearest_idx (identity when out == in, idx >> 1 when out == 2*in, else the scale rule); otherwise the generic
+ * kernel, which always applies the scale rule  min(floorf(dst * float(1/s)), in-1).  `small` = out_h + out_w <= 128.
+ * (probed on torch 2.10 CPU; the 420-px pipeline always takes the generic kernel) */
+static int nearest_src(int dst, int in, int out, float inv_scale, int small) {
+    if (small && out == in) return dst;
+    if (small && out == 2 * in) return dst >> 1;
+    int s = (int)floorf((float)dst * inv_scale);
+    return s > in - 1 ? in - 1 : s;
+}
+
 /* CropResizePad.__call__ (src/utils/bbox_utils.py:20-56).  images f32 [n_img,C,H,W] (src_u8=0) or
  * u8 [n_img,H,W,C] (src_u8=1, value/255 as in renderer.py:121); out f32 [n,C,target,target].
  * mask_mode as in include/freepose_hip.h.  Returns 0, or 1+i if box i does not resize to `target`. */
@@ -218,14 +230,15 @@ int fpo_crop_resize_pad(const void* images, int src_u8, int n_img, int C, int H,
         const int img = n_img == 1 ? 0 : i;
         for (int oy = 0; oy < target; ++oy)
             for (int ox = 0; ox < target; ++ox) {
-                int y2 = (int)floorf((float)oy * inv2); if (y2 > S_h - 1) y2 = S_h - 1;
-                int x2 = (int)floorf((float)ox * inv2); if (x2 > S_w - 1) x2 = S_w - 1;
+                const int small1 = (h1 + w1) <= 128, small2 = (outsz + outsz) <= 128;
+                const int y2 = nearest_src(oy, S_h, outsz, inv2, small2);
+                const int x2 = nearest_src(ox, S_w, outsz, inv2, small2);
                 const int yy = y2 - pad_t, xx = x2 - pad_l;
                 const int valid = !(yy < 0 || yy >= h1 || xx < 0 || xx >= w1);
                 int ys = 0, xs = 0;
                 if (valid) {
-                    ys = (int)floorf((float)yy * inv1); if (ys > ch - 1) ys = ch - 1; ys += y0;
-                    xs = (int)floorf((float)xx * inv1); if (xs > cw - 1) xs = cw - 1; xs += x0;
+                    ys = y0 + nearest_src(yy, ch, h1, inv1, small1);
+                    xs = x0 + nearest_src(xx, cw, w1, inv1, small1);
                 }
                 float m = 1.f;
                 if (valid && masks && mask_mode) m = masks[((size_t)i * H + ys) * W + xs] ? 1.f : 0.f;
@@ -234,7 +247,8 @@ int fpo_crop_resize_pad(const void* images, int src_u8, int n_img, int C, int H,
                     if (valid) {
                         if (mask_mode == 2) v = m;
                         else {
-                            if (src_u8) v = (float)((double)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c] / 255.0);
+                            if (src_u8 == 1) v = (float)((double)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c] / 255.0);
+                            else if (src_u8 == 2) v = (float)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c] / 255.0f; /* utils.py:20 */
                             else v = ((const float*)images)[(((size_t)img * C + c) * H + ys) * W + xs];
                             v *= m;
                         }
@@ -281,7 +295,7 @@ int fpo_geodesic_select(const double* grid, int G, const double* Rp, double thre
 
 /* depth>0 mask bbox with the <100 px fallback (renderer.py:112-119; template.py:73-78) and the x/y extents of
  * depthmap_to_pointcloud (src/pipeline/utils.py:122-145,157-158).  out [Hn,8] as in freepose_hip.h */
-void fpo_depth_extents(const float* depth, int Hn, int Hh, int W, double fx, double fy, double cx, double cy, float* out) {
+void fpo_depth_extents(const float* depth, int Hn, int Hh, int W, double fx, double fy, double cx, double cy, double* out) {
     for (int v = 0; v < Hn; ++v) {
         const float* d = depth + (size_t)v * Hh * W;
         int cnt = 0, xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1, any = 0;
@@ -301,10 +315,10 @@ void fpo_depth_extents(const float* depth, int Hn, int Hh, int W, double fx, dou
             if (cnt == 0) { xmin = lo; ymin = lo; xmax = hx; ymax = hy; }
             else { if (lo < xmin) xmin = lo; if (lo < ymin) ymin = lo; if (hx > xmax) xmax = hx; if (hy > ymax) ymax = hy; }
         }
-        float* o = out + (size_t)v * 8;
-        o[0] = (float)xmin; o[1] = (float)ymin; o[2] = (float)xmax; o[3] = (float)ymax;
-        o[4] = any ? (float)(Xmax - Xmin) : 0.f; o[5] = any ? (float)(Ymax - Ymin) : 0.f;
-        o[6] = (float)cnt; o[7] = 0.f;
+        double* o = out + (size_t)v * 8;
+        o[0] = xmin; o[1] = ymin; o[2] = xmax; o[3] = ymax;
+        o[4] = any ? Xmax - Xmin : 0.0; o[5] = any ? Ymax - Ymin : 0.0;
+        o[6] = cnt; o[7] = 0.0;
     }
 }
 

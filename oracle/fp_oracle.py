@@ -125,11 +125,12 @@ def template_score(tmpl_bits: np.ndarray, q_bits: np.ndarray, weights: np.ndarra
     return s
 
 
-def crop_resize_pad(images: np.ndarray, boxes: np.ndarray, target: int, ext: float = 0.0, masks=None, mask_mode: int = 0):
+def crop_resize_pad(images: np.ndarray, boxes: np.ndarray, target: int, ext: float = 0.0, masks=None, mask_mode: int = 0,
+                    u8_float_div: bool = False):
     if images.dtype == np.uint8:
         img = np.ascontiguousarray(images)
         n_img, H, W, Cc = img.shape
-        src = 1
+        src = 2 if u8_float_div else 1
     else:
         img = np.ascontiguousarray(images, dtype=np.float32)
         n_img, Cc, H, W = img.shape
@@ -164,7 +165,9 @@ def geodesic_select(grid: np.ndarray, R_prev: np.ndarray, thresh_deg: float) -> 
 def depth_extents(depth: np.ndarray, fx, fy, cx, cy) -> np.ndarray:
     d = np.ascontiguousarray(depth, dtype=np.float32)
     Hn, H, W = d.shape
-    out = np.empty((Hn, 8), dtype=np.float32)
+    out = np.empty((Hn, 8), dtype=np.float64)
+    # the C ABI carries the intrinsics as float32 (include/freepose_hip.h); widen exactly those values
+    fx, fy, cx, cy = (float(np.float32(v)) for v in (fx, fy, cx, cy))
     lib().fpo_depth_extents(_p(d), C.c_int(Hn), C.c_int(H), C.c_int(W), C.c_double(fx), C.c_double(fy), C.c_double(cx),
                             C.c_double(cy), _p(out))
     return out

@@ -1,0 +1,80 @@
+"""world_size-2 gloo tests of the N>1 path (freepose_amd/parallel.py): bank-row sharding + all-gather + canonical merge
+gives the unsharded top-k on every rank; proposal/object sharding + row all-gather reassembles every result.  The
+per-shard scan is played by the oracle here (no GPU); on the MI355X the same code runs fp_bank_topk / fp_topk_merge over
+RCCL."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from freepose_amd import parallel
+    from oracle import fp_oracle as fo
+    r, w, _ = parallel.init_from_env("gloo")
+    assert (r, w) == (rank, world) and parallel.world() == (rank, world)
+
+    # ---- bank-row sharding -------------------------------------------------------------
+    N, D, Q, k = 1501, 384, 5, 100
+    rng = np.random.Generator(np.random.PCG64(11))
+    base = rng.standard_normal((40, D)).astype(np.float32)
+    bank = base[rng.integers(0, 40, N)] + 0.01 * rng.standard_normal((N, D)).astype(np.float32)  # tie-heavy
+    bank_bits = fo.bank_prepare(bank)
+    q_bits = fo.l2norm_rows(fo.to_bf16_bits(rng.standard_normal((Q, D)).astype(np.float32)))
+    lo, hi = parallel.shard_range(N, rank, world)
+    assert (lo, hi) == ((0, 751), (751, 1501))[rank]
+
+    def local(queries, kk):
+        s, i = fo.bank_topk(bank_bits[lo:hi], q_bits, min(kk, hi - lo), idx_offset=lo)
+        return torch.from_numpy(s), torch.from_numpy(i)
+    s, i = parallel.sharded_bank_topk(local, None, k)
+    s_ref, i_ref = fo.bank_topk(bank_bits, q_bits, k)
+    assert np.array_equal(i.numpy(), i_ref) and np.array_equal(s.numpy(), s_ref)
+
+    # ---- proposal / object sharding: round-robin items, variable rows per rank ---------------------------
+    items = parallel.shard_items(7, rank, world)
+    assert items == ([0, 2, 4, 6], [1, 3, 5])[rank]
+    rows = torch.tensor([[float(it), it * 10.0, rank] for it in items], dtype=torch.float64)
+    allr = parallel.all_gather_rows(rows)
+    assert allr.shape == (7, 3) and sorted(allr[:, 0].tolist()) == list(range(7))
+    assert torch.equal(parallel.all_gather_cat(torch.full((2, 3), float(rank)), dim=1)[:, ::3], torch.tensor([[0., 1.], [0., 1.]]))
+    dist.barrier()
+    Path(tmp, f"ok{rank}").write_text("ok")
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_single_process_paths():
+    from freepose_amd import parallel
+    assert parallel.world() == (0, 1)
+    assert parallel.shard_range(10, 0, 1) == (0, 10)
+    assert [parallel.shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    t = torch.arange(6.0).reshape(2, 3)
+    assert parallel.all_gather_cat(t) is t and parallel.all_gather_rows(t) is t
+    s = torch.tensor([[0.5, 0.75, 0.75, 0.25]])
+    i = torch.tensor([[7, 9, 3, 1]], dtype=torch.int32)
+    ms, mi = parallel.merge_topk(s, i, 3)
+    assert mi.tolist() == [[3, 9, 7]] and ms.tolist() == [[0.75, 0.75, 0.5]]

@@ -1,0 +1,227 @@
+"""bench.py — proposals/sec of the per-proposal 6D-pose hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One STEP = one pass of the hot path over `--proposals-per-step` synthetic proposals per GPU, every stage executed:
+518x518 crop -> ViT-L/14-reg layer-22 patch features -> FFA -> cosine top-100 over a 46 037 x 1024 bank -> 576 pose
+hypotheses of an 82k-triangle mesh rasterised (420^2), cropped, pushed through the ViT, patchwise-scored against the
+query -> top-3 -> metric (R,t).  Inputs are resident in HBM before the timed region.  Proposals are sharded across
+ranks (weak scaling, no data-path collective); the only collective is the all-gather of 16-float result rows.
+
+Prints ONE JSON line on rank 0 (metric/value/unit/... + "roofline" for the dominant kernel + "cpu_baseline").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def icosphere(sub: int):
+    t = (1 + 5 ** 0.5) / 2
+    v = [np.array(p, np.float64) for p in ([-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t],
+                                           [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1])]
+    v = [p / np.linalg.norm(p) for p in v]
+    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+         [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]]
+    for _ in range(sub):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = (v[a] + v[b]) / 2
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        f = nf
+    return np.array(v), np.array(f, dtype=np.int32)
+
+
+def synthetic_mesh(sub: int, seed: int = 40):
+    v, f = icosphere(sub)
+    v = v * (1 + 0.25 * np.sin(3 * v[:, :1]) * np.cos(2 * v[:, 1:2]) + 0.1 * np.sin(7 * v[:, 2:3]))
+    v /= np.abs(v).max()                      # unit half-extent (resize_meshes.py), rendered at scale 0.25
+    col = np.random.Generator(np.random.PCG64(seed)).integers(0, 256, size=(len(v), 3), dtype=np.uint8)
+    return v.astype(np.float32), f, col
+
+
+def synthetic_bank(N, D, seed=21):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mu = rng.standard_normal(D).astype(np.float32)
+    x = rng.standard_normal((N, D), dtype=np.float32) + 2.0 * mu      # anisotropic like a real bank
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def synthetic_proposals(B, res, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    crops = torch.from_numpy(rng.random((B, 3, res, res), dtype=np.float32)).to(torch.bfloat16)
+    yy, xx = np.mgrid[0:res, 0:res]
+    masks = np.stack([(((yy - res * rng.uniform(.4, .6)) / (res * rng.uniform(.2, .45))) ** 2 +
+                       ((xx - res * rng.uniform(.4, .6)) / (res * rng.uniform(.2, .45))) ** 2) <= 1 for _ in range(B)])
+    boxes = np.array([[100 + 7 * b, 80 + 5 * b, 300 + 9 * b, 260 + 3 * b] for b in range(B)])
+    scales = rng.uniform(0.03, 0.15, size=B)
+    K = np.array([[1066.778, 0, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1]], dtype=np.float32)
+    return crops, torch.from_numpy(masks), K, boxes, scales
+
+
+def cpu_baseline(args, mesh_arrays, bank_f32):
+    """the oracle (CPU restatement) timed on this box's host cores on a bounded sample of the same workload"""
+    from oracle import fp_oracle as fo, vit_ref
+    from freepose_amd.ops import random_state_dict
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    sd = {k: v.float() for k, v in random_state_dict("dinov2_vitl14_reg", 0).items()}
+    x = torch.rand(1, 3, args.res, args.res)
+    vit_ref.vit_forward(sd, x[:, :, :224, :224], layer=2)            # warm the thread pool
+    t0 = time.perf_counter()
+    n_vit = 3
+    for _ in range(n_vit):
+        feats = vit_ref.vit_forward(sd, x, layer=22, feature_type="patch")
+    t_vit = (time.perf_counter() - t0) / n_vit
+    bank_bits = fo.bank_prepare(bank_f32[:8192])
+    q = fo.l2norm_rows(fo.to_bf16_bits(np.random.default_rng(0).standard_normal((1, bank_f32.shape[1])).astype(np.float32)))
+    t0 = time.perf_counter()
+    fo.bank_topk(bank_bits, q, 100)
+    t_scan = (time.perf_counter() - t0) * (bank_f32.shape[0] / 8192)
+    P = (args.res // 14) ** 2
+    tm = fo.to_bf16_bits(np.random.default_rng(1).standard_normal((2, P, 1024)).astype(np.float32))
+    qn = fo.l2norm_rows(fo.to_bf16_bits(feats[0].numpy()))
+    t0 = time.perf_counter()
+    fo.template_score(tm, qn)
+    t_score = (time.perf_counter() - t0) / 2 * args.hyp
+    v, f, c = mesh_arrays
+    from freepose_amd.src.pipeline.retrieval.renderer import grid_poses
+    poses = np.array(grid_poses(args.hyp))[:2].astype(np.float32)
+    t0 = time.perf_counter()
+    fo.rasterize(v, f, c, poses, 0.25, 600, 600, 210, 210, 420, 420)
+    t_raster = (time.perf_counter() - t0) / 2 * args.hyp
+    per_prop = (1 + args.hyp) * t_vit + t_scan + t_score + t_raster
+    return {"value": 1.0 / per_prop, "unit": "proposals/s", "cores": ncores, "kind": "port",
+            "sample": f"{n_vit} ViT-L/14 layer-22 fp32 forwards @{args.res}^2 (torch, {ncores} threads, {t_vit:.2f} s/crop), "
+                      f"8192-row bank scan + top-100, 2 template scorings, 2 renders of the {len(f)}-triangle mesh "
+                      f"(scalar C oracle); extrapolated to 1+{args.hyp} forwards, {bank_f32.shape[0]} rows, {args.hyp} hypotheses",
+            "seconds_per_proposal": per_prop,
+            "stage_seconds": {"vit_per_crop": t_vit, "bank_scan": t_scan, "template_score": t_score, "raster": t_raster}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--proposals-per-step", type=int, default=1, help="proposals per GPU per step")
+    ap.add_argument("--hyp", type=int, default=576)
+    ap.add_argument("--res", type=int, default=518)
+    ap.add_argument("--bank", type=int, default=46037)
+    ap.add_argument("--mesh-sub", type=int, default=6, help="icosphere subdivisions (6 -> 81 920 triangles)")
+    ap.add_argument("--vit-batch", type=int, default=192)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from freepose_amd import ops, parallel
+    from freepose_amd.pipeline import HotPath, pack_results
+    from freepose_amd.retrieval import TemplateBank
+    import torch.distributed as dist
+
+    rank, world, local = parallel.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+
+    vit = ops.ViT("dinov2_vitl14_reg", seed=0)                         # random-init weights of the real architecture
+    bank_f32 = synthetic_bank(args.bank, 1024)
+    bank = TemplateBank(bank_f32, shard=False)                         # bank replicated, proposals sharded
+    mv, mf, mc = synthetic_mesh(args.mesh_sub)
+    hp = HotPath(vit, bank, ops.Mesh(mv, mf, mc), n_hyp=args.hyp, crop_res=args.res, vit_batch=args.vit_batch)
+    B = args.proposals_per_step
+    crops, masks, K, boxes, scales = synthetic_proposals(B, args.res, seed=100 + rank)
+    crops, masks = crops.cuda(), masks.cuda()
+
+    def step():
+        res = hp.run(crops, masks, K, boxes, scales)
+        rows = pack_results(res).cuda()
+        return parallel.all_gather_rows(rows) if world > 1 else rows
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    vit.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = vit.profile_read()
+    vit.profile(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    if rank == 0:
+        n_prop = world * B * args.steps
+        flops_vit = vit.flops(1, args.res, args.res, 22) * (1 + args.hyp) * B * args.steps
+        gemm_tf = prof["gemm_flops"] / max(prof["ms_gemm"], 1e-9) / 1e9
+        out = {
+            "metric": "proposals/sec (ViT-L feat + top-k + 576-pose render-compare)",
+            "value": n_prop / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"per-proposal hot path: ViT-L/14-reg layer-22 @{args.res}^2 -> FFA -> top-100 over "
+                                   f"{args.bank}x1024 bank -> {args.hyp} hypotheses rasterised ({len(mf)} triangles, 420^2), cropped to "
+                                   f"{args.res}^2, ViT + patchwise score -> top-3 pose; all stages per proposal (no feature cache)",
+                       "proposals_per_step_per_gpu": B, "vit_forwards_per_proposal": 1 + args.hyp, "weights": "seeded random init, DINOv2 ViT-L/14-reg shapes",
+                       "parallelism": f"proposals sharded over {world} rank(s), bank replicated"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all ViT linear layers)", "achieved": gemm_tf,
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TFLOPS,
+                         "traffic": _pmc_traffic(), "launches": prof["gemm_launches"],
+                         "avg_launch_ms": prof["ms_gemm"] / max(prof["gemm_launches"], 1),
+                         "flops_per_launch": prof["gemm_flops"] / max(prof["gemm_launches"], 1)},
+            "stage_ms_rank0": {"vit_gemm": prof["ms_gemm"] / args.steps, "vit_attention": prof["ms_attn"] / args.steps,
+                               "vit_other": prof["ms_other"] / args.steps},
+            "vit_tflops_end_to_end": flops_vit / dt / 1e12,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, (mv, mf, mc), bank_f32)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary (profiles/), if present"""
+    p = ROOT / "profiles" / "r01_gemm_pmc.json"
+    if p.exists():
+        try:
+            return json.loads(p.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,7 @@ SIGNATURES = {
     "fp_timer_destroy": (c_int, [c_void_p]),
     "fp_vit_profile": (c_int, [c_void_p, c_int]),
     "fp_vit_profile_read": (c_int, [c_void_p, P(c_float), P(c_float), P(c_float), P(c_double)]),
+    "fp_vit_profile_gemm_launches": (C.c_long, [c_void_p]),
 }
 
 

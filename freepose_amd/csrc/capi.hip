@@ -88,9 +88,12 @@ struct fp_vit {
     std::map<std::pair<int, int>, bf16_t*> pos_cache;
     // profiling
     bool prof = false;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    struct EvPair { hipEvent_t a, b; int cls; };
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
     float ms_gemm = 0, ms_attn = 0, ms_other = 0;
-    double gemm_flops = 0;
+    double gemm_flops = 0;   // algorithmic (unpadded) FLOPs of the GEMM launches issued while profiling
+    long gemm_launches = 0;
 };
 
 extern "C" int fp_vit_create(fp_ctx* ctx, const fp_vit_arch* arch, fp_vit** out) {
@@ -120,8 +123,7 @@ extern "C" int fp_vit_destroy(fp_vit* v) {
     if (v->pe_w) (void)hipFree(v->pe_w);
     if (v->ones) (void)hipFree(v->ones);
     for (auto& kv : v->pos_cache) (void)hipFree(kv.second);
-    for (int i = 0; i < 2; ++i)
-        if (v->ev[i]) (void)hipEventDestroy(v->ev[i]);
+    for (auto& p : v->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete v;
     return FP_OK;
 }
@@ -202,19 +204,24 @@ extern "C" double fp_vit_flops(const fp_vit* v, int B, int H, int W, int layer) 
 }
 
 namespace {
+// Per-kernel-class timing with HIP events on the launch stream.  Events are only RECORDED here (no host sync, so the
+// timed region is not perturbed); fp_vit_profile_read() synchronises once and sums the elapsed times.
 struct ProfScope {
-    fp_vit* v; hipStream_t s; float* acc;
-    ProfScope(fp_vit* v_, hipStream_t s_, float* acc_) : v(v_), s(s_), acc(acc_) {
-        if (v->prof) (void)hipEventRecord(v->ev[0], s);
+    fp_vit* v; hipStream_t s; int cls; size_t slot;
+    ProfScope(fp_vit* v_, hipStream_t s_, float* acc_) : v(v_), s(s_), slot((size_t)-1) {
+        cls = acc_ == &v->ms_gemm ? 0 : (acc_ == &v->ms_attn ? 1 : 2);
+        if (!v->prof) return;
+        if (v->ev_used == v->ev_pool.size()) {
+            fp_vit::EvPair p{};
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            v->ev_pool.push_back(p);
+        }
+        slot = v->ev_used++;
+        v->ev_pool[slot].cls = cls;
+        (void)hipEventRecord(v->ev_pool[slot].a, s);
     }
     ~ProfScope() {
-        if (v->prof) {
-            (void)hipEventRecord(v->ev[1], s);
-            (void)hipEventSynchronize(v->ev[1]);
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, v->ev[0], v->ev[1]);
-            *acc += ms;
-        }
+        if (slot != (size_t)-1) (void)hipEventRecord(v->ev_pool[slot].b, s);
     }
 };
 }  // namespace
@@ -265,9 +272,10 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         g.X = A0; g.ldx = v->KP; g.W = v->pe_w; g.ldw = v->KP; g.C = X; g.ldc = D; g.bias = v->pe_b;
         g.M = B * P; g.N = D; g.K = v->KP; g.pos = pos_patch; g.P = P; g.npad = npad; g.tok_off = 1 + a.n_reg;
         if ((rc = fp_gemm_bf16(g, FP_EPI_PATCH, s))) return rc;
-        v->gemm_flops += 2.0 * g.M * (3.0 * a.patch * a.patch) * D;
+        if (v->prof) { v->gemm_flops += 2.0 * g.M * (3.0 * a.patch * a.patch) * D; v->gemm_launches += 1; }
     }
     const int Mi = (int)M;
+    const double Malg = (double)B * n_tok;  // algorithmic rows (pad rows are overhead, not counted as work)
     for (int i = 0; i < L; ++i) {
         const VitBlockW& w = v->blk[i];
         {
@@ -284,7 +292,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
             gv.X = Y; gv.ldx = D; gv.W = w.qkvw + (size_t)2 * D * D; gv.ldw = D; gv.C = Vt; gv.ldc = 8;
             gv.bias = w.qkvb + 2 * D; gv.M = Mi; gv.N = D; gv.K = D; gv.npad = npad; gv.heads = a.heads;
             if ((rc = fp_gemm_bf16(gv, FP_EPI_VT, s))) return rc;
-            v->gemm_flops += 2.0 * Mi * 3.0 * D * D;
+            if (v->prof) { v->gemm_flops += 2.0 * Malg * 3.0 * D * D; v->gemm_launches += 2; }
         }
         {
             ProfScope ps(v, s, &v->ms_attn);
@@ -296,7 +304,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
             g.X = AO; g.ldx = D; g.W = w.projw; g.ldw = D; g.C = X; g.ldc = D; g.bias = w.projb;
             g.gamma = w.ls1 ? w.ls1 : v->ones; g.resid = X; g.ldr = D; g.M = Mi; g.N = D; g.K = D;
             if ((rc = fp_gemm_bf16(g, FP_EPI_BIAS_LS_RES, s))) return rc;
-            v->gemm_flops += 2.0 * Mi * (double)D * D;
+            if (v->prof) { v->gemm_flops += 2.0 * Malg * (double)D * D; v->gemm_launches += 1; }
         }
         {
             ProfScope ps(v, s, &v->ms_other);
@@ -312,7 +320,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
             g2.X = H1; g2.ldx = a.mlp_dim; g2.W = w.fc2w; g2.ldw = a.mlp_dim; g2.C = X; g2.ldc = D; g2.bias = w.fc2b;
             g2.gamma = w.ls2 ? w.ls2 : v->ones; g2.resid = X; g2.ldr = D; g2.M = Mi; g2.N = D; g2.K = a.mlp_dim;
             if ((rc = fp_gemm_bf16(g2, FP_EPI_BIAS_LS_RES, s))) return rc;
-            v->gemm_flops += 4.0 * Mi * (double)D * a.mlp_dim;
+            if (v->prof) { v->gemm_flops += 4.0 * Malg * (double)D * a.mlp_dim; v->gemm_launches += 2; }
         }
     }
     // ---- K8: final norm + token slice (dino.py:23-30) ------------------------------------------------
@@ -332,23 +340,30 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
 
 extern "C" int fp_vit_profile(fp_vit* v, int enable) {
     FP_REQUIRE(v, "vit_profile: null");
-    if (enable && !v->ev[0]) {
-        FP_HIP(hipEventCreate(&v->ev[0]));
-        FP_HIP(hipEventCreate(&v->ev[1]));
-    }
     v->prof = enable != 0;
+    v->ev_used = 0;
     v->ms_gemm = v->ms_attn = v->ms_other = 0;
     v->gemm_flops = 0;
+    v->gemm_launches = 0;
     return FP_OK;
 }
 extern "C" int fp_vit_profile_read(fp_vit* v, float* g, float* at, float* o, double* fl) {
     FP_REQUIRE(v, "vit_profile_read: null");
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (size_t i = 0; i < v->ev_used; ++i) {
+        FP_HIP(hipEventSynchronize(v->ev_pool[i].b));
+        float ms = 0.f;
+        FP_HIP(hipEventElapsedTime(&ms, v->ev_pool[i].a, v->ev_pool[i].b));
+        acc[v->ev_pool[i].cls] += ms;
+    }
+    v->ms_gemm = acc[0]; v->ms_attn = acc[1]; v->ms_other = acc[2];
     if (g) *g = v->ms_gemm;
     if (at) *at = v->ms_attn;
     if (o) *o = v->ms_other;
     if (fl) *fl = v->gemm_flops;
     return FP_OK;
 }
+extern "C" long fp_vit_profile_gemm_launches(const fp_vit* v) { return v ? v->gemm_launches : 0; }
 
 // ---------------------------------------------------------------------------------------------
 // FFA / retrieval / template score

@@ -99,7 +99,8 @@ class ViT:
     def profile_read(self):
         g, a, o, f = C.c_float(), C.c_float(), C.c_float(), C.c_double()
         check(self.lib.fp_vit_profile_read(self.handle, C.byref(g), C.byref(a), C.byref(o), C.byref(f)))
-        return {"ms_gemm": g.value, "ms_attn": a.value, "ms_other": o.value, "gemm_flops": f.value}
+        return {"ms_gemm": g.value, "ms_attn": a.value, "ms_other": o.value, "gemm_flops": f.value,
+                "gemm_launches": int(self.lib.fp_vit_profile_gemm_launches(self.handle))}
 
     def __del__(self):
         try:

@@ -1,0 +1,87 @@
+"""The per-proposal hot path as one batched, device-resident pipeline (what bench.py times and smoke() checks):
+
+    crop [3,R,R] + mask  ->  ViT-L/14 layer-22 patch features  ->  FFA descriptor  ->  cosine top-k over the bank
+                         ->  H pose hypotheses: rasterise -> mask bbox -> crop/resize -> ViT -> patchwise score vs the query
+                         ->  top-3 hypotheses -> metric (R, t) from the render's depth extents
+
+It is the composition the reference performs per proposal across scripts/extract_proposals_ground.py:126-145 (retrieval)
+and src/pipeline/estimators/{pose_estimator.py:79-118, online_pose_estimator.py:49-96} (render-and-compare), with the
+template features computed from fresh renders (the reference's cache-miss / online path) so no stage is skipped.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from freepose_amd import ops, parallel
+from freepose_amd.retrieval import TemplateBank
+from freepose_amd.src.pipeline.retrieval.renderer import MeshRenderer, grid_poses
+from freepose_amd.src.pipeline.utils import z_from_extents
+
+
+@dataclass
+class ProposalResult:
+    topk_scores: np.ndarray      # [k] retrieval scores
+    topk_idx: np.ndarray         # [k] bank rows
+    hyp_idx: np.ndarray          # [3] best hypotheses
+    hyp_scores: np.ndarray       # [3]
+    TCO: List[np.ndarray]        # 3 x [4,4]
+
+
+class HotPath:
+    def __init__(self, vit: ops.ViT, bank: TemplateBank, mesh: ops.Mesh, n_hyp: int = 576, crop_res: int = 518,
+                 render_res: int = 420, k: int = 100, layer: int = 22, vit_batch: int = 192, render_scale: float = 0.25):
+        self.vit, self.bank, self.mesh = vit, bank, mesh
+        self.n_hyp, self.crop_res, self.render_res, self.k, self.layer = n_hyp, crop_res, render_res, k, layer
+        self.vit_batch, self.render_scale = vit_batch, render_scale
+        self.hyp_poses = np.array(grid_poses(n_hyp))
+        self._poses_dev = torch.from_numpy(self.hyp_poses.astype(np.float32)).cuda()
+        self.fx = self.fy = 600.0 * render_res / 420.0
+        self.cx = self.cy = render_res / 2
+
+    def retrieve(self, crops: torch.Tensor, masks: torch.Tensor):
+        """crops bf16 [B,3,R,R], masks bool/u8 [B,R,R] -> (query patch feats [B,P,D], top-k scores, top-k idx)"""
+        feats = self.vit(crops, layer=self.layer, feature_type="patch")
+        g = self.crop_res // 14
+        desc = ops.ffa(feats, masks[:, : g * 14, : g * 14], cell=14, normalize=True)
+        s, i = self.bank.topk(desc, self.k)
+        return feats, s, i
+
+    def render_hypotheses(self):
+        rgb, depth = ops.rasterize(self.mesh, self._poses_dev, self.render_scale, self.fx, self.fy, self.cx, self.cy,
+                                   self.render_res, self.render_res)
+        ext = ops.depth_extents(depth, self.fx, self.fy, self.cx, self.cy)
+        crops = ops.crop_resize_pad(rgb, ext[:, :4].to(torch.int32), self.crop_res, 0.0, out_bf16=True)
+        return crops, ext
+
+    def hypothesis_features(self, crops: torch.Tensor) -> torch.Tensor:
+        return torch.cat([self.vit(crops[i:i + self.vit_batch], layer=self.layer, feature_type="patch")
+                          for i in range(0, crops.shape[0], self.vit_batch)], dim=0)
+
+    def run(self, crops: torch.Tensor, masks: torch.Tensor, K: np.ndarray, bboxes: np.ndarray, scales) -> List[ProposalResult]:
+        """one pass of the hot path over a batch of proposals (every stage executed for every proposal)"""
+        feats, top_s, top_i = self.retrieve(crops, masks)
+        out = []
+        for b in range(crops.shape[0]):
+            hyp_crops, ext = self.render_hypotheses()          # the retrieved mesh under all hypotheses
+            hyp_feats = self.hypothesis_features(hyp_crops)
+            q = ops.l2_normalize(feats[b])
+            scores = ops.template_score(hyp_feats, q)
+            idx_all = torch.arange(self.n_hyp, dtype=torch.int32, device=scores.device)
+            s3, i3 = ops.topk_merge(scores[None], idx_all[None], 3)
+            i3h = i3[0].cpu().numpy().astype(np.int64)
+            e = ext[i3[0].long()].cpu().numpy()
+            ratio = float(scales[b]) / self.render_scale
+            tco = [z_from_extents(bboxes[b], e[j, 4] * ratio, e[j, 5] * ratio, K, self.hyp_poses[i3h[j]]) for j in range(3)]
+            out.append(ProposalResult(top_s[b].cpu().numpy(), top_i[b].cpu().numpy(), i3h, s3[0].cpu().numpy(), tco))
+        return out
+
+
+def pack_results(results: List[ProposalResult]) -> torch.Tensor:
+    """fixed-width rows (top-1 mesh row, score, best hypothesis, score, R9, t3) for the result all-gather"""
+    rows = [[float(r.topk_idx[0]), float(r.topk_scores[0]), float(r.hyp_idx[0]), float(r.hyp_scores[0]),
+             *r.TCO[0][:3, :3].flatten().tolist(), *r.TCO[0][:3, 3].tolist()] for r in results]
+    return torch.tensor(rows, dtype=torch.float64).reshape(-1, 16)

@@ -149,6 +149,9 @@ int fp_timer_destroy(void* timer);
 /* toggles per-kernel-class event timing inside fp_vit_forward (gemm / attention / other), read back in ms */
 int fp_vit_profile(fp_vit* vit, int enable);
 int fp_vit_profile_read(fp_vit* vit, float* h_ms_gemm, float* h_ms_attn, float* h_ms_other, double* h_gemm_flops);
+/* number of GEMM kernel launches recorded since fp_vit_profile(vit, 1) (events are recorded without host syncs;
+ * fp_vit_profile_read synchronises once and sums) */
+long fp_vit_profile_gemm_launches(const fp_vit* vit);
 
 #ifdef __cplusplus
 }

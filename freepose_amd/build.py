@@ -25,6 +25,9 @@ REPO = ROOT.parent
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+    # gfx950 has one unified VGPR/AGPR file: keep MFMA accumulators in VGPRs so VALU epilogue / softmax-rescale work on
+    # them needs no v_accvgpr_read/write round trips (attention: -128 moves per KV tile, occupancy 2 -> 3 waves/SIMD)
+    "-mllvm", "-amdgpu-mfma-vgpr-form=1",
     "-Wno-unused-result", "-DNDEBUG",
 ]
 

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mnew = fmaxf(mrow[fq], mx);
-            const float alpha = exp2f((mrow[fq] - mnew) * p.scale_log2e);
+            // raw v_exp_f32 (results below 2^-126 flush to 0, which is what a masked / negligible weight should be)
+            const float alpha = __builtin_amdgcn_exp2f((mrow[fq] - mnew) * p.scale_log2e);
             mrow[fq] = mnew;
             const float mb = mnew * p.scale_log2e;
             float rs = 0.f;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
             for (int fk = 0; fk < 4; ++fk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pv[fk][r] = exp2f(fmaf(s[fk][fq][r], p.scale_log2e, -mb));
+                    pv[fk][r] = __builtin_amdgcn_exp2f(fmaf(s[fk][fq][r], p.scale_log2e, -mb));
                     rs += pv[fk][r];
                 }
             lsum[fq] = lsum[fq] * alpha + rs;

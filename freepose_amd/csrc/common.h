@@ -19,18 +19,28 @@ __host__ __device__ __forceinline__ float bf2f(bf16_t h) {
     return v.f;
 }
 __host__ __device__ __forceinline__ bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950 has a hardware RNE f32->bf16 convert (v_cvt_pk_bf16_f32); identical to the software form below for every
+    // finite input, branch-free (the software NaN test costs a divergent branch per element in epilogues).
+    return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));
+#else
     union { uint32_t u; float f; } v;
     v.f = f;
     uint32_t u = v.u;
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+#endif
 }
 // round an f32 to the nearest bf16 value but keep it in f32 (models a bf16 module boundary)
 __host__ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+    bf16x2_hw v;
+    v[0] = static_cast<__bf16>(lo);
+    v[1] = static_cast<__bf16>(hi);
+    return __builtin_bit_cast(uint32_t, v);  // one v_cvt_pk_bf16_f32
 }
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

@@ -17,6 +17,12 @@
 // src/pipeline/retrieval/dino.py:16-23 (patch_embed.proj, attn.qkv, attn.proj, mlp.fc1, mlp.fc2).
 #include "gemm_bf16.h"
 
+#include <stdlib.h>
+
+#ifndef FP_GEMM_DEFAULT_VARIANT
+#define FP_GEMM_DEFAULT_VARIANT 0
+#endif
+
 namespace {
 
 constexpr int BK = 64;         // bf16 per K stage  (128-byte LDS rows)
@@ -34,8 +40,22 @@ __device__ __forceinline__ int key_perm(int row) {
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output ulp):
+// erf(z) = 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1/(1 + p z), z >= 0; odd extension.  ~14 VALU ops vs ~40 for erff.
+__device__ __forceinline__ float gelu_erf_poly(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erfabs = fmaf(-poly * t, e, 1.0f);      // erf(|x|/sqrt2)
+    const float erfv = copysignf(erfabs, x);
+    return 0.5f * x * (1.0f + erfv);
+}
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     constexpr bool TRANS = (EPI == FP_EPI_VT);
     constexpr int NW = WM * WN;
@@ -122,28 +142,74 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         for (int j = 0; j < TR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = p.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
-        const char* sb = smem + (kt & 1) * STAGE;
+    auto load_frags = [&](const char* sb, int kk, bf16x8_t (&fr)[TR], bf16x8_t (&fc)[TC]) {
+        const int slotR = (((kk << 2) | lg) ^ keyR) << 4;
+        const int slotC = (((kk << 2) | lg) ^ keyC) << 4;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fr[TR], fc[TC];
-            const int slotR = (((kk << 2) | lg) ^ keyR) << 4;
-            const int slotC = (((kk << 2) | lg) ^ keyC) << 4;
+        for (int f = 0; f < TR; ++f) fr[f] = *(const bf16x8_t*)(sb + baseR + f * 4 * ROWB + slotR);
 #pragma unroll
-            for (int f = 0; f < TR; ++f)
-                fr[f] = *(const bf16x8_t*)(sb + baseR + f * 4 * ROWB + slotR);
+        for (int f = 0; f < TC; ++f) fc[f] = *(const bf16x8_t*)(sb + baseC + f * 16 * ROWB + slotC);
+    };
+    auto mma_block = [&](const bf16x8_t (&fr)[TR], const bf16x8_t (&fc)[TC]) {
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int f = 0; f < TC; ++f)
-                fc[f] = *(const bf16x8_t*)(sb + baseC + f * 16 * ROWB + slotC);
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int i = 0; i < TC; ++i)
+            for (int j = 0; j < TR; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[j], fc[i], acc[i][j], 0, 0, 0);
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
+    };
+
+    if constexpr ((VAR & 2) == 0) {
+        // ---- plain double-buffered loop: one barrier per K tile, fragments read right before use ----
+        stage(0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+            const char* sb = smem + (kt & 1) * STAGE;
 #pragma unroll
-                for (int j = 0; j < TR; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[j], fc[i], acc[i][j], 0, 0, 0);
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t fr[TR], fc[TC];
+                load_frags(sb, kk, fr, fc);
+                mma_block(fr, fc);
+            }
+        }
+    } else {
+        // ---- software-pipelined loop: fragments of k-step j+1 are read while k-step j's MFMAs run; the single
+        // barrier of a tile sits at its SECOND k-step, where every wave has finished reading the tile, so the DMA
+        // of tile t+2 is issued half a tile earlier and the next tile's first fragments are already in flight.
+        bf16x8_t frA[TR], fcA[TC], frB[TR], fcB[TC];
+        stage(0, 0);
+        if (nkt > 1) stage(1, 1);
+        if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IX + IW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // `settle`: pass a fragment set through an empty asm.  hipcc cannot count LDS reads across the loop back-edge
+        // and would otherwise emit lgkmcnt(0) AFTER the prefetch reads are issued (waiting for the prefetch itself);
+        // with the settle placed BEFORE the prefetch its wait covers only reads issued a whole MFMA block earlier.
+        auto settle = [&](bf16x8_t (&fr)[TR], bf16x8_t (&fc)[TC]) {
+#pragma unroll
+            for (int f = 0; f < TR; ++f) asm volatile("" : "+v"(fr[f]));
+#pragma unroll
+            for (int f = 0; f < TC; ++f) asm volatile("" : "+v"(fc[f]));
+        };
+        load_frags(smem, 0, frA, fcA);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char* sb = smem + (kt & 1) * STAGE;
+            settle(frA, fcA);
+            load_frags(sb, 1, frB, fcB);
+            mma_block(frA, fcA);
+            if (kt + 1 < nkt) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 2 < nkt) stage(kt & 1, kt + 2);
+                settle(frB, fcB);
+                load_frags(smem + ((kt + 1) & 1) * STAGE, 0, frA, fcA);
+            }
+            mma_block(frB, fcB);
         }
     }
 
@@ -181,7 +247,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
                 size_t orow = (size_t)m;
                 if constexpr (EPI == FP_EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int e = 0; e < RUN; ++e) v[e] = gelu_erf(rbf(v[e]));
+                    for (int e = 0; e < RUN; ++e) v[e] = (VAR & 4) ? gelu_erf_poly(rbf(v[e])) : gelu_erf(rbf(v[e]));
                 } else if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
                     const uint4* rp = (const uint4*)(p.resid + (size_t)m * p.ldr + nb);
                     uint4 r0 = rp[0], r1 = rp[1];
@@ -247,11 +313,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr int SMEM = 2 * STAGE;
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         FP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -267,8 +333,19 @@ template <int EPI>
 int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // big tile once the grid can fill the chip with it, else the 128x128 tile
     const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
-    if (tiles_big >= 192) return launch_cfg<256, 256, 2, 4, EPI>(a, stream);
-    return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
+    // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads,
+    // 4 = polynomial erf in the GELU epilogue.  FP_GEMM_VARIANT overrides the default (A/B probing only).
+    static int var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
+    const bool big = tiles_big >= 192;
+#define FP_GEMM_CASE(V)                                                          \
+    case V: return big ? launch_cfg<256, 256, 2, 4, EPI, V>(a, stream)          \
+                       : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);
+    switch (var & 7) {
+        FP_GEMM_CASE(0) FP_GEMM_CASE(1) FP_GEMM_CASE(2) FP_GEMM_CASE(3)
+        FP_GEMM_CASE(4) FP_GEMM_CASE(5) FP_GEMM_CASE(6) FP_GEMM_CASE(7)
+    }
+#undef FP_GEMM_CASE
+    return FP_ERR_INVALID;
 }
 
 }  // namespace

@@ -112,9 +112,9 @@ def test_online_estimator_recovers_planted_pose(tmp_path):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         fe = DINOv2FeatureExtractor("dinov2_vits14_reg", seed=4)
-    est = DinoOnlinePoseEstimator(n_coarse_poses=8, n_fine_poses=2000, cache_size=0, cache_dir=tmp_path / "c", feature_extractor=fe)
+    est = DinoOnlinePoseEstimator(n_coarse_poses=8, n_fine_poses=20000, cache_size=0, cache_dir=tmp_path / "c", feature_extractor=fe)
     mesh = _mesh()
-    i = 777
+    i = 7777
     true_pose = est.fine_mesh_poses[i]
     render = est.renderer.render_from_poses(mesh, [true_pose], scale=0.25)
     crops, _, masks, ext = MeshRenderer.generate_proposals(render, return_extents=True)

@@ -31,6 +31,7 @@ constexpr int QB = QW * NWAVE;
 constexpr int ROWB = 128;   // bytes per LDS row (64 bf16)
 constexpr int TILE = KVB * ROWB;          // 8 KiB (K tile) == 64 d-rows * 128 B (V^T tile)
 constexpr int STAGE = 2 * TILE;
+constexpr int NSLOT = 3;                  // LDS ring depth (48 KiB per workgroup -> 3 workgroups per CU)
 
 struct AttnArgs {
     const bf16_t* QK; int ldqk;  // elements
@@ -110,13 +111,29 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
     float mrow[2] = {-1e30f, -1e30f};
     float lsum[2] = {0.f, 0.f};
 
+    // 3-slot LDS ring, two K/V tiles in flight: each wave issues 4 DMA instructions per tile, so `vmcnt(4)` means
+    // "tile t has landed, tile t+1 may still be in flight".  Raw s_barrier (a __syncthreads() would drain vmcnt to 0).
+    // The barrier of iteration t also proves every wave finished reading tile t-1, whose slot tile t+2 now reuses.
     const int ntile = (p.n_tok + KVB - 1) / KVB;
     stage(0, 0);
+    if (ntile > 1) stage(1, KVB);
+    // The Q fragments came from ordinary global loads; while a DMA is in flight hipcc would protect their first use in
+    // the loop with vmcnt(0) EVERY iteration (draining the ring).  Wait once here and pass them through an empty asm so
+    // the compiler sees them as ready registers.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int fq = 0; fq < 2; ++fq)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) asm volatile("" : "+v"(qf[fq][kk]));
+    int slot = 0;
     for (int t = 0; t < ntile; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < ntile) stage((t + 1) & 1, (t + 1) * KVB);
-        const char* sb = smem + (t & 1) * STAGE;
+        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ntile) stage(slot >= 1 ? slot - 1 : NSLOT - 1, (t + 2) * KVB);   // (slot + 2) % 3
+        const char* sb = smem + slot * STAGE;
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
         const int kv0 = t * KVB;
 
         // ---- S^T = K Q^T -------------------------------------------------------------------------
@@ -197,10 +214,11 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) {
                 const char* rp = sb + baseV + fd * 4 * ROWB;
-                const uint2 a0 = *(const uint2*)(rp + s0);
-                const uint2 a1 = *(const uint2*)(rp + s1);
-                const uint4 w = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, w);
+                // (typed as bf16 vectors like the K reads: an integer-typed LDS load makes hipcc protect it against the
+                //  in-flight LDS DMA with a vmcnt(0), draining the ring every tile)
+                const bf16x4_t a0 = *(const bf16x4_t*)(rp + s0);
+                const bf16x4_t a1 = *(const bf16x4_t*)(rp + s1);
+                const bf16x8_t vf = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                 for (int fq = 0; fq < 2; ++fq)
                     o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[fq][ks], o[fd][fq], 0, 0, 0);
@@ -246,7 +264,7 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     a.B = B; a.H = H; a.n_tok = n_tok; a.npad = npad; a.D = H * HD;
     a.scale_log2e = 1.4426950408889634f / 8.0f;
     dim3 grid(cdiv(npad, QB), H, B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NWAVE * 64), NSLOT * STAGE, stream, a);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -10,7 +10,7 @@ export PYTHONPATH=$REPO
 V=${FP_GEMM_VARIANT:-}
 
 echo "== kernel trace + stats of bench.py"
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_stdout.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_stdout.log 2>&1
 find $OUT/bench -name "*kernel_stats*.csv" | head -1 | xargs -I{} cp {} $OUT/bench_kernel_stats.csv
 tail -2 $OUT/bench_stdout.log
 
@@ -18,9 +18,9 @@ for shape in "1024 4096 2" "2048 1024 0" "4096 1024 1"; do
   set -- $shape
   tag="N$1_K$2_e$3"
   echo "== PMC passes for gemm $tag"
-  timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $OUT/pmc1_$tag -o p -- python $REPO/tools/gemm_probe.py --N $1 --K $2 --epi $3 --iters 3 > $OUT/pmc1_$tag.log 2>&1
-  timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc2_$tag -o p -- python $REPO/tools/gemm_probe.py --N $1 --K $2 --epi $3 --iters 3 > $OUT/pmc2_$tag.log 2>&1
-  timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum WRITE_SIZE -d $OUT/pmc3_$tag -o p -- python $REPO/tools/gemm_probe.py --N $1 --K $2 --epi $3 --iters 3 > $OUT/pmc3_$tag.log 2>&1
+  timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS -d $OUT/pmc1_$tag -o p -- python $REPO/tools/gemm_probe.py --N $1 --K $2 --epi $3 --iters 3 > $OUT/pmc1_$tag.log 2>&1
+  timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/pmc2_$tag -o p -- python $REPO/tools/gemm_probe.py --N $1 --K $2 --epi $3 --iters 3 > $OUT/pmc2_$tag.log 2>&1
+  timeout 300 rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum WRITE_SIZE -d $OUT/pmc3_$tag -o p -- python $REPO/tools/gemm_probe.py --N $1 --K $2 --epi $3 --iters 3 > $OUT/pmc3_$tag.log 2>&1
 done
 # keep only the small CSVs (counter collection + stats), drop bulky traces
 python - <<'EOF'

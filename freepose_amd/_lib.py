@@ -27,6 +27,7 @@ class VitArch(C.Structure):
 SIGNATURES = {
     "fp_last_error": (c_char_p, []),
     "fp_version": (c_int, []),
+    "fp_set_option": (c_int, [c_char_p, c_int]),
     "fp_ctx_create": (c_int, [c_int, P(c_void_p)]),
     "fp_ctx_destroy": (c_int, [c_void_p]),
     "fp_ctx_workspace_bytes": (c_size_t, [c_void_p]),

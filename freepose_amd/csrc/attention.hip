@@ -31,7 +31,6 @@ constexpr int QB = QW * NWAVE;
 constexpr int ROWB = 128;   // bytes per LDS row (64 bf16)
 constexpr int TILE = KVB * ROWB;          // 8 KiB (K tile) == 64 d-rows * 128 B (V^T tile)
 constexpr int STAGE = 2 * TILE;
-constexpr int NSLOT = 3;                  // LDS ring depth (48 KiB per workgroup -> 3 workgroups per CU)
 
 struct AttnArgs {
     const bf16_t* QK; int ldqk;  // elements
@@ -47,6 +46,7 @@ __device__ __forceinline__ int key_perm4(int row) {  // rows laid out 16a + 4f +
     return (((rl >> 4) << 1) | ((rl & 3) >> 1)) & 7;
 }
 
+template <int NSLOT>  // LDS ring depth: NSLOT-1 K/V tiles in flight (16 KiB per slot)
 __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,8 +115,11 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
     // "tile t has landed, tile t+1 may still be in flight".  Raw s_barrier (a __syncthreads() would drain vmcnt to 0).
     // The barrier of iteration t also proves every wave finished reading tile t-1, whose slot tile t+2 now reuses.
     const int ntile = (p.n_tok + KVB - 1) / KVB;
+    constexpr int PF = NSLOT - 1;   // tiles in flight
     stage(0, 0);
-    if (ntile > 1) stage(1, KVB);
+#pragma unroll
+    for (int i = 1; i < PF; ++i)
+        if (ntile > i) stage(i, i * KVB);
     // The Q fragments came from ordinary global loads; while a DMA is in flight hipcc would protect their first use in
     // the loop with vmcnt(0) EVERY iteration (draining the ring).  Wait once here and pass them through an empty asm so
     // the compiler sees them as ready registers.
@@ -127,11 +130,14 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
         for (int kk = 0; kk < 2; ++kk) asm volatile("" : "+v"(qf[fq][kk]));
     int slot = 0;
     for (int t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // tiles t+1 .. t+PF-1 may stay in flight (4 DMA instructions per tile per wave); near the end fewer are pending
+        const int ahead = min(PF - 1, ntile - 1 - t);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < ntile) stage(slot >= 1 ? slot - 1 : NSLOT - 1, (t + 2) * KVB);   // (slot + 2) % 3
+        if (t + PF < ntile) stage(slot >= 1 ? slot - 1 : NSLOT - 1, (t + PF) * KVB);   // slot of tile t-1 = (slot+PF) % NSLOT
         const char* sb = smem + slot * STAGE;
         slot = slot + 1 == NSLOT ? 0 : slot + 1;
         const int kv0 = t * KVB;
@@ -264,7 +270,10 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     a.B = B; a.H = H; a.n_tok = n_tok; a.npad = npad; a.D = H * HD;
     a.scale_log2e = 1.4426950408889634f / 8.0f;
     dim3 grid(cdiv(npad, QB), H, B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NWAVE * 64), NSLOT * STAGE, stream, a);
+    const int nslot = fp_opt_get(FP_OPT_ATTN_SLOTS, 3);
+    if (nslot == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    else if (nslot == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(NWAVE * 64), 4 * STAGE, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(NWAVE * 64), 3 * STAGE, stream, a);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -19,6 +19,16 @@ void fp_set_error(const char* fmt, ...) {
 extern "C" const char* fp_last_error(void) { return g_err; }
 extern "C" int fp_version(void) { return 100; }
 
+static int g_opts[FP_OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+int fp_opt_get(int key, int dflt) { return (key >= 0 && key < FP_OPT_COUNT && g_opts[key] >= 0) ? g_opts[key] : dflt; }
+extern "C" int fp_set_option(const char* name, int value) {
+    FP_REQUIRE(name, "set_option: null name");
+    if (!strcmp(name, "gemm_variant")) g_opts[FP_OPT_GEMM_VARIANT] = value;
+    else if (!strcmp(name, "attn_slots")) g_opts[FP_OPT_ATTN_SLOTS] = value;
+    else { fp_set_error("set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
+    return FP_OK;
+}
+
 int fp_ctx::get(const char* name, size_t bytes, void** out) {
     Buf& b = bufs[name];
     if (b.bytes < bytes) {

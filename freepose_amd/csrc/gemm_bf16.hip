@@ -335,11 +335,15 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
     // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads,
     // 4 = polynomial erf in the GELU epilogue.  FP_GEMM_VARIANT overrides the default (A/B probing only).
-    static int var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
+    static int env_var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
+    const int var = fp_opt_get(FP_OPT_GEMM_VARIANT, env_var);
     const bool big = tiles_big >= 192;
 #define FP_GEMM_CASE(V)                                                          \
     case V: return big ? launch_cfg<256, 256, 2, 4, EPI, V>(a, stream)          \
                        : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);
+    if (big && (var & 8)) {   // experimental: 16-wave workgroup (4 waves/SIMD), 64x64 per wave, non-pipelined reads
+        if constexpr (EPI != FP_EPI_VT) return launch_cfg<256, 256, 4, 4, EPI, 4>(a, stream);
+    }
     switch (var & 7) {   // measured on MI355X (profiles/): 6 is the fastest; 0 is kept as the plain baseline for A/B runs
         FP_GEMM_CASE(0)
         default:

@@ -27,6 +27,11 @@ def context(device: Optional[int] = None):
     return h
 
 
+def set_option(name: str, value: int):
+    """experiment toggle (A/B measurements): 'gemm_variant', 'attn_slots'; value < 0 restores the default"""
+    check(_lib.load().fp_set_option(name.encode(), int(value)), "fp_set_option")
+
+
 def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
     if not t.is_cuda:
         t = t.to("cuda", non_blocking=False)

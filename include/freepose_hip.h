@@ -27,6 +27,8 @@ typedef struct fp_mesh fp_mesh; /* device copy of a triangle mesh for the raster
 
 const char* fp_last_error(void);
 int fp_version(void);
+/* experiment toggles for A/B measurements ("gemm_variant", "attn_slots"); value < 0 restores the default */
+int fp_set_option(const char* name, int value);
 int fp_ctx_create(int device, fp_ctx** out);
 int fp_ctx_destroy(fp_ctx* ctx);
 /* bytes currently held in the context's workspaces (diagnostics) */

@@ -40,6 +40,26 @@ struct AttnArgs {
     float scale_log2e;           // log2(e) / sqrt(hd)
 };
 
+// combine a value with the lane whose id differs in bit 4 (16-lane rows) / bit 5 (32-lane halves): gfx950
+// v_permlane16_swap / v_permlane32_swap are plain VALU instructions (a ds_bpermute round trip costs ~100 cycles of
+// latency on the softmax critical path).  swap(a=v, b=v) leaves {own, partner} in the two results on every lane.
+__device__ __forceinline__ float xlane_max16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xlane_max32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xlane_sum16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xlane_sum32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ int key_plain(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int key_perm4(int row) {  // rows laid out 16a + 4f + b (a,b in 0..3)
     const int rl = row & 63;
@@ -179,8 +199,9 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
             for (int fk = 0; fk < 4; ++fk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[fk][fq][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // the 4 lanes sharing a query differ in lane bits 4 and 5: VALU row/half swaps, not ds_bpermute
+            mx = xlane_max16(mx);
+            mx = xlane_max32(mx);
             const float mnew = fmaxf(mrow[fq], mx);
             // raw v_exp_f32 (results below 2^-126 flush to 0, which is what a masked / negligible weight should be)
             const float alpha = __builtin_amdgcn_exp2f((mrow[fq] - mnew) * p.scale_log2e);
@@ -236,8 +257,8 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int fq = 0; fq < 2; ++fq) {
         float l = lsum[fq];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xlane_sum16(l);
+        l = xlane_sum32(l);
         const float inv = 1.0f / l;
         const int q = q0 + 16 * fq + li;
         if (q < p.npad) {
@@ -270,7 +291,7 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     a.B = B; a.H = H; a.n_tok = n_tok; a.npad = npad; a.D = H * HD;
     a.scale_log2e = 1.4426950408889634f / 8.0f;
     dim3 grid(cdiv(npad, QB), H, B);
-    const int nslot = fp_opt_get(FP_OPT_ATTN_SLOTS, 3);
+    const int nslot = fp_opt_get(FP_OPT_ATTN_SLOTS, 2);   // measured: 2 >= 3 > 4 (profiles/r01_ab.md)
     if (nslot == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     else if (nslot == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(NWAVE * 64), 4 * STAGE, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(NWAVE * 64), 3 * STAGE, stream, a);

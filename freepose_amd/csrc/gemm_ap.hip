@@ -146,7 +146,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_ap_kernel(FpGemmArgs p) {
 
     for (int j = 0; j < nsteps; ++j) {
         // ---------------- L slot: DMA for step j+3, fragments of step j ----------------
-        if (j + 3 < nsteps) { issue(j + 3); issued = j + 3; }
+        if (j + 3 < nsteps) {
+            if constexpr (!(VAR & 64)) issue(j + 3);   // ablation bit 64: no in-loop DMA (timing probe, wrong results)
+            issued = (VAR & 64) ? issued : j + 3;
+        }
         load_frags(j);
         {   // next slot's reader: group B reads step j (A's view) / group A reads step j+1 (B's view)
             const int needed = groupB ? j + 1 : j;
@@ -154,7 +157,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_ap_kernel(FpGemmArgs p) {
         }
         slot_barrier();
         // ---------------- M slot: 32 MFMAs of step j ----------------
-        mma();
+        if constexpr (!(VAR & 32)) mma();             // ablation bit 32: no MFMAs (timing probe, wrong results)
+        else {
+#pragma unroll
+            for (int f = 0; f < TR; ++f) asm volatile("" ::"v"(fr[f]));
+#pragma unroll
+            for (int f = 0; f < TC; ++f) asm volatile("" ::"v"(fc[f]));
+        }
         if (j + 1 < nsteps) {
             wait_vm_dyn(issued - (j + 1));   // step j+1 is read in the next slot (by A: L(j+1); by B in the one after)
             slot_barrier();
@@ -165,10 +174,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_ap_kernel(FpGemmArgs p) {
     fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg);
 }
 
-template <int EPI>
+template <int EPI, int VAR = 4>
 int launch_ap(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int SMEM = NST * STG;
-    auto kern = gemm_ap_kernel<EPI, 4>;
+    auto kern = gemm_ap_kernel<EPI, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         FP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -187,7 +196,13 @@ int fp_gemm_bf16_ap(const FpGemmArgs& a, int epi, hipStream_t stream) {
     switch (epi) {
         case FP_EPI_BIAS: return launch_ap<FP_EPI_BIAS>(a, stream);
         case FP_EPI_BIAS_GELU: return launch_ap<FP_EPI_BIAS_GELU>(a, stream);
-        case FP_EPI_BIAS_LS_RES: return launch_ap<FP_EPI_BIAS_LS_RES>(a, stream);
+        case FP_EPI_BIAS_LS_RES: {
+            const int abl = fp_opt_get(FP_OPT_GEMM_VARIANT, 0) & (32 | 64);   // timing ablations (A/B probing only)
+            if (abl == 32) return launch_ap<FP_EPI_BIAS_LS_RES, 4 | 32>(a, stream);
+            if (abl == 64) return launch_ap<FP_EPI_BIAS_LS_RES, 4 | 64>(a, stream);
+            if (abl == 96) return launch_ap<FP_EPI_BIAS_LS_RES, 4 | 96>(a, stream);
+            return launch_ap<FP_EPI_BIAS_LS_RES>(a, stream);
+        }
         case FP_EPI_PATCH: return launch_ap<FP_EPI_PATCH>(a, stream);
         case FP_EPI_VT: return launch_ap<FP_EPI_VT>(a, stream);
         default: fp_set_error("gemm_ap: unknown epilogue %d", epi); return FP_ERR_INVALID;

@@ -21,7 +21,7 @@
 #include <stdlib.h>
 
 #ifndef FP_GEMM_DEFAULT_VARIANT
-#define FP_GEMM_DEFAULT_VARIANT 6
+#define FP_GEMM_DEFAULT_VARIANT 14
 #endif
 
 namespace {

@@ -37,6 +37,7 @@ def ab(name, variants, setter, fn, flops, rounds=5):
 
 def main():
     gemm_variants = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "6,14,0".split(","))]
+    only_gemm = len(sys.argv) > 2
     attn_variants = [2, 3, 4]
     M = 64 * 1376
     for (N, K, epi) in [(2048, 1024, 0), (1024, 1024, 2), (4096, 1024, 1), (1024, 4096, 2)]:
@@ -48,7 +49,7 @@ def main():
         o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ab(f"gemm N={N} K={K} epi={epi}", gemm_variants, lambda v: ops.set_option("gemm_variant", v),
            lambda: ops.gemm(x, w, b, epi, gamma=g, resid=r, out=o), 2.0 * M * N * K)
-    for (B, n_tok) in [(64, 1374), (64, 905)]:
+    for (B, n_tok) in ([] if only_gemm else [(64, 1374), (64, 905)]):
         npad = (n_tok + 15) // 16 * 16
         qk = torch.randn(B * npad, 2048, device="cuda").to(torch.bfloat16)
         vt = torch.randn(B, 16, 64, npad, device="cuda").to(torch.bfloat16)

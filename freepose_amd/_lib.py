@@ -40,6 +40,7 @@ SIGNATURES = {
     "fp_bank_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fp_bank_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fp_topk_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fp_rerank_views": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fp_l2_normalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fp_template_score": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fp_crop_resize_pad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,

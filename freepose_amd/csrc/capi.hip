@@ -430,6 +430,14 @@ extern "C" int fp_topk_merge(fp_ctx* ctx, const float* cs, const int32_t* ci, in
     return fp_topk_merge_launch(cs, ci, Q, C, k, os, oi, (hipStream_t)stream);
 }
 
+extern "C" int fp_rerank_views(fp_ctx* ctx, const void* d_views, const int32_t* d_offsets, const int32_t* d_cand,
+                               const void* d_queries, int Q, int C, int D, int k, float* d_out, void* stream) {
+    FP_REQUIRE(ctx && d_views && d_offsets && d_cand && d_queries && d_out, "rerank_views: null argument");
+    if (Q == 0 || C == 0) return FP_OK;
+    return fp_rerank_views_launch((const bf16_t*)d_views, d_offsets, d_cand, (const bf16_t*)d_queries, d_out, Q, C, D, k,
+                                  (hipStream_t)stream);
+}
+
 extern "C" int fp_template_score(fp_ctx* ctx, const void* d_tmpl, const void* d_query, const float* d_weights, int T,
                                  int P, int D, float* d_scores, void* stream) {
     FP_REQUIRE(ctx && d_tmpl && d_query && d_scores, "template_score: null argument");

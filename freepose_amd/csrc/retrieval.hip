@@ -301,6 +301,93 @@ __global__ __launch_bounds__(64) void template_mean_kernel(const float* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K11 per-view fine re-rank (scripts/extract_proposals_ground.py:147-160; video variant :160-176):
+//   for each coarse candidate c of query q:  s_v = bf16( normalize_bf16(view_v) . f_q ) over the mesh's views,
+//   score[q,c] = float32 numpy mean of the top-k s_v (sorted descending, numpy pairwise summation order).
+// The per-view descriptors are kept raw fp32->bf16 (as np.load(...).to(bf16)) in one device-resident store
+// [sum_views, D] with per-mesh row offsets; they are normalised on the fly with the reference's rounding points.
+// One workgroup per (query, candidate); one wave per view row, scores into LDS, bitonic sort, ordered mean.
+constexpr int RR_MAXV = 1024;
+template <int NCH>
+__global__ __launch_bounds__(256) void rerank_views_kernel(const bf16_t* __restrict__ views, const int* __restrict__ offsets,
+                                                           const int* __restrict__ cand, const bf16_t* __restrict__ queries,
+                                                           float* __restrict__ out, int C, int D, int k) {
+    __shared__ float sc[RR_MAXV];
+    const int q = blockIdx.y, c = blockIdx.x;
+    const int mesh = cand[(size_t)q * C + c];
+    const int r0 = offsets[mesh], nv = min(offsets[mesh + 1] - r0, RR_MAXV);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float qv[NCH][8];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int base = (ch * 64 + lane) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[ch][e] = base < D ? bf2f(queries[(size_t)q * D + base + e]) : 0.f;
+    }
+    for (int v = wave; v < nv; v += 4) {
+        const bf16_t* row = views + (size_t)(r0 + v) * D;
+        float x[NCH][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int base = (ch * 64 + lane) * 8;
+            uint4 a = make_uint4(0, 0, 0, 0);
+            if (base < D) a = *(const uint4*)(row + base);
+            const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[ch][2 * e] = lo_bf(w[e]); x[ch][2 * e + 1] = hi_bf(w[e]); }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = __fmaf_rn(x[ch][e], x[ch][e], ss);
+        }
+        ss = wave_sum(ss);
+        const float nrm = fmaxf(rbf(__fsqrt_rn(ss)), 1e-12f);
+        float acc = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __fmaf_rn(rbf(__fdiv_rn(x[ch][e], nrm)), qv[ch][e], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) sc[v] = rbf(acc);
+    }
+    int n2 = 1;
+    while (n2 < nv) n2 <<= 1;
+    __syncthreads();
+    for (int i = nv + threadIdx.x; i < n2; i += blockDim.x) sc[i] = -3.0e38f;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = ((i & size) == 0);
+                    const float a = sc[i], b = sc[j];
+                    if ((a < b) == desc) { sc[i] = b; sc[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x == 0) {
+        // numpy float32 mean of the kk top values: pairwise summation (8 running sums, tree, sequential tail; n <= 128)
+        const int kk = min(k, nv);
+        float res;
+        if (kk < 8) {
+            res = 0.f;
+            for (int i = 0; i < kk; ++i) res += sc[i];
+        } else {
+            float r[8];
+            for (int j = 0; j < 8; ++j) r[j] = sc[j];
+            int i = 8;
+            for (; i < kk - (kk % 8); i += 8)
+                for (int j = 0; j < 8; ++j) r[j] += sc[i + j];
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < kk; ++i) res += sc[i];
+        }
+        out[(size_t)q * C + c] = kk > 0 ? __fdiv_rn(res, (float)kk) : -3.0e38f;
+    }
+}
+
 }  // namespace
 
 int fp_cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s) {
@@ -365,6 +452,19 @@ int fp_template_score_launch(const bf16_t* tmpl, const bf16_t* qn, const float* 
     else hipLaunchKernelGGL(template_dots_kernel<3>, dim3(blocks), dim3(256), 0, s, tmpl, qn, dots, T, P, D);
     FP_LAUNCH_CHECK();
     hipLaunchKernelGGL(template_mean_kernel, dim3(T), dim3(64), 0, s, dots, weights, scores, T, P);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+// per-view re-rank: out [Q,C] f32.  k <= 128 (numpy pairwise block), views per mesh <= 1024.
+int fp_rerank_views_launch(const bf16_t* views, const int* offsets, const int* cand, const bf16_t* queries, float* out,
+                           int Q, int C, int D, int k, hipStream_t s) {
+    FP_REQUIRE(Q > 0 && C > 0 && D % 8 == 0 && D <= 1536 && k > 0 && k <= 128, "rerank_views: bad shape");
+    const int nch = cdiv(D, 512);
+    dim3 grid(C, Q);
+    if (nch == 1) hipLaunchKernelGGL(rerank_views_kernel<1>, grid, dim3(256), 0, s, views, offsets, cand, queries, out, C, D, k);
+    else if (nch == 2) hipLaunchKernelGGL(rerank_views_kernel<2>, grid, dim3(256), 0, s, views, offsets, cand, queries, out, C, D, k);
+    else hipLaunchKernelGGL(rerank_views_kernel<3>, grid, dim3(256), 0, s, views, offsets, cand, queries, out, C, D, k);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -220,6 +220,20 @@ def topk_merge(cand_scores: torch.Tensor, cand_idx: torch.Tensor, k: int):
     return s, i
 
 
+def rerank_views(views_bf16: torch.Tensor, offsets: torch.Tensor, cand_idx: torch.Tensor, queries: torch.Tensor, k: int) -> torch.Tensor:
+    """per-view fine re-rank scores f32 [Q,C] (numpy-mean of the top-k per-view scores of each candidate mesh)"""
+    lib = _lib.load()
+    v = _dev(views_bf16, torch.bfloat16)
+    off = _dev(offsets).to(torch.int32).contiguous()
+    cd = _dev(cand_idx).to(torch.int32).contiguous()
+    q = _dev(queries, torch.bfloat16).reshape(cd.shape[0], v.shape[1])
+    out = torch.empty(cd.shape, dtype=torch.float32, device=v.device)
+    if cd.numel():
+        check(lib.fp_rerank_views(context(), ptr(v), ptr(off), ptr(cd), ptr(q), cd.shape[0], cd.shape[1], v.shape[1], int(k),
+                                  ptr(out), current_stream()), "fp_rerank_views")
+    return out
+
+
 def template_score(tmpl: torch.Tensor, query: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
     """tmpl bf16 [T,P,D] raw, query bf16 [P,D] used as given -> scores f32 [T] (bf16-valued unless weighted)."""
     lib = _lib.load()

@@ -48,6 +48,28 @@ class TemplateBank:
         names = [self.mesh_ids[j] if self.mesh_ids else int(j) for j in i]
         return names, s.tolist(), i
 
+    # ---- per-view fine re-rank (extract_proposals_ground.py:147-160; --topk k) -----------------------------------------
+    def attach_views(self, per_mesh_views: Sequence[np.ndarray]):
+        """per_mesh_views[i]: the [<=600, D] fp32 descriptor file of bank row i (data/datasets/<retrieval>/<mesh>.npy).
+        Kept device-resident as raw bf16 rows back to back (the whole Objaverse-LVIS+GSO store is 46037 x 600 x 1024 x 2 B
+        = 56.6 GB, inside one MI355X's HBM) instead of 100 np.load calls per proposal."""
+        if len(per_mesh_views) != self.N:
+            raise ValueError("need one per-view descriptor array per bank row")
+        counts = np.array([len(v) for v in per_mesh_views], dtype=np.int64)
+        self.view_offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).cuda()
+        self.views = torch.cat([torch.as_tensor(v, dtype=torch.float32) for v in per_mesh_views]).to("cuda", torch.bfloat16)
+
+    def retrieve_reranked(self, queries: torch.Tensor, topk: int = 25, n_coarse: int = 100):
+        """coarse top-100 scan, then per-candidate mean of its top-k per-view scores; the winner is the FIRST maximum in
+        coarse order (Python `max(dict, key=dict.get)` semantics).  Returns (names, scores, bank rows, fine scores [Q,C])."""
+        s, i = self.topk(queries, min(n_coarse, self.N))
+        fine = ops.rerank_views(self.views, self.view_offsets, i, queries, topk)
+        pos = torch.arange(fine.shape[1], dtype=torch.int32, device=fine.device)[None].expand(fine.shape[0], -1).contiguous()
+        best_s, best_p = ops.topk_merge(fine, pos, 1)
+        rows = torch.gather(i, 1, best_p.long())[:, 0].cpu().numpy()
+        names = [self.mesh_ids[j] if self.mesh_ids else int(j) for j in rows]
+        return names, best_s[:, 0].cpu().numpy().tolist(), rows, fine
+
     def soft_vote(self, per_frame_queries: List[torch.Tensor], k: int = 100):
         """video soft-vote (ground_video.py:154-159,186-190): dense [N] score vectors with only each frame's top-k
         filled, mean over frames, per-object arg-max.  per_frame_queries[f] is bf16 [n_obj, D]."""

@@ -81,6 +81,12 @@ int fp_bank_topk(fp_ctx* ctx, const void* d_bank_bf16, int N, int D, const void*
 /* merge per-shard candidates [Q,C] down to [Q,k] with the same ordering (after an RCCL all-gather). */
 int fp_topk_merge(fp_ctx* ctx, const float* d_cand_scores, const int32_t* d_cand_idx, int Q, int C, int k,
                   float* d_out_scores, int32_t* d_out_idx, void* stream);
+/* per-view fine re-rank (scripts/extract_proposals_ground.py:147-160, --topk k): d_views bf16 [sum_views, D] = the
+ * per-mesh descriptor files back to back (np.load(...).to(bf16), NOT normalised), d_offsets i32 [n_mesh+1] row offsets,
+ * d_cand i32 [Q,C] coarse candidates (mesh rows), d_queries bf16 [Q,D].  d_out f32 [Q,C] = numpy float32 mean of the
+ * top-k per-view scores bf16(normalize_bf16(view) . f).  k <= 128, <= 1024 views per mesh. */
+int fp_rerank_views(fp_ctx* ctx, const void* d_views, const int32_t* d_offsets, const int32_t* d_cand,
+                    const void* d_queries, int Q, int C, int D, int k, float* d_out, void* stream);
 /* F.normalize(x, dim=-1) on bf16 rows with the reference's rounding points. */
 int fp_l2_normalize(fp_ctx* ctx, const void* d_x_bf16, int rows, int D, void* d_y_bf16, void* stream);
 

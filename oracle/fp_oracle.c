@@ -193,6 +193,49 @@ static int nearest_src(int dst, int in, int out, float inv_scale, int small) {
     return s > in - 1 ? in - 1 : s;
 }
 
+/* numpy's float32 pairwise summation for n <= 128 (np.mean of the top-k scores, extract_proposals_ground.py:156) */
+static float np_pairwise_sum_f32(const float* a, int n) {
+    if (n < 8) { float r = 0.f; for (int i = 0; i < n; ++i) r += a[i]; return r; }
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+static int fdesc_cmp(const void* a, const void* b) { const float x = *(const float*)a, y = *(const float*)b; return (x < y) - (x > y); }
+
+/* per-view fine re-rank (scripts/extract_proposals_ground.py:147-160): per candidate mesh, normalise its per-view
+ * descriptors in bf16, dot with the query (bf16 result), top-k, numpy float32 mean.  views bf16 [sum_views, D] (raw),
+ * offsets [n_mesh+1], cand [Q,C], out [Q,C]. */
+void fpo_rerank_views(const bf16* views, const int32_t* offsets, const int32_t* cand, const bf16* queries, int Q, int C, int D,
+                      int k, float* out) {
+    float* tn = (float*)malloc((size_t)D * 4);
+    float* qf = (float*)malloc((size_t)D * 4);
+    float* sc = (float*)malloc(1024 * 4);
+    for (int q = 0; q < Q; ++q) {
+        for (int i = 0; i < D; ++i) qf[i] = bf2f(queries[(size_t)q * D + i]);
+        for (int c = 0; c < C; ++c) {
+            const int mesh = cand[(size_t)q * C + c];
+            const int r0 = offsets[mesh];
+            int nv = offsets[mesh + 1] - r0; if (nv > 1024) nv = 1024;
+            for (int v = 0; v < nv; ++v) {
+                const bf16* x = views + (size_t)(r0 + v) * D;
+                float n = rbf(sqrtf(dot64_bf(x, x, D)));
+                if (n < 1e-12f) n = 1e-12f;
+                for (int i = 0; i < D; ++i) tn[i] = rbf(bf2f(x[i]) / n);
+                sc[v] = rbf(dot64_ff(tn, qf, D));
+            }
+            qsort(sc, nv, sizeof(float), fdesc_cmp);
+            const int kk = k < nv ? k : nv;
+            out[(size_t)q * C + c] = kk > 0 ? np_pairwise_sum_f32(sc, kk) / (float)kk : -3.0e38f;
+        }
+    }
+    free(tn); free(qf); free(sc);
+}
+
 /* CropResizePad.__call__ (src/utils/bbox_utils.py:20-56).  images f32 [n_img,C,H,W] (src_u8=0) or
  * u8 [n_img,H,W,C] (src_u8=1, value/255 as in renderer.py:121); out f32 [n,C,target,target].
  * mask_mode as in include/freepose_hip.h.  Returns 0, or 1+i if box i does not resize to `target`. */

@@ -125,6 +125,17 @@ def template_score(tmpl_bits: np.ndarray, q_bits: np.ndarray, weights: np.ndarra
     return s
 
 
+def rerank_views(view_bits: np.ndarray, offsets: np.ndarray, cand: np.ndarray, q_bits: np.ndarray, k: int) -> np.ndarray:
+    v = np.ascontiguousarray(view_bits, dtype=np.uint16)
+    off = np.ascontiguousarray(offsets, dtype=np.int32)
+    cd = np.ascontiguousarray(cand, dtype=np.int32)
+    q = np.ascontiguousarray(q_bits, dtype=np.uint16).reshape(cd.shape[0], v.shape[1])
+    out = np.empty(cd.shape, dtype=np.float32)
+    lib().fpo_rerank_views(_p(v), _p(off), _p(cd), _p(q), C.c_int(cd.shape[0]), C.c_int(cd.shape[1]), C.c_int(v.shape[1]),
+                           C.c_int(k), _p(out))
+    return out
+
+
 def crop_resize_pad(images: np.ndarray, boxes: np.ndarray, target: int, ext: float = 0.0, masks=None, mask_mode: int = 0,
                     u8_float_div: bool = False):
     if images.dtype == np.uint8:

@@ -181,3 +181,39 @@ def test_ffa_and_topk_match_reference_expressions(golden_dir):
         assert (ref[i[0]] >= thr - abs(thr) * 2.0 ** -7).all()
         # canonical order: scores descending, ties by ascending index
         assert all((s[0][j] > s[0][j + 1]) or (s[0][j] == s[0][j + 1] and i[0][j] < i[0][j + 1]) for j in range(99))
+
+
+# ---- per-view fine re-rank -------------------------------------------------------------------------------
+def _rerank_case(seed=77, n_mesh=12, D=1024):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    counts = rng.integers(30, 61, size=n_mesh)
+    base = rng.standard_normal((n_mesh, D)).astype(np.float32)
+    views = [(base[i] + 0.7 * rng.standard_normal((counts[i], D))).astype(np.float32) for i in range(n_mesh)]
+    q = (base[[3, 8]] + 0.5 * rng.standard_normal((2, D))).astype(np.float32)
+    cand = np.stack([rng.permutation(n_mesh)[:8], rng.permutation(n_mesh)[:8]]).astype(np.int32)
+    return views, counts, q, cand
+
+
+def test_rerank_oracle_matches_reference_expressions():
+    """reference lines evaluated verbatim with torch/numpy on CPU (extract_proposals_ground.py:149-156) vs the oracle"""
+    import torch
+    import torch.nn.functional as F
+    views, counts, q, cand = _rerank_case()
+    qn = F.normalize(torch.from_numpy(q).to(torch.bfloat16), dim=-1)
+    ref = np.zeros(cand.shape, np.float32)
+    for qi in range(2):
+        for ci, m in enumerate(cand[qi]):
+            fine = F.normalize(torch.from_numpy(views[m]).to(torch.bfloat16), dim=-1)
+            pred = (fine @ qn[qi]).float()
+            top, _ = torch.topk(pred, 25)
+            ref[qi, ci] = top.cpu().numpy().mean().item()
+    view_bits = fo.to_bf16_bits(np.concatenate(views))
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    out = fo.rerank_views(view_bits, off, cand, fo.torch_to_bits(qn), 25)
+    assert np.abs(out - ref).max() <= 2.0 ** -8 * np.abs(ref).max()      # 1 bf16 ulp of a single view score
+    assert (out == ref).mean() >= 0.5                                    # mostly bit-identical (same numpy mean order)
+    assert (out.argmax(axis=1) == ref.argmax(axis=1)).all()
+    # the planted meshes (queries are noisy copies of meshes 3 and 8) win whenever they are among the candidates
+    for qi, m in enumerate((3, 8)):
+        if m in cand[qi]:
+            assert cand[qi][out[qi].argmax()] == m

@@ -250,3 +250,26 @@ def test_rasterizer_large_triangles_and_untextured():
     assert (rgb_o[d_o > 0] == 255).all()
     # the nearer small triangle occludes the quad at the image centre
     assert abs(d_o[0, 210, 210] - (1.1 - 0.075)) < 1e-3
+
+
+def test_rerank_views_bit_exact_and_bank_api():
+    """per-view fine re-rank (--topk 25 path): HIP kernel vs oracle bit for bit; TemplateBank.retrieve_reranked picks the
+    planted mesh and resolves ties to the first maximum in coarse order"""
+    from freepose_amd import ops
+    from freepose_amd.retrieval import TemplateBank
+    from oracle import fp_oracle as fo
+    from tests.test_golden_cpu import _rerank_case
+    for D in (1024, 384):
+        views, counts, q, cand = _rerank_case(D=D)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        view_bits = fo.to_bf16_bits(np.concatenate(views))
+        q_bits = fo.l2norm_rows(fo.to_bf16_bits(q))
+        for k in (1, 7, 25, 64):
+            o = fo.rerank_views(view_bits, off, cand, q_bits, k)
+            g = ops.rerank_views(fo.bits_to_torch(view_bits), torch.from_numpy(off), torch.from_numpy(cand), fo.bits_to_torch(q_bits), k)
+            assert np.array_equal(g.cpu().numpy().view(np.uint32), o.view(np.uint32)), (D, k)
+    views, counts, q, cand = _rerank_case()
+    bank = TemplateBank(np.stack([v.mean(axis=0) for v in views]), [f"m{i}" for i in range(len(views))])
+    bank.attach_views(views)
+    names, scores, rows, fine = bank.retrieve_reranked(ops.l2_normalize(torch.from_numpy(q).to(torch.bfloat16)), topk=25, n_coarse=12)
+    assert names == ["m3", "m8"] and fine.shape == (2, 12)

@@ -61,6 +61,8 @@ __device__ __forceinline__ float xlane_sum32(float v) {
 }
 
 __device__ __forceinline__ int key_plain(int row) { return (row >> 1) & 7; }
+// K tile rows are read in the order 32 (fk>>1) + 8 a + 4 (fk&1) + b (a = li>>2, b = li&3): key follows (a, b>>1)
+__device__ __forceinline__ int key_krow(int row) { return ((((row >> 3) & 3) << 1) | ((row >> 1) & 1)) & 7; }
 __device__ __forceinline__ int key_perm4(int row) {  // rows laid out 16a + 4f + b (a,b in 0..3)
     const int rl = row & 63;
     return (((rl >> 4) << 1) | ((rl & 3) >> 1)) & 7;
@@ -72,8 +74,18 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QB + wave * QW;
+    // XCD-aware block order (1-D grid): the q-blocks of one (crop, head) are consecutive LOGICAL ids, hence run on one
+    // XCD and share its L2 copy of that head's K / V^T (rocprofv3: 4.4x over-fetch when they were spread over 8 XCDs)
+    const int nqb = (p.npad + QB - 1) / QB;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
+    const int qb = bid % nqb, bh = bid / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const int q0 = qb * QB + wave * QW;
 
     const size_t rowbase = (size_t)b * p.npad;
     const char* gQK = (const char*)p.QK;
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
     for (int it = 0; it < 2; ++it) {
         const int row = (it * NWAVE + wave) * 8 + (lane >> 3);
         rowK[it] = row;
-        offK[it] = (uint32_t)((p.D + h * HD) * 2 + (((lane & 7) ^ key_plain(row)) << 4));
+        offK[it] = (uint32_t)((p.D + h * HD) * 2 + (((lane & 7) ^ key_krow(row)) << 4));
         slotV[it] = (lane & 7) ^ key_perm4(row);
         offV[it] = (uint32_t)row * (uint32_t)p.npad * 2u;
     }
@@ -118,10 +130,13 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
     };
 
     // ---- fragment read offsets -----------------------------------------------------------------
-    const int keyK = (li >> 1) & 7;                                // key_plain(16 f + li)
-    const int baseK = li * ROWB;                                   // + f*16*ROWB
-    const int keyV = (((li >> 2) << 1) | ((li & 3) >> 1)) & 7;     // key_perm4(row) for every f
-    const int baseV = TILE + ((li >> 2) * 16 + (li & 3)) * ROWB;   // + f*4*ROWB
+    // K fragment fk, A-row i = li  <->  tile key  32 (fk>>1) + 8 (li>>2) + 4 (fk&1) + (li&3).  With this row permutation a
+    // lane's S^T registers of fragments (2s, 2s+1) are the 8 CONSECUTIVE keys 32 s + 8 lg + j, i.e. exactly the MFMA
+    // B-operand k-order of the P^T fragment, so the matching V^T fragment is one contiguous ds_read_b128.
+    const int keyK = (((li >> 2) << 1) | ((li & 3) >> 1)) & 7;     // key_krow(row) for every fk
+    const int baseK = ((li >> 2) * 8 + (li & 3)) * ROWB;           // + (32 (fk>>1) + 4 (fk&1)) * ROWB
+    const int keyV = (((li >> 2) << 1) | ((li & 3) >> 1)) & 7;     // key_perm4(row) for every fd
+    const int baseV = TILE + ((li >> 2) * 16 + (li & 3)) * ROWB;   // + fd*4*ROWB
 
     f32x4_t o[4][2];
 #pragma unroll
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
             const int slot = (((kk << 2) | lg) ^ keyK) << 4;
 #pragma unroll
             for (int fk = 0; fk < 4; ++fk) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sb + baseK + fk * 16 * ROWB + slot);
+                const bf16x8_t kf = *(const bf16x8_t*)(sb + baseK + (32 * (fk >> 1) + 4 * (fk & 1)) * ROWB + slot);
 #pragma unroll
                 for (int fq = 0; fq < 2; ++fq)
                     s[fk][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[fq][kk], s[fk][fq], 0, 0, 0);
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
             for (int fk = 0; fk < 4; ++fk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (kv0 + 16 * fk + 4 * lg + r >= p.n_tok) {
+                    if (kv0 + 32 * (fk >> 1) + 8 * lg + 4 * (fk & 1) + r >= p.n_tok) {
                         s[fk][0][r] = -1e30f;
                         s[fk][1][r] = -1e30f;
                     }
@@ -233,19 +248,15 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
         }
 
         // ---- O^T += V^T P^T ----------------------------------------------------------------------
-        // contraction slot (lg, j) <-> key 32 ks + 16 (j>>2) + 4 lg + (j&3): two 8-byte reads per fragment
+        // contraction slot (lg, j) <-> key 32 ks + 8 lg + j: one 16-byte read per V^T fragment (slot 4 ks + lg), conflict
+        // free under the same XOR key as the GEMM's permuted-row operand.  (bf16-typed like the K reads: an integer-typed
+        // LDS load makes hipcc protect it against the in-flight LDS DMA with a vmcnt(0), draining the ring every tile.)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int s0 = ((((ks << 2) | (lg >> 1)) ^ keyV) << 4) + ((lg & 1) << 3);
-            const int s1 = ((((ks << 2) | 2 | (lg >> 1)) ^ keyV) << 4) + ((lg & 1) << 3);
+            const int sv = (((ks << 2) | lg) ^ keyV) << 4;
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) {
-                const char* rp = sb + baseV + fd * 4 * ROWB;
-                // (typed as bf16 vectors like the K reads: an integer-typed LDS load makes hipcc protect it against the
-                //  in-flight LDS DMA with a vmcnt(0), draining the ring every tile)
-                const bf16x4_t a0 = *(const bf16x4_t*)(rp + s0);
-                const bf16x4_t a1 = *(const bf16x4_t*)(rp + s1);
-                const bf16x8_t vf = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8_t vf = *(const bf16x8_t*)(sb + baseV + fd * 4 * ROWB + sv);
 #pragma unroll
                 for (int fq = 0; fq < 2; ++fq)
                     o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[fq][ks], o[fd][fq], 0, 0, 0);
@@ -290,7 +301,7 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     a.QK = QK; a.ldqk = ldqk; a.Vt = Vt; a.O = O; a.ldo = ldo;
     a.B = B; a.H = H; a.n_tok = n_tok; a.npad = npad; a.D = H * HD;
     a.scale_log2e = 1.4426950408889634f / 8.0f;
-    dim3 grid(cdiv(npad, QB), H, B);
+    dim3 grid(cdiv(npad, QB) * H * B);
     const int nslot = fp_opt_get(FP_OPT_ATTN_SLOTS, 2);   // measured: 2 >= 3 > 4 (profiles/r01_ab.md)
     if (nslot == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     else if (nslot == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(NWAVE * 64), 4 * STAGE, stream, a);

@@ -69,15 +69,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_ap_kernel(FpGemmArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const bool groupB = wm != 0;
 
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    }
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    int tile_m, tile_n;
+    fp_gemm_tile(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
 
     // ---- DMA: each wave moves 2 pieces (16 rows x 64 B) of the X slab and 2 of the W slab per step --------------
     uint32_t offX[2], offW[2];

@@ -26,6 +26,28 @@ struct FpGemmArgs {
     int heads;
 };
 
+// Tile order shared by the GEMM kernels.  blockIdx -> logical id (XCD-contiguous, bijective) -> (tile_m, tile_n) in
+// column STRIPS of 4 n-tiles swept m-major: the 32 tiles an XCD runs concurrently then cover 8 X row-panels x 4 W
+// panels, so a strip's W slabs (<= 2 MB) stay in the XCD's 4 MB L2 for the whole sweep and each X panel is fetched once
+// per strip.  (rocprofv3, fc1 with N = 4096: the plain row-major order streamed the 8 MB weight matrix once per 2
+// row-panels — FETCH_SIZE 9x the algorithmic bytes.)
+__device__ __forceinline__ void fp_gemm_tile(int block, int nblocks, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = block & 7, pos = block >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    constexpr int SW = 4;
+    const int full = tiles_n / SW, tail = tiles_n - full * SW;
+    const int in_full = full * tiles_m * SW;
+    if (id < in_full) {
+        const int strip = id / (tiles_m * SW), rem = id - strip * (tiles_m * SW);
+        tm = rem / SW;
+        tn = strip * SW + (rem - tm * SW);
+    } else {
+        const int rem = id - in_full;
+        tm = rem / tail;
+        tn = full * SW + (rem - tm * tail);
+    }
+}
+
 // Launch on `stream`. Returns FP_OK / error code (fp_last_error() has the text).
 int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream);
 // anti-phase schedule (gemm_ap.hip): 256x256 tiles only; same preconditions as fp_gemm_bf16

@@ -60,15 +60,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     const int wm = wave / WN, wn = wave % WN;
 
     // ---- XCD-aware tile order (bijective for any grid size) -----------------------------------
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    }
-    const int m0 = (bid / tiles_n) * BM;
-    const int n0 = (bid % tiles_n) * BN;
+    int tile_m, tile_n;
+    fp_gemm_tile(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tile_m, tile_n);
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
 
     // ---- per-lane DMA source offsets ------------------------------------------------------------
     uint32_t offX[IX], offW[IW];

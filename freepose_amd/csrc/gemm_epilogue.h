@@ -31,9 +31,14 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
     constexpr int TN = BN / WN / 16;
     if constexpr (!TRANS) {
         // lane owns, for each of its TM token rows, 4*TN consecutive output features
-        constexpr int RUN = 4 * TN;
-        static_assert(RUN == 16, "epilogue assumes 16 consecutive features per lane");
-        const int nb = n0 + wn * (16 * TN) + lg * RUN;
+        // (a wave's 16*TN columns are handled as NG independent groups of 64 columns, each with the permuted-row map
+        //  a*16 + 4f + b, so a lane owns 16 consecutive features per group)
+        constexpr int RUN = 16;
+        static_assert(TN % 4 == 0, "wave tile width must be a multiple of 64 columns");
+        constexpr int NG = TN / 4;
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+        const int nb = n0 + wn * (16 * TN) + grp * 64 + lg * RUN;
         if (nb < p.N) {
             float bias[RUN], gam[RUN];
             {
@@ -56,9 +61,9 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                 if (m >= p.M) continue;
                 float v[RUN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias[4 * j + r];
+                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][grp * 4 + j][r] + bias[4 * j + r];
                 size_t orow = (size_t)m;
                 if constexpr (EPI == FP_EPI_BIAS_GELU) {
 #pragma unroll
@@ -94,6 +99,7 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                 op[0] = o0;
                 op[1] = o1;
             }
+        }
         }
     } else {
         // transposed V store: lane owns, for each of its TN features, 4*TM consecutive tokens

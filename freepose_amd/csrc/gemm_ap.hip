@@ -68,6 +68,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_ap_kernel(FpGemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const bool groupB = wm != 0;
+    char* epi_stage = smem + NST * STG + wave * fp_gemm::EPI_STAGE_BYTES;   // row-coalescing slab of the epilogue
 
     int tile_m, tile_n;
     fp_gemm_tile(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tile_m, tile_n);
@@ -166,12 +167,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_ap_kernel(FpGemmArgs p) {
             slot_barrier();                  // A's last barrier pairs with B's barrier after its last L slot
         }
     }
-    fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg);
+    fp_gemm::epilogue<BM, BN, WM, WN, EPI, (VAR & 4), TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage);
 }
 
 template <int EPI, int VAR = 4>
 int launch_ap(const FpGemmArgs& a, hipStream_t stream) {
-    constexpr int SMEM = NST * STG;
+    constexpr int SMEM = NST * STG + NW * fp_gemm::EPI_STAGE_BYTES;
     auto kern = gemm_ap_kernel<EPI, VAR>;
     static bool attr_set = false;
     if (!attr_set) {

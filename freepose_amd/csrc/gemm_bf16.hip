@@ -21,7 +21,7 @@
 #include <stdlib.h>
 
 #ifndef FP_GEMM_DEFAULT_VARIANT
-#define FP_GEMM_DEFAULT_VARIANT 14
+#define FP_GEMM_DEFAULT_VARIANT 110
 #endif
 
 namespace {
@@ -58,31 +58,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    char* epi_stage = smem + 2 * STAGE + wave * fp_gemm::EPI_STAGE_BYTES;   // row-coalescing slab of the epilogue
 
-    // ---- XCD-aware tile order (bijective for any grid size) -----------------------------------
-    int tile_m, tile_n;
-    fp_gemm_tile(blockIdx.x, gridDim.x, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tile_m, tile_n);
-    const int m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
+    // ---- XCD-aware tile order (bijective for any grid size).  PERSIST: a resident grid walks the tiles t = block,
+    // block + grid, ...; the grid is a multiple of 8, so a workgroup's tiles keep its XCD under the same remap.
+    constexpr bool PERSIST = (VAR & 32) != 0;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int m0, n0;
 
     // ---- per-lane DMA source offsets ------------------------------------------------------------
     uint32_t offX[IX], offW[IW];
+    auto set_tile = [&](int t, int& tm0, int& tn0) {
+        int tile_m, tile_n;
+        fp_gemm_tile(t, ntiles, tiles_m, tiles_n, tile_m, tile_n);
+        tm0 = tile_m * BM;
+        tn0 = tile_n * BN;
 #pragma unroll
-    for (int it = 0; it < IX; ++it) {
-        const int row = (it * NW + wave) * 8 + (lane >> 3);
-        const int key = TRANS ? key_perm<TM>(row) : key_plain(row);
-        const int ks = (lane & 7) ^ key;
-        const int rg = min(m0 + row, p.M - 1);
-        offX[it] = (uint32_t)rg * (uint32_t)p.ldx * 2u + ks * 16;
-    }
+        for (int it = 0; it < IX; ++it) {
+            const int row = (it * NW + wave) * 8 + (lane >> 3);
+            const int key = TRANS ? key_perm<TM>(row) : key_plain(row);
+            const int ks = (lane & 7) ^ key;
+            const int rg = min(tm0 + row, p.M - 1);
+            offX[it] = (uint32_t)rg * (uint32_t)p.ldx * 2u + ks * 16;
+        }
 #pragma unroll
-    for (int it = 0; it < IW; ++it) {
-        const int row = (it * NW + wave) * 8 + (lane >> 3);
-        const int key = TRANS ? key_plain(row) : key_perm<TN>(row);
-        const int ks = (lane & 7) ^ key;
-        const int rg = min(n0 + row, p.N - 1);
-        offW[it] = (uint32_t)rg * (uint32_t)p.ldw * 2u + ks * 16;
-    }
+        for (int it = 0; it < IW; ++it) {
+            const int row = (it * NW + wave) * 8 + (lane >> 3);
+            const int key = TRANS ? key_plain(row) : key_perm<TN>(row);
+            const int ks = (lane & 7) ^ key;
+            const int rg = min(tn0 + row, p.N - 1);
+            offW[it] = (uint32_t)rg * (uint32_t)p.ldw * 2u + ks * 16;
+        }
+    };
+    int tile = blockIdx.x;
+    set_tile(tile, m0, n0);
     const char* gX = (const char*)p.X;
     const char* gW = (const char*)p.W;
 
@@ -114,10 +124,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     const int baseC = (TRANS ? BM * ROWB : 0) + rowC0 * ROWB;
 
     f32x4_t acc[TC][TR];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < TC; ++i)
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int j = 0; j < TR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
 
     const int nkt = p.K / BK;
     auto load_frags = [&](const char* sb, int kk, bf16x8_t (&fr)[TR], bf16x8_t (&fc)[TC]) {
@@ -138,7 +151,42 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
     };
 
-    if constexpr ((VAR & 2) == 0) {
+    if constexpr (PERSIST) {
+        // ---- persistent plain loop: the LDS buffers alternate on a step counter that runs across tiles; during the
+        // LAST k-step of a tile the first stage of the workgroup's next tile is already being fetched, so address
+        // set-up, pipeline fill and workgroup launch hide behind that step's MFMAs and the epilogue, and the
+        // epilogue's stores drain while the next tile computes.
+        static_assert((VAR & 2) == 0, "persistent form uses the plain loop");
+        const int tstride = gridDim.x;
+        int g = 0;
+        stage(0, 0);
+        for (;;) {
+            const bool has_next = tile + tstride < ntiles;
+            int m0n = 0, n0n = 0;
+            for (int kt = 0; kt < nkt; ++kt, ++g) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 1 < nkt) stage((g + 1) & 1, kt + 1);
+                else if (has_next) {
+                    set_tile(tile + tstride, m0n, n0n);
+                    stage((g + 1) & 1, 0);
+                }
+                const char* sb = smem + (g & 1) * STAGE;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8_t fr[TR], fc[TC];
+                    load_frags(sb, kk, fr, fc);
+                    mma_block(fr, fc);
+                }
+            }
+            fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage);
+            if (!has_next) return;
+            tile += tstride;
+            m0 = m0n;
+            n0 = n0n;
+            zero_acc();
+        }
+    } else if constexpr ((VAR & 2) == 0) {
         // ---- plain double-buffered loop: one barrier per K tile, fragments read right before use ----
         stage(0, 0);
         for (int kt = 0; kt < nkt; ++kt) {
@@ -191,20 +239,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         }
     }
 
-    fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg);
+    fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr int SMEM = 2 * STAGE;
+    constexpr int SMEM = 2 * STAGE + (EPI == FP_EPI_VT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         FP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
     }
-    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    if constexpr ((VAR & 32) != 0) {   // one resident workgroup per CU (128 KiB of LDS each)
+        static int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n & ~7; }();
+        tiles = tiles < ncu ? tiles : ncu;
+    }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), SMEM, stream, a);
     FP_LAUNCH_CHECK();
     return FP_OK;
@@ -214,8 +266,10 @@ template <int EPI>
 int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // big tile once the grid can fill the chip with it, else the 128x128 tile
     const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
-    // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads,
-    // 4 = polynomial erf in the GELU epilogue.  FP_GEMM_VARIANT overrides the default (A/B probing only).
+    // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads (8-wave kernels),
+    // 4 = polynomial erf in the GELU epilogue, 8 = 16-wave big tile, 16 = anti-phase kernel, 32 = persistent tile walk,
+    // 64 = streaming output stores (the last two with the 16-wave big tile).  FP_GEMM_VARIANT / fp_set_option override
+    // the default (A/B probing only).
     static int env_var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
     const int var = fp_opt_get(FP_OPT_GEMM_VARIANT, env_var);
     const bool big = tiles_big >= 192;
@@ -224,7 +278,14 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
                        : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);
     if (big && (var & 16)) return fp_gemm_bf16_ap(a, EPI, stream);   // anti-phase two-group schedule (gemm_ap.hip)
     if (big && (var & 8)) {   // experimental: 16-wave workgroup (4 waves/SIMD), 64x64 per wave, non-pipelined reads
-        if constexpr (EPI != FP_EPI_VT) return launch_cfg<256, 256, 4, 4, EPI, 4>(a, stream);
+        if constexpr (EPI != FP_EPI_VT) {
+            switch (var & (32 | 64)) {   // 32: persistent tile walk, 64: streaming (non-temporal) output stores
+                case 32: return launch_cfg<256, 256, 4, 4, EPI, 4 | 32>(a, stream);
+                case 64: return launch_cfg<256, 256, 4, 4, EPI, 4 | 64>(a, stream);
+                case 96: return launch_cfg<256, 256, 4, 4, EPI, 4 | 96>(a, stream);
+                default: return launch_cfg<256, 256, 4, 4, EPI, 4>(a, stream);
+            }
+        }
     }
     switch (var & 7) {   // measured on MI355X (profiles/): 6 is the fastest; 0 is kept as the plain baseline for A/B runs
         FP_GEMM_CASE(0)

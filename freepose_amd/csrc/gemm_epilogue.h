@@ -23,83 +23,128 @@ __device__ __forceinline__ float gelu_erf_poly(float x) {
     return 0.5f * x * (1.0f + erfv);
 }
 
+// bytes of LDS each wave needs for the row-coalescing stage of the non-transposed epilogues (16 rows x 128 B)
+constexpr int EPI_STAGE_BYTES = 2048;
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+// `stg`: this wave's private EPI_STAGE_BYTES slab of LDS (unused by the transposed epilogue).
+//
+// Non-transposed epilogues run in two phases per 16-token x 64-feature block of the wave tile:
+//   phase 1 (accumulator layout: lane = token row li, 16 consecutive features): + bias [, GELU], round to bf16, write the
+//            lane's 32 B into the slab (row li; 16-B slots XOR-swizzled with (row>>1)&7 like the operand tiles);
+//   phase 2 (row layout: 8 lanes x 16 B = one full 128-B output row, 8 rows per instruction): read back, apply
+//            LayerScale+residual / position embedding with equally coalesced loads, store.
+// Full rows are what allows STREAMING stores (VAR bit 64, used by the big-tile kernels whose outputs are far larger than
+// L2 + MALL): measured (profiles/r01_ab.md) the write-back tail of plain stores cost 10-25 % of each GEMM — every tile
+// round dirties the whole L2 and the next round stalls on its eviction — while non-temporal full-line stores bring the
+// bias-only GEMM to the vendor library's epilogue-free time.  From the accumulator layout (16 lines per 16-lane pass)
+// streaming stores would be partial-line writes.
 template <int BM, int BN, int WM, int WN, int EPI, int VAR, int TC, int TR>
 __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC][TR], int m0, int n0, int wm, int wn,
-                                         int li, int lg) {
+                                         int li, int lg, char* stg) {
     constexpr bool TRANS = (EPI == FP_EPI_VT);
     constexpr int TM = BM / WM / 16;
     constexpr int TN = BN / WN / 16;
     if constexpr (!TRANS) {
-        // lane owns, for each of its TM token rows, 4*TN consecutive output features
-        // (a wave's 16*TN columns are handled as NG independent groups of 64 columns, each with the permuted-row map
-        //  a*16 + 4f + b, so a lane owns 16 consecutive features per group)
-        constexpr int RUN = 16;
         static_assert(TN % 4 == 0, "wave tile width must be a multiple of 64 columns");
         constexpr int NG = TN / 4;
+        const int lane = lg * 16 + li;
+        const int prow = lane >> 3, pslot = lane & 7;           // phase-2 role: row inside an 8-row half, 16-B column chunk
+        char* wr = stg + li * 128;
+        const int wkey = (li >> 1) & 7;
+        const int mbase = m0 + wm * (16 * TM);
 #pragma unroll
         for (int grp = 0; grp < NG; ++grp) {
-        const int nb = n0 + wn * (16 * TN) + grp * 64 + lg * RUN;
-        if (nb < p.N) {
-            float bias[RUN], gam[RUN];
-            {
-                const uint4* bp = (const uint4*)(p.bias + nb);
-                uint4 b0 = bp[0], b1 = bp[1];
-                const uint32_t w[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const int nbw = n0 + wn * (16 * TN) + grp * 64;     // the wave's 64-feature group
+            const int nb1 = nbw + lg * 16;                      // phase-1 features of this lane
+            const int nb2 = nbw + pslot * 8;                    // phase-2 features of this lane
+            // bias / LayerScale stay packed (bf16 pairs) and are unpacked at use: the 16-wave kernels run at 128 VGPRs
+            uint32_t biasw[8], gamw[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { bias[2 * e] = lo_bf(w[e]); bias[2 * e + 1] = hi_bf(w[e]); }
+            for (int e = 0; e < 8; ++e) biasw[e] = 0u;
+            if (nb1 < p.N) {
+                const uint4* bp = (const uint4*)(p.bias + nb1);
+                const uint4 b0 = bp[0], b1 = bp[1];
+                biasw[0] = b0.x; biasw[1] = b0.y; biasw[2] = b0.z; biasw[3] = b0.w;
+                biasw[4] = b1.x; biasw[5] = b1.y; biasw[6] = b1.z; biasw[7] = b1.w;
             }
-            if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
-                const uint4* gp = (const uint4*)(p.gamma + nb);
-                uint4 g0 = gp[0], g1 = gp[1];
-                const uint32_t w[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            // LayerScale+residual: the residual rows of block i+1 are requested (row layout, 16 B per lane) before block i
+            // is processed, so their HBM latency overlaps a whole block instead of sitting between an LDS read and its store
+            uint4 res[2][2];
+            auto load_res = [&](int i, uint4 (&r)[2]) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { gam[2 * e] = lo_bf(w[e]); gam[2 * e + 1] = hi_bf(w[e]); }
+                for (int h = 0; h < 2; ++h) {
+                    const int m = min(mbase + 16 * i + h * 8 + prow, p.M - 1);
+                    r[h] = *(const uint4*)(p.resid + (size_t)m * p.ldr + min(nb2, p.N - 8));
+                }
+            };
+            if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
+                const uint4 g0 = *(const uint4*)(p.gamma + min(nb2, p.N - 8));
+                gamw[0] = g0.x; gamw[1] = g0.y; gamw[2] = g0.z; gamw[3] = g0.w;
+                load_res(0, res[0]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wm * (16 * TM) + 16 * i + li;
-                if (m >= p.M) continue;
-                float v[RUN];
+                if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
+                    if (i + 1 < TM) load_res(i + 1, res[(i + 1) & 1]);
+                }
+                // ---- phase 1 ----------------------------------------------------------------------------------------
+                float v[16];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][grp * 4 + j][r] + bias[4 * j + r];
-                size_t orow = (size_t)m;
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t bw = biasw[2 * j + (r >> 1)];
+                        v[4 * j + r] = acc[i][grp * 4 + j][r] + ((r & 1) ? hi_bf(bw) : lo_bf(bw));
+                    }
                 if constexpr (EPI == FP_EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int e = 0; e < RUN; ++e) v[e] = (VAR & 4) ? gelu_erf_poly(rbf(v[e])) : gelu_erf(rbf(v[e]));
-                } else if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
-                    const uint4* rp = (const uint4*)(p.resid + (size_t)m * p.ldr + nb);
-                    uint4 r0 = rp[0], r1 = rp[1];
-                    const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        // reference rounding points: linear out -> bf16, *gamma -> bf16, +resid -> bf16
-                        v[2 * e] = lo_bf(w[e]) + rbf(gam[2 * e] * rbf(v[2 * e]));
-                        v[2 * e + 1] = hi_bf(w[e]) + rbf(gam[2 * e + 1] * rbf(v[2 * e + 1]));
-                    }
-                } else if constexpr (EPI == FP_EPI_PATCH) {
-                    const int b = m / p.P, pp = m - b * p.P;
-                    orow = (size_t)b * p.npad + p.tok_off + pp;
-                    const uint4* pp4 = (const uint4*)(p.pos + (size_t)pp * p.N + nb);
-                    uint4 q0 = pp4[0], q1 = pp4[1];
-                    const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        v[2 * e] = rbf(v[2 * e]) + lo_bf(w[e]);
-                        v[2 * e + 1] = rbf(v[2 * e + 1]) + hi_bf(w[e]);
-                    }
+                    for (int e = 0; e < 16; ++e) v[e] = (VAR & 4) ? gelu_erf_poly(rbf(v[e])) : gelu_erf(rbf(v[e]));
                 }
-                uint4 o0, o1;
-                o0.x = pack_bf2(v[0], v[1]);   o0.y = pack_bf2(v[2], v[3]);
-                o0.z = pack_bf2(v[4], v[5]);   o0.w = pack_bf2(v[6], v[7]);
-                o1.x = pack_bf2(v[8], v[9]);   o1.y = pack_bf2(v[10], v[11]);
-                o1.z = pack_bf2(v[12], v[13]); o1.w = pack_bf2(v[14], v[15]);
-                uint4* op = (uint4*)(p.C + orow * p.ldc + nb);
-                op[0] = o0;
-                op[1] = o1;
+                u32x4_t w0, w1;                                  // bf16 rounding point of the linear layer (/ GELU) output
+                w0.x = pack_bf2(v[0], v[1]);   w0.y = pack_bf2(v[2], v[3]);
+                w0.z = pack_bf2(v[4], v[5]);   w0.w = pack_bf2(v[6], v[7]);
+                w1.x = pack_bf2(v[8], v[9]);   w1.y = pack_bf2(v[10], v[11]);
+                w1.z = pack_bf2(v[12], v[13]); w1.w = pack_bf2(v[14], v[15]);
+                *(bf16x8_t*)(wr + (((2 * lg) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w0);
+                *(bf16x8_t*)(wr + (((2 * lg + 1) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w1);
+                // ---- phase 2 (DS operations of one wave execute in issue order: no barrier) ---------------------------
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = h * 8 + prow;
+                    const u32x4_t t = __builtin_bit_cast(
+                        u32x4_t, *(const bf16x8_t*)(stg + r * 128 + ((pslot ^ ((r >> 1) & 7)) << 4)));
+                    const int m = mbase + 16 * i + r;
+                    if (m >= p.M || nb2 >= p.N) continue;
+                    size_t orow = (size_t)m;
+                    u32x4_t o = t;
+                    if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
+                        const uint4 rr = res[i & 1][h];
+                        const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+                        const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+                        uint32_t ow[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)   // reference rounding points: linear -> bf16, *gamma -> bf16, +resid -> bf16
+                            ow[e] = pack_bf2(lo_bf(rw[e]) + rbf(lo_bf(gamw[e]) * lo_bf(tw[e])),
+                                             hi_bf(rw[e]) + rbf(hi_bf(gamw[e]) * hi_bf(tw[e])));
+                        o = u32x4_t{ow[0], ow[1], ow[2], ow[3]};
+                    } else if constexpr (EPI == FP_EPI_PATCH) {
+                        const int b = m / p.P, pp = m - b * p.P;
+                        orow = (size_t)b * p.npad + p.tok_off + pp;
+                        const uint4 q = *(const uint4*)(p.pos + (size_t)pp * p.N + nb2);
+                        const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+                        const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
+                        uint32_t ow[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            ow[e] = pack_bf2(lo_bf(tw[e]) + lo_bf(qw[e]), hi_bf(tw[e]) + hi_bf(qw[e]));
+                        o = u32x4_t{ow[0], ow[1], ow[2], ow[3]};
+                    }
+                    if constexpr ((VAR & 64) != 0) __builtin_nontemporal_store(o, (u32x4_t*)(p.C + orow * p.ldc + nb2));
+                    else *(u32x4_t*)(p.C + orow * p.ldc + nb2) = o;
+                }
             }
-        }
         }
     } else {
         // transposed V store: lane owns, for each of its TN features, 4*TM consecutive tokens

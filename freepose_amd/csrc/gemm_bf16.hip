@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
 template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr int SMEM = 2 * STAGE + (EPI == FP_EPI_VT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
+    constexpr int SMEM = 2 * STAGE + WM * WN * fp_gemm::EPI_STAGE_BYTES;
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -278,7 +278,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
                        : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);
     if (big && (var & 16)) return fp_gemm_bf16_ap(a, EPI, stream);   // anti-phase two-group schedule (gemm_ap.hip)
     if (big && (var & 8)) {   // experimental: 16-wave workgroup (4 waves/SIMD), 64x64 per wave, non-pipelined reads
-        if constexpr (EPI != FP_EPI_VT) {
+        {
             switch (var & (32 | 64)) {   // 32: persistent tile walk, 64: streaming (non-temporal) output stores
                 case 32: return launch_cfg<256, 256, 4, 4, EPI, 4 | 32>(a, stream);
                 case 64: return launch_cfg<256, 256, 4, 4, EPI, 4 | 64>(a, stream);

@@ -146,8 +146,47 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                 }
             }
         }
+    } else if constexpr (TM == 4) {
+        // transposed V store, staged like the row-major epilogues with the roles swapped: a block is 16 FEATURES (rows,
+        // lane li) x 64 TOKENS (lane lg owns 16 consecutive ones); phase 2 writes one full 128-B line of Vt[b,h,d,:]
+        // (64 tokens of one feature) per 8 lanes.  Blocks never straddle a crop: npad and the tile origin are
+        // multiples of 16 and a lane's 8-token chunk is 8-aligned.
+        const int lane = lg * 16 + li;
+        const int prow = lane >> 3, pslot = lane & 7;
+        char* wr = stg + li * 128;
+        const int wkey = (li >> 1) & 7;
+        const int m2 = m0 + wm * (16 * TM) + pslot * 8;        // phase-2 tokens of this lane (first of 8)
+        const int b2 = m2 / p.npad, t2 = m2 - b2 * p.npad;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n1 = n0 + wn * (16 * TN) + 16 * i + li;
+            const float bias = (p.bias && n1 < p.N) ? bf2f(p.bias[n1]) : 0.f;
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias;
+            u32x4_t w0, w1;
+            w0.x = pack_bf2(v[0], v[1]);   w0.y = pack_bf2(v[2], v[3]);
+            w0.z = pack_bf2(v[4], v[5]);   w0.w = pack_bf2(v[6], v[7]);
+            w1.x = pack_bf2(v[8], v[9]);   w1.y = pack_bf2(v[10], v[11]);
+            w1.z = pack_bf2(v[12], v[13]); w1.w = pack_bf2(v[14], v[15]);
+            *(bf16x8_t*)(wr + (((2 * lg) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w0);
+            *(bf16x8_t*)(wr + (((2 * lg + 1) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = h * 8 + prow;
+                const u32x4_t t = __builtin_bit_cast(
+                    u32x4_t, *(const bf16x8_t*)(stg + r * 128 + ((pslot ^ ((r >> 1) & 7)) << 4)));
+                const int n = n0 + wn * (16 * TN) + 16 * i + r;
+                if (n >= p.N || m2 >= p.M) continue;
+                u32x4_t* op = (u32x4_t*)(p.C + (((size_t)b2 * p.heads + (n >> 6)) * 64 + (n & 63)) * p.npad + t2);
+                if constexpr ((VAR & 64) != 0) __builtin_nontemporal_store(t, op);
+                else *op = t;
+            }
+        }
     } else {
-        // transposed V store: lane owns, for each of its TN features, 4*TM consecutive tokens
+        // transposed V store (direct form, wave tiles taller than 64 tokens): lane owns, for each of its TN features, 4*TM consecutive tokens
         constexpr int RUN = 4 * TM;
         static_assert(RUN % 16 == 0, "token runs are stored in 16-token groups");
 #pragma unroll

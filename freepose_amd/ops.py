@@ -356,13 +356,14 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epi: int = 0, gam
     return out
 
 
-def gemm_vt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, npad: int, heads: int) -> torch.Tensor:
+def gemm_vt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, npad: int, heads: int,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     x, w, bias = _dev(x, torch.bfloat16), _dev(w, torch.bfloat16), _dev(bias, torch.bfloat16)
     M, K = x.shape
     N = w.shape[0]
     B = M // npad
-    vt = torch.zeros((B, heads, 64, npad), dtype=torch.bfloat16, device=x.device)
+    vt = out if out is not None else torch.zeros((B, heads, 64, npad), dtype=torch.bfloat16, device=x.device)
     check(lib.fp_op_gemm_vt(ptr(x), K, ptr(w), K, ptr(vt), ptr(bias), M, N, K, npad, heads, current_stream()), "fp_op_gemm_vt")
     return vt
 

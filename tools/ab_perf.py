@@ -49,6 +49,13 @@ def main():
         o = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         ab(f"gemm N={N} K={K} epi={epi}", gemm_variants, lambda v: ops.set_option("gemm_variant", v),
            lambda: ops.gemm(x, w, b, epi, gamma=g, resid=r, out=o), 2.0 * M * N * K)
+    if True:   # V projection with the transposed per-head store
+        x = torch.randn(M, 1024, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(1024, 1024, device="cuda") * 0.02).to(torch.bfloat16)
+        b = torch.zeros(1024, device="cuda").to(torch.bfloat16)
+        vt = torch.empty(64, 16, 64, 1376, device="cuda", dtype=torch.bfloat16)
+        ab("gemm_vt N=1024 K=1024", gemm_variants, lambda v: ops.set_option("gemm_variant", v),
+           lambda: ops.gemm_vt(x, w, b, 1376, 16, out=vt), 2.0 * M * 1024 * 1024)
     for (B, n_tok) in ([] if only_gemm else [(64, 1374), (64, 905)]):
         npad = (n_tok + 15) // 16 * 16
         qk = torch.randn(B * npad, 2048, device="cuda").to(torch.bfloat16)

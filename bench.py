@@ -27,6 +27,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # HBM3E, same guide
 
 
 def icosphere(sub: int):
@@ -145,7 +146,7 @@ def main():
     args = ap.parse_args()
 
     from freepose_amd import ops, parallel
-    from freepose_amd.pipeline import HotPath, pack_results
+    from freepose_amd.pipeline import HotPath, StageClock, pack_results
     from freepose_amd.retrieval import TemplateBank
     import torch.distributed as dist
 
@@ -174,6 +175,7 @@ def main():
     if world > 1:
         dist.barrier()
     vit.profile(True)
+    hp.clock = StageClock()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -184,6 +186,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = vit.profile_read()
     vit.profile(False)
+    stage_ms = hp.clock.read()
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -211,6 +214,7 @@ def main():
             "stage_ms_rank0": {"vit_gemm": prof["ms_gemm"] / args.steps, "vit_attention": prof["ms_attn"] / args.steps,
                                "vit_other": prof["ms_other"] / args.steps},
             "vit_tflops_end_to_end": flops_vit / dt / 1e12,
+            "stages_rank0": stage_table(args, prof, stage_ms, n_tri=len(mf), n_vert=len(mv), n_prop=B * args.steps),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, (mv, mf, mc), bank_f32)
@@ -220,6 +224,40 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
+    """per-stage time (HIP events, rank 0, summed over the timed steps) with the ALGORITHMIC work of SURVEY.md §8(d) and
+    the fraction of the roofline that bounds the stage"""
+    g = args.res // 14
+    P, n_tok, D, H = g * g, g * g + 5, 1024, args.hyp
+    crops = (1 + H) * n_prop
+    rows = []
+
+    def add(name, ms, bound, work, note=""):
+        if ms <= 0:
+            return
+        if bound == "mfma":
+            ach, peak, unit = work / ms / 1e9, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = work / ms / 1e6, HBM_PEAK_GBS, "GB/s"
+        rows.append({"stage": name, "ms": ms, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                     "frac": ach / peak, "work": work, "note": note})
+
+    add("vit_linear_layers", prof["ms_gemm"], "mfma", prof["gemm_flops"], "22 x (qk, v, proj, fc1, fc2) + patch embed")
+    add("vit_attention", prof["ms_attn"], "mfma", 22 * 4.0 * n_tok * n_tok * D * crops, "4 n^2 D flops per block per crop")
+    add("vit_layernorm_etc", prof["ms_other"], "hbm", (22 * 2 + 1) * 2.0 * n_tok * D * 2 * crops + 3.0 * 518 * 518 * 2 * crops,
+        "LayerNorm read+write per call, im2col, token init")
+    add("ffa", stage_ms.get("ffa", 0), "hbm", P * D * 2.0 * n_prop, "P*D*2 bytes per crop")
+    add("bank_scan_topk", stage_ms.get("bank_scan_topk", 0), "hbm", args.bank * D * 2.0 * args.steps,
+        f"one pass over the bf16 bank per step, shared by its Q = {args.proposals_per_step} queries")
+    add("rasterize", stage_ms.get("rasterize", 0), "hbm", (H * 420 * 420 * 7.0 + n_vert * 32.0 + n_tri * 12.0) * n_prop,
+        f"mandatory rgb+depth writes; {H * n_tri * n_prop / max(stage_ms.get('rasterize', 1e9), 1e-9) / 1e6:.1f} G triangle set-ups/s")
+    add("depth_extents", stage_ms.get("depth_extents", 0), "hbm", H * 420 * 420 * 4.0 * n_prop, "depth read")
+    add("crop_resize", stage_ms.get("crop_resize", 0), "hbm", H * 3.0 * args.res * args.res * 2 * n_prop, "bf16 crop writes (reads are a subset of the renders)")
+    add("template_score", stage_ms.get("template_score", 0), "hbm", H * P * D * 2.0 * n_prop, "T*P*D*2 bytes")
+    add("hypothesis_top3", stage_ms.get("hypothesis_top3", 0), "hbm", H * 8.0 * n_prop, "latency-bound (576 scores)")
+    return rows
 
 
 def _pmc_traffic():

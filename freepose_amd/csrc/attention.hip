@@ -23,6 +23,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
 constexpr int HD = 64;      // head dim
 constexpr int KVB = 64;     // keys per tile
 constexpr int QW = 32;      // queries per wave
@@ -31,6 +33,7 @@ constexpr int QB = QW * NWAVE;
 constexpr int ROWB = 128;   // bytes per LDS row (64 bf16)
 constexpr int TILE = KVB * ROWB;          // 8 KiB (K tile) == 64 d-rows * 128 B (V^T tile)
 constexpr int STAGE = 2 * TILE;
+constexpr float LAZY_THR = 40.0f;   // logits; 40 * log2(e)/8 = 7.2 -> probabilities stay below 2^8 between rescales
 
 struct AttnArgs {
     const bf16_t* QK; int ldqk;  // elements
@@ -51,15 +54,6 @@ __device__ __forceinline__ float xlane_max32(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
-__device__ __forceinline__ float xlane_sum16(float v) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xlane_sum32(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 __device__ __forceinline__ int key_plain(int row) { return (row >> 1) & 7; }
 // K tile rows are read in the order 32 (fk>>1) + 8 a + 4 (fk&1) + b (a = li>>2, b = li&3): key follows (a, b>>1)
 __device__ __forceinline__ int key_krow(int row) { return ((((row >> 3) & 3) << 1) | ((row >> 1) & 1)) & 7; }
@@ -69,7 +63,7 @@ __device__ __forceinline__ int key_perm4(int row) {  // rows laid out 16a + 4f +
 }
 
 template <int NSLOT>  // LDS ring depth: NSLOT-1 K/V tiles in flight (16 KiB per slot)
-__global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {   // 3 waves/SIMD: <= 168 VGPRs
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,18 +109,37 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
         slotV[it] = (lane & 7) ^ key_perm4(row);
         offV[it] = (uint32_t)row * (uint32_t)p.npad * 2u;
     }
+    // running per-lane source pointers (advanced by one tile per call); only a tile that can reach past the crop's npad
+    // rows takes the clamped path (keys >= n_tok are masked anyway, the clamp just keeps the reads inside the buffers)
+    const char* kp[2];
+    const char* vp[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        kp[it] = gQK + (rowbase + rowK[it]) * (size_t)p.ldqk * 2 + offK[it];
+        vp[it] = gVt + offV[it] + (size_t)(slotV[it] * 8) * 2;
+    }
+    const size_t kstep = (size_t)KVB * p.ldqk * 2;
     auto stage = [&](int buf, int kv0) {
         char* sb = smem + buf * STAGE;
+        if (kv0 + KVB <= p.npad) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int key = min(kv0 + rowK[it], p.npad - 1);
-            glds16(gQK + (rowbase + key) * (size_t)p.ldqk * 2 + offK[it], sb + (it * NWAVE + wave) * 1024);
+            for (int it = 0; it < 2; ++it) glds16(kp[it], sb + (it * NWAVE + wave) * 1024);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) glds16(vp[it], sb + TILE + (it * NWAVE + wave) * 1024);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int key = min(kv0 + rowK[it], p.npad - 1);
+                glds16(gQK + (rowbase + key) * (size_t)p.ldqk * 2 + offK[it], sb + (it * NWAVE + wave) * 1024);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int k8 = min(kv0 + slotV[it] * 8, p.npad - 8);
+                glds16(gVt + offV[it] + (size_t)k8 * 2, sb + TILE + (it * NWAVE + wave) * 1024);
+            }
         }
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int k8 = min(kv0 + slotV[it] * 8, p.npad - 8);
-            glds16(gVt + offV[it] + (size_t)k8 * 2, sb + TILE + (it * NWAVE + wave) * 1024);
-        }
+        for (int it = 0; it < 2; ++it) { kp[it] += kstep; vp[it] += KVB * 2; }
     };
 
     // ---- fragment read offsets -----------------------------------------------------------------
@@ -144,7 +157,10 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float mrow[2] = {-1e30f, -1e30f};
-    float lsum[2] = {0.f, 0.f};
+    f32x4_t lacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};   // [0]: running sum of P per query
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     // 3-slot LDS ring, two K/V tiles in flight: each wave issues 4 DMA instructions per tile, so `vmcnt(4)` means
     // "tile t has landed, tile t+1 may still be in flight".  Raw s_barrier (a __syncthreads() would drain vmcnt to 0).
@@ -205,10 +221,28 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
                     }
         }
 
-        // ---- online softmax (per query column; 4 lanes lg=0..3 share a query) --------------------
-        bf16x8_t pf[2][2];  // [fq][ks]  B-operand fragments of P^T
+        // ---- V^T fragments of the whole tile: issued now, their LDS latency hides behind the first softmax -----------
+        // contraction slot (lg, j) <-> key 32 ks + 8 lg + j: one 16-byte read per fragment (slot 4 ks + lg), conflict free
+        // under the same XOR key as the GEMM's permuted-row operand.  (bf16-typed like the K reads: an integer-typed LDS
+        // load makes hipcc protect it against the in-flight LDS DMA with a vmcnt(0), draining the ring every tile.)
+        bf16x8_t vf[2][4];
 #pragma unroll
-        for (int fq = 0; fq < 2; ++fq) {
+        for (int ks = 0; ks < 2; ++ks) {
+            const int sv = (((ks << 2) | lg) ^ keyV) << 4;
+#pragma unroll
+            for (int fd = 0; fd < 4; ++fd) vf[ks][fd] = *(const bf16x8_t*)(sb + baseV + fd * 4 * ROWB + sv);
+        }
+
+        // ---- online softmax of one 16-query half (per query column; 4 lanes lg=0..3 share a query) ---------------------
+        // Issue slots are the bound here (one VALU-class instruction per SIMD per 4 clocks, MFMA included), so:
+        //  * the running maximum is LAZY: it is raised (and O, l rescaled) only when some query of the wave exceeds its
+        //    reference by more than LAZY_THR logits; until then probabilities are taken against the old reference and may
+        //    reach 2^8 — harmless in fp32 accumulators and in bf16 P (same relative precision), and the common case skips
+        //    the exp / 18 multiplies of the rescale;
+        //  * the row sums come from the matrix pipe: a fifth "V^T" fragment of ones accumulates sum_k P[k,q] (over all
+        //    four lanes' keys at once) in lacc, replacing 16 packed adds and the cross-lane reduction at the end.
+        bf16x8_t pf[2][2];  // [fq][ks]  B-operand fragments of P^T
+        auto softmax_max = [&](int fq) {
             float mx = s[0][fq][0];
 #pragma unroll
             for (int fk = 0; fk < 4; ++fk)
@@ -217,25 +251,33 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
             // the 4 lanes sharing a query differ in lane bits 4 and 5: VALU row/half swaps, not ds_bpermute
             mx = xlane_max16(mx);
             mx = xlane_max32(mx);
-            const float mnew = fmaxf(mrow[fq], mx);
-            // raw v_exp_f32 (results below 2^-126 flush to 0, which is what a masked / negligible weight should be)
-            const float alpha = __builtin_amdgcn_exp2f((mrow[fq] - mnew) * p.scale_log2e);
-            mrow[fq] = mnew;
-            const float mb = mnew * p.scale_log2e;
-            float rs = 0.f;
+            if (__builtin_amdgcn_ballot_w64(mx > mrow[fq] + LAZY_THR) != 0) {   // wave-uniform
+                const float mnew = fmaxf(mrow[fq], mx);
+                // raw v_exp_f32 (results below 2^-126 flush to 0, which is what a masked / negligible weight should be)
+                const float alpha = __builtin_amdgcn_exp2f((mrow[fq] - mnew) * p.scale_log2e);
+                mrow[fq] = mnew;
+                lacc[fq][0] *= alpha;
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[fd][fq][r] *= alpha;
+            }
+        };
+        auto softmax_exp = [&](int fq) {
+            const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e};
+            const float nmb = -(mrow[fq] * p.scale_log2e);
+            const f32x2_t mb2 = {nmb, nmb};
             float pv[4][4];
 #pragma unroll
             for (int fk = 0; fk < 4; ++fk)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pv[fk][r] = __builtin_amdgcn_exp2f(fmaf(s[fk][fq][r], p.scale_log2e, -mb));
-                    rs += pv[fk][r];
+                for (int r = 0; r < 4; r += 2) {
+                    // two elements per v_pk_fma_f32 (each lane of it is an ordinary fused multiply-add)
+                    const f32x2_t a = {s[fk][fq][r], s[fk][fq][r + 1]};
+                    const f32x2_t e = __builtin_elementwise_fma(a, sc2, mb2);
+                    pv[fk][r] = __builtin_amdgcn_exp2f(e[0]);
+                    pv[fk][r + 1] = __builtin_amdgcn_exp2f(e[1]);
                 }
-            lsum[fq] = lsum[fq] * alpha + rs;
-#pragma unroll
-            for (int fd = 0; fd < 4; ++fd)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[fd][fq][r] *= alpha;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 w;
@@ -245,32 +287,39 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_fwd_kernel(AttnArgs p) {
                 w.w = pack_bf2(pv[2 * ks + 1][2], pv[2 * ks + 1][3]);
                 pf[fq][ks] = __builtin_bit_cast(bf16x8_t, w);
             }
-        }
-
-        // ---- O^T += V^T P^T ----------------------------------------------------------------------
-        // contraction slot (lg, j) <-> key 32 ks + 8 lg + j: one 16-byte read per V^T fragment (slot 4 ks + lg), conflict
-        // free under the same XOR key as the GEMM's permuted-row operand.  (bf16-typed like the K reads: an integer-typed
-        // LDS load makes hipcc protect it against the in-flight LDS DMA with a vmcnt(0), draining the ring every tile.)
+        };
+        // ---- O^T += V^T P^T (and l += 1^T P^T) for one half ------------------------------------------------------------
+        auto pv_half = [&](int fq) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int sv = (((ks << 2) | lg) ^ keyV) << 4;
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int fd = 0; fd < 4; ++fd) {
-                const bf16x8_t vf = *(const bf16x8_t*)(sb + baseV + fd * 4 * ROWB + sv);
-#pragma unroll
-                for (int fq = 0; fq < 2; ++fq)
-                    o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[fq][ks], o[fd][fq], 0, 0, 0);
+                for (int fd = 0; fd < 4; ++fd)
+                    o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks][fd], pf[fq][ks], o[fd][fq], 0, 0, 0);
+                lacc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[fq][ks], lacc[fq], 0, 0, 0);
             }
+        };
+
+        softmax_max(0);
+        softmax_exp(0);
+        softmax_max(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // half 0's ten MFMAs go to the matrix pipe one at a time between slices of half 1's exp / convert work, so the
+        // wave overlaps the two pipes by itself instead of relying on the other waves of the SIMD being out of phase
+        softmax_exp(1);
+        pv_half(0);
+#pragma unroll
+        for (int g = 0; g < 10; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU
         }
+        __builtin_amdgcn_sched_barrier(0);
+        pv_half(1);
     }
 
     // ---- normalise and store: lane owns 16 consecutive d (= 16 lg + 4 fd + r) of query li ---------
 #pragma unroll
     for (int fq = 0; fq < 2; ++fq) {
-        float l = lsum[fq];
-        l = xlane_sum16(l);
-        l = xlane_sum32(l);
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / lacc[fq][0];   // D-row 4 lg of the ones product: the full row sum on every lane
         const int q = q0 + 16 * fq + li;
         if (q < p.npad) {
             uint4 w0, w1;

@@ -1,0 +1,119 @@
+// Measured peaks on the box the bench runs on ("re-measure a peak-GEMM microbench on the box and quote
+// both"; "quote measured hipMemcpyDtoD / stream-triad too").  Standalone development probe, not part of the library:
+//   hipcc --offload-arch=gfx950 -O3 tools/peaks_probe.hip -o /tmp/peaks_probe && /tmp/peaks_probe
+// Prints one JSON object.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// ---- MFMA issue peak: 8 independent accumulators per wave, operands live in registers, no memory traffic ----------
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, float seed) {
+    bf16x8_t a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                       // non-trivial data: power (and so the clock) depends on the values
+        a[e] = (__bf16)(seed * (float)((threadIdx.x * 7 + e * 13) % 31 - 15) * 0.03f);
+        b[e] = (__bf16)(seed * (float)((threadIdx.x * 5 + e * 11) % 29 - 14) * 0.02f);
+    }
+    f32x4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123456.789f) out[0] = s;                   // keep the loop alive
+}
+
+// ---- HBM: 16 B per lane, grid-stride -----------------------------------------------------------------------------
+template <int MODE>   // 0 copy, 1 copy with streaming stores, 2 triad a = b + s*c, 3 read-only sum
+__global__ __launch_bounds__(256) void stream_kernel(const u32x4_t* __restrict__ b, const u32x4_t* __restrict__ c,
+                                                     u32x4_t* __restrict__ a, size_t n, float s, float* sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (; i < n; i += stride) {
+        u32x4_t v = b[i];
+        if (MODE == 0) a[i] = v;
+        else if (MODE == 1) __builtin_nontemporal_store(v, a + i);
+        else if (MODE == 2) {
+            const u32x4_t w = c[i];
+            u32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __float_as_uint(__uint_as_float(v[e]) + s * __uint_as_float(w[e]));
+            a[i] = o;
+        } else acc += __uint_as_float(v[0]) + __uint_as_float(v[1]) + __uint_as_float(v[2]) + __uint_as_float(v[3]);
+    }
+    if (MODE == 3 && acc == 123456.789f) sink[0] = acc;
+}
+
+template <class F>
+static float time_ms(F&& f, int reps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    f();
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        hipEventRecord(e0, 0);
+        f();
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return best;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    float* sink;
+    CK(hipMalloc(&sink, 64));
+
+    // MFMA: 8 waves per CU-workgroup x 4 workgroups per CU
+    const int iters = 20000, wgs = ncu * 4;
+    const float ms_mfma = time_ms([&] { hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, 0, sink, iters, 1.0f); }, 5);
+    const double mfma_tf = (double)wgs * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 32) / (ms_mfma * 1e-3) / 1e12;
+
+    const size_t bytes = (size_t)2 << 30, n = bytes / 16;
+    u32x4_t *A, *B, *Cc;
+    CK(hipMalloc(&A, bytes));
+    CK(hipMalloc(&B, bytes));
+    CK(hipMalloc(&Cc, bytes));
+    CK(hipMemset(B, 0x3c, bytes));
+    CK(hipMemset(Cc, 0x3d, bytes));
+    const int grid = ncu * 16;
+    const float ms_copy = time_ms([&] { hipLaunchKernelGGL(stream_kernel<0>, dim3(grid), dim3(256), 0, 0, B, Cc, A, n, 0.f, sink); }, 5);
+    const float ms_copy_nt = time_ms([&] { hipLaunchKernelGGL(stream_kernel<1>, dim3(grid), dim3(256), 0, 0, B, Cc, A, n, 0.f, sink); }, 5);
+    const float ms_triad = time_ms([&] { hipLaunchKernelGGL(stream_kernel<2>, dim3(grid), dim3(256), 0, 0, B, Cc, A, n, 0.5f, sink); }, 5);
+    const float ms_read = time_ms([&] { hipLaunchKernelGGL(stream_kernel<3>, dim3(grid), dim3(256), 0, 0, B, Cc, A, n, 0.f, sink); }, 5);
+    const float ms_d2d = time_ms([&] { hipMemcpyAsync(A, B, bytes, hipMemcpyDeviceToDevice, 0); }, 5);
+    // 94 MB read (the bank scan's pass size): below the 256 MB MALL, so a repeated pass can be served from it
+    const size_t nb = (size_t)94283776 / 16;
+    const float ms_read_bank = time_ms([&] { hipLaunchKernelGGL(stream_kernel<3>, dim3(grid), dim3(256), 0, 0, B, Cc, A, nb, 0.f, sink); }, 5);
+
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, "
+           "\"mfma_bf16_16x16x32_issue_peak_tflops\": %.1f, "
+           "\"hbm_copy_gbs\": %.0f, \"hbm_copy_streaming_store_gbs\": %.0f, \"hbm_triad_gbs\": %.0f, \"hbm_read_gbs\": %.0f, "
+           "\"hipMemcpyDtoD_gbs\": %.0f, \"read_94MB_repeated_gbs\": %.0f, \"buffer_bytes\": %zu}\n",
+           prop.name, ncu, prop.clockRate / 1000, mfma_tf, 2.0 * bytes / ms_copy / 1e6, 2.0 * bytes / ms_copy_nt / 1e6,
+           3.0 * bytes / ms_triad / 1e6, 1.0 * bytes / ms_read / 1e6, 2.0 * bytes / ms_d2d / 1e6,
+           94283776.0 / ms_read_bank / 1e6, bytes);
+    return 0;
+}

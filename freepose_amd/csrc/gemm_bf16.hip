@@ -268,7 +268,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
     // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads (8-wave kernels),
     // 4 = polynomial erf in the GELU epilogue, 8 = 16-wave big tile, 16 = anti-phase kernel, 32 = persistent tile walk,
-    // 64 = streaming output stores (the last two with the 16-wave big tile).  FP_GEMM_VARIANT / fp_set_option override
+    // 64 = streaming epilogue I/O: non-temporal output stores and residual loads (the last two with the 16-wave big tile).  FP_GEMM_VARIANT / fp_set_option override
     // the default (A/B probing only).
     static int env_var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
     const int var = fp_opt_get(FP_OPT_GEMM_VARIANT, env_var);

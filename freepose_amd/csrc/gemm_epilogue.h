@@ -76,7 +76,9 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int m = min(mbase + 16 * i + h * 8 + prow, p.M - 1);
-                    r[h] = *(const uint4*)(p.resid + (size_t)m * p.ldr + min(nb2, p.N - 8));
+                    const u32x4_t* rp = (const u32x4_t*)(p.resid + (size_t)m * p.ldr + min(nb2, p.N - 8));
+                    const u32x4_t rv = ((VAR & 64) != 0) ? __builtin_nontemporal_load(rp) : *rp;   // read once: streaming too
+                    r[h] = make_uint4(rv.x, rv.y, rv.z, rv.w);
                 }
             };
             if constexpr (EPI == FP_EPI_BIAS_LS_RES) {

@@ -69,46 +69,80 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out, float inv_s
     return min((int)floorf((float)dst * inv_scale), in - 1);
 }
 
+constexpr int CROP_ROWS = 8;
+
 template <int SRC_U8, int OUT_BF16>
 __global__ __launch_bounds__(256) void crop_kernel(const void* __restrict__ images, int n_img, int C, int H, int W,
                                                    const CropParam* __restrict__ params, int target,
                                                    const uint8_t* __restrict__ masks, int mask_mode,
                                                    void* __restrict__ outp) {
-    const int i = blockIdx.z;
+    // u8 sources: the 256 possible values of u8/255 (as float(double/255.0) or as fp32 division, whichever the caller's
+    // reference path uses) are tabulated once per block instead of dividing per pixel and channel
+    __shared__ float lut[256];
+    if (SRC_U8 != 0) {
+        const int t = threadIdx.x;
+        lut[t] = (SRC_U8 == 1) ? (float)((double)t / 255.0) : __fdiv_rn((float)t, 255.0f);
+        __syncthreads();
+    }
+    const int i = blockIdx.y;
     const CropParam p = params[i];
     const int img = (n_img == 1) ? 0 : i;
-    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-    const int oy = blockIdx.y;
-    if (ox >= target) return;
-    bool valid = (p.out == target) && p.cw > 0 && p.ch > 0;
-    int ys = 0, xs = 0;
-    if (valid) {
-        const bool small1 = (p.h1 + p.w1) <= 128, small2 = (2 * p.out) <= 128;
-        const int y2 = nearest_src(oy, p.S_h, p.out, p.inv2, small2);
-        const int x2 = nearest_src(ox, p.S_w, p.out, p.inv2, small2);
-        const int y1 = y2 - p.pad_t, x1 = x2 - p.pad_l;
-        if (y1 < 0 || y1 >= p.h1 || x1 < 0 || x1 >= p.w1) valid = false;
-        else {
-            ys = p.y0 + nearest_src(y1, p.ch, p.h1, p.inv1, small1);
-            xs = p.x0 + nearest_src(x1, p.cw, p.w1, p.inv1, small1);
-        }
-    }
-    float m = 1.f;
-    if (valid && masks && mask_mode != 0) m = masks[((size_t)i * H + ys) * W + xs] ? 1.f : 0.f;
-    for (int c = 0; c < C; ++c) {
-        float v = 0.f;
-        if (valid) {
-            if (mask_mode == 2) v = m;
-            else {
-                if (SRC_U8 == 1) v = (float)((double)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c] / 255.0);
-                else if (SRC_U8 == 2) v = __fdiv_rn((float)((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs) * C + c], 255.0f);
-                else v = ((const float*)images)[(((size_t)img * C + c) * H + ys) * W + xs];
-                v *= m;
+    const bool geom = (p.out == target) && p.cw > 0 && p.ch > 0;
+    const bool small1 = (p.h1 + p.w1) <= 128, small2 = (2 * p.out) <= 128;
+    // a block owns a strip of CROP_ROWS output rows; a thread walks (row, pixel pair) items of the strip
+    const int npair = (target + 1) >> 1;
+    const int row0 = blockIdx.x * CROP_ROWS;
+    const int nrow = min(CROP_ROWS, target - row0);
+    for (int item = threadIdx.x; item < nrow * npair; item += blockDim.x) {
+        const int oy = row0 + item / npair;
+        const int ox0 = (item % npair) * 2;
+        bool valid[2] = {false, false};
+        int ys = 0, xs[2] = {0, 0};
+        if (geom) {
+            const int y2 = nearest_src(oy, p.S_h, p.out, p.inv2, small2);
+            const int y1 = y2 - p.pad_t;
+            if (y1 >= 0 && y1 < p.h1) {
+                ys = p.y0 + nearest_src(y1, p.ch, p.h1, p.inv1, small1);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (ox0 + k >= target) continue;
+                    const int x2 = nearest_src(ox0 + k, p.S_w, p.out, p.inv2, small2);
+                    const int x1 = x2 - p.pad_l;
+                    if (x1 >= 0 && x1 < p.w1) {
+                        valid[k] = true;
+                        xs[k] = p.x0 + nearest_src(x1, p.cw, p.w1, p.inv1, small1);
+                    }
+                }
             }
         }
-        const size_t o = (((size_t)i * C + c) * target + oy) * target + ox;
-        if (OUT_BF16) ((bf16_t*)outp)[o] = f2bf(v);
-        else ((float*)outp)[o] = v;
+        float m[2] = {1.f, 1.f};
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (valid[k] && masks && mask_mode != 0) m[k] = masks[((size_t)i * H + ys) * W + xs[k]] ? 1.f : 0.f;
+        const bool pair = ox0 + 1 < target;
+        for (int c = 0; c < C; ++c) {
+            float v[2] = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!valid[k]) continue;
+                if (mask_mode == 2) v[k] = m[k];
+                else {
+                    if (SRC_U8 != 0) v[k] = lut[((const uint8_t*)images)[(((size_t)img * H + ys) * W + xs[k]) * C + c]];
+                    else v[k] = ((const float*)images)[(((size_t)img * C + c) * H + ys) * W + xs[k]];
+                    v[k] *= m[k];
+                }
+            }
+            const size_t o = (((size_t)i * C + c) * target + oy) * target + ox0;
+            if (OUT_BF16) {
+                bf16_t* op = (bf16_t*)outp + o;
+                if (pair && (o & 1) == 0) *(uint32_t*)op = pack_bf2(v[0], v[1]);
+                else { op[0] = f2bf(v[0]); if (pair) op[1] = f2bf(v[1]); }
+            } else {
+                float* op = (float*)outp + o;
+                op[0] = v[0];
+                if (pair) op[1] = v[1];
+            }
+        }
     }
 }
 
@@ -155,29 +189,50 @@ __global__ __launch_bounds__(1024) void compact_flags_kernel(const int32_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// one block per view: count, bbox of (depth > 0) with the <100 px fallback square, fp64 extents
-__global__ __launch_bounds__(256) void depth_extents_kernel(const float* __restrict__ depth, int Hh, int W, double fx,
-                                                            double fy, double cx, double cy, double* __restrict__ out) {
+// one block per view: count, bbox of (depth > 0) with the <100 px fallback square, fp64 extents.
+// X = ((x - cx) / fx) * z: the quotient depends only on the column (row for Y), so it is tabulated once per block in
+// LDS and the per-pixel work is two fp64 multiplies — bit-identical to dividing per pixel, ~10x less fp64 work.
+constexpr int EXT_THREADS = 1024;
+__global__ __launch_bounds__(EXT_THREADS) void depth_extents_kernel(const float* __restrict__ depth, int Hh, int W, double fx,
+                                                                    double fy, double cx, double cy, double* __restrict__ out) {
+    extern __shared__ double tab[];   // [W] column factors, then [Hh] row factors
+    double* ax = tab;
+    double* ay = tab + W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) ax[x] = ((double)x - cx) / fx;
+    for (int y = threadIdx.x; y < Hh; y += blockDim.x) ay[y] = ((double)y - cy) / fy;
+    __syncthreads();
     const int v = blockIdx.x;
     const float* d = depth + (size_t)v * Hh * W;
     int cnt = 0, xmin = 1 << 30, ymin = 1 << 30, xmax = -1, ymax = -1;
     double Xmin = 1e300, Xmax = -1e300, Ymin = 1e300, Ymax = -1e300;
-    for (int i = threadIdx.x; i < Hh * W; i += blockDim.x) {
-        const float z = d[i];
+    auto pixel = [&](float z, int x, int y) {
         if (z != 0.f) {  // depthmap_to_pointcloud keeps every row that is not all-zero
-            const int y = i / W, x = i - y * W;
-            const double X = ((double)x - cx) / fx * (double)z, Y = ((double)y - cy) / fy * (double)z;
+            const double X = ax[x] * (double)z, Y = ay[y] * (double)z;
             Xmin = fmin(Xmin, X); Xmax = fmax(Xmax, X); Ymin = fmin(Ymin, Y); Ymax = fmax(Ymax, Y);
             if (z > 0.f) { ++cnt; xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y); }
         }
+    };
+    const int npx = Hh * W;
+    if ((W & 3) == 0 && (((size_t)v * npx) & 3) == 0) {   // rows are whole float4s: 16-B loads, one div per four pixels
+        const float4* d4 = (const float4*)d;
+        for (int i4 = threadIdx.x; i4 < npx / 4; i4 += blockDim.x) {
+            const float4 z = d4[i4];
+            const int i = i4 * 4, y = i / W, x = i - y * W;
+            pixel(z.x, x, y); pixel(z.y, x + 1, y); pixel(z.z, x + 2, y); pixel(z.w, x + 3, y);
+        }
+    } else {
+        for (int i = threadIdx.x; i < npx; i += blockDim.x) {
+            const int y = i / W, x = i - y * W;
+            pixel(d[i], x, y);
+        }
     }
-    __shared__ int si[5][256];
-    __shared__ double sd[4][256];
+    __shared__ int si[5][EXT_THREADS];
+    __shared__ double sd[4][EXT_THREADS];
     const int t = threadIdx.x;
     si[0][t] = cnt; si[1][t] = xmin; si[2][t] = ymin; si[3][t] = xmax; si[4][t] = ymax;
     sd[0][t] = Xmin; sd[1][t] = Xmax; sd[2][t] = Ymin; sd[3][t] = Ymax;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = EXT_THREADS / 2; s > 0; s >>= 1) {
         if (t < s) {
             si[0][t] += si[0][t + s];
             si[1][t] = min(si[1][t], si[1][t + s]); si[2][t] = min(si[2][t], si[2][t + s]);
@@ -210,7 +265,7 @@ int fp_crop_resize_pad_launch(const void* images, int src_u8, int n_img, int C, 
     hipLaunchKernelGGL(crop_params_kernel, dim3(cdiv(n, 64)), dim3(64), 0, s, boxes, n, H, W, bbox_extend,
                        bbox_extend == 0.f ? 1 : 0, target, params);
     FP_LAUNCH_CHECK();
-    dim3 grid(cdiv(target, 256), target, n), block(256);
+    dim3 grid(cdiv(target, CROP_ROWS), n), block(256);
 #define FP_CROP(U, O) hipLaunchKernelGGL((crop_kernel<U, O>), grid, block, 0, s, images, n_img, C, H, W, params, target, masks, mask_mode, out)
     if (src_u8 == 1) { if (out_bf16) FP_CROP(1, 1); else FP_CROP(1, 0); }
     else if (src_u8 == 2) { if (out_bf16) FP_CROP(2, 1); else FP_CROP(2, 0); }
@@ -263,7 +318,7 @@ extern "C" int fp_depth_extents(fp_ctx* ctx, const float* d_depth, int Hn, int H
                                 float cy, double* d_out, void* stream) {
     FP_REQUIRE(ctx && d_depth && d_out, "depth_extents: null argument");
     if (Hn == 0) return FP_OK;
-    hipLaunchKernelGGL(depth_extents_kernel, dim3(Hn), dim3(256), 0, (hipStream_t)stream, d_depth, Hh, W, (double)fx,
+    hipLaunchKernelGGL(depth_extents_kernel, dim3(Hn), dim3(EXT_THREADS), (size_t)(Hh + W) * sizeof(double), (hipStream_t)stream, d_depth, Hh, W, (double)fx,
                        (double)fy, (double)cx, (double)cy, d_out);
     FP_LAUNCH_CHECK();
     return FP_OK;

@@ -236,6 +236,18 @@ __global__ __launch_bounds__(1024) void topk_merge_kernel(const float* __restric
 //   score[t] = bf16( (sum_p d[t,p]) / P )
 // qn is the already-normalised (or, frame-0 quirk, raw) query [P, D]; weights optional [T,P] f32
 // (mask_scores variant: score = sum(d*w)/sum(w)).
+// bf16( x / n ) with the IEEE quotient's rounding but without its ~12-instruction expansion: r = v_rcp_f32(n) (1 ulp), one
+// residual correction step puts q within 1 fp32 ulp of the correctly rounded quotient, and that can only change the
+// bf16 rounding when q's discarded 16 bits sit next to the midpoint 0x8000 — only those lanes (9 in 65536) take the exact
+// division.  Bit-identical to rbf(__fdiv_rn(x, n)) (what the oracle computes); the kernel was VALU-bound on the divisions.
+__device__ __forceinline__ float div_rbf(float x, float n, float r) {
+    float q = x * r;
+    const float e = __fmaf_rn(-q, n, x);
+    q = __fmaf_rn(e, r, q);
+    if ((__float_as_uint(q) & 0xffffu) - 0x7ffcu <= 8u) q = __fdiv_rn(x, n);
+    return rbf(q);
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void template_dots_kernel(const bf16_t* __restrict__ tmpl,
                                                             const bf16_t* __restrict__ qn, float* __restrict__ dots,
@@ -244,18 +256,32 @@ __global__ __launch_bounds__(256) void template_dots_kernel(const bf16_t* __rest
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long nwave = ((long)gridDim.x * blockDim.x) >> 6;
     const long rows = (long)T * P;
-    for (long r = wave; r < rows; r += nwave) {
+    // the row a wave will process NEXT is requested before the current one is reduced: two rows (4 KB) in flight per wave
+    uint4 na[NCH], nb[NCH];
+    auto fetch = [&](long r) {
         const int pidx = (int)(r % P);
-        float x[NCH][8], qq[NCH][8];
-        float ss = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int base = (c * 64 + lane) * 8;
-            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+            na[c] = make_uint4(0, 0, 0, 0);
+            nb[c] = make_uint4(0, 0, 0, 0);
             if (base < D) {
-                a = *(const uint4*)(tmpl + (size_t)r * D + base);
-                b = *(const uint4*)(qn + (size_t)pidx * D + base);
+                na[c] = *(const uint4*)(tmpl + (size_t)r * D + base);
+                nb[c] = *(const uint4*)(qn + (size_t)pidx * D + base);
             }
+        }
+    };
+    if (wave < rows) fetch(wave);
+    for (long r = wave; r < rows; r += nwave) {
+        float x[NCH][8], qq[NCH][8];
+        float ss = 0.f;
+        uint4 ca[NCH], cb[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { ca[c] = na[c]; cb[c] = nb[c]; }
+        if (r + nwave < rows) fetch(r + nwave);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint4 a = ca[c], b = cb[c];
             const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -267,11 +293,12 @@ __global__ __launch_bounds__(256) void template_dots_kernel(const bf16_t* __rest
         }
         ss = wave_sum(ss);
         const float nrm = fmaxf(rbf(__fsqrt_rn(ss)), 1e-12f);
+        const float rinv = __builtin_amdgcn_rcpf(nrm);
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = __fmaf_rn(rbf(__fdiv_rn(x[c][e], nrm)), qq[c][e], acc);
+            for (int e = 0; e < 8; ++e) acc = __fmaf_rn(div_rbf(x[c][e], nrm, rinv), qq[c][e], acc);
         acc = wave_sum(acc);
         if (lane == 0) dots[r] = rbf(acc);
     }
@@ -343,11 +370,12 @@ __global__ __launch_bounds__(256) void rerank_views_kernel(const bf16_t* __restr
         }
         ss = wave_sum(ss);
         const float nrm = fmaxf(rbf(__fsqrt_rn(ss)), 1e-12f);
+        const float rinv = __builtin_amdgcn_rcpf(nrm);
         float acc = 0.f;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = __fmaf_rn(rbf(__fdiv_rn(x[ch][e], nrm)), qv[ch][e], acc);
+            for (int e = 0; e < 8; ++e) acc = __fmaf_rn(div_rbf(x[ch][e], nrm, rinv), qv[ch][e], acc);
         acc = wave_sum(acc);
         if (lane == 0) sc[v] = rbf(acc);
     }

@@ -207,12 +207,19 @@ __global__ __launch_bounds__(128) void ffa_kernel(const bf16_t* __restrict__ fea
     if (c2 * 2 >= D) return;
     const uint32_t* fp = (const uint32_t*)(feats + (size_t)b * P * D) + c2;
     float a0 = 0.f, a1 = 0.f;
-    for (int pidx = 0; pidx < P; ++pidx) {
-        if (pm[pidx]) {
-            const uint32_t w = fp[(size_t)pidx * (D / 2)];
-            a0 += lo_bf(w);
-            a1 += hi_bf(w);
-        }
+    // the additions keep their order (ascending patch index, the oracle's); the loads do not wait for the mask test, so
+    // FFA_UNR rows are in flight per thread instead of one (a single crop has only D/2 threads to hide latency with)
+    constexpr int FFA_UNR = 16;
+    for (int p0 = 0; p0 < P; p0 += FFA_UNR) {
+        uint32_t w[FFA_UNR];
+#pragma unroll
+        for (int u = 0; u < FFA_UNR; ++u) w[u] = (p0 + u < P) ? fp[(size_t)(p0 + u) * (D / 2)] : 0u;
+#pragma unroll
+        for (int u = 0; u < FFA_UNR; ++u)
+            if (p0 + u < P && pm[p0 + u]) {
+                a0 += lo_bf(w[u]);
+                a1 += hi_bf(w[u]);
+            }
     }
     // mean of a bf16 tensor: fp32 accumulate, divide, round to bf16 (0/0 -> NaN like the reference)
     const float m0 = a0 / (float)cnt, m1 = a1 / (float)cnt;

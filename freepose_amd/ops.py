@@ -389,6 +389,45 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y
 
 
+def plan_vit_batches(n: int, n_tok: int, max_batch: int = 192, n_cu: int = 256) -> list:
+    """Split n crops into ViT batches whose GEMM grids fill whole rounds of the resident (one workgroup per CU) grid.
+
+    The persistent GEMM walks 256x256 tiles with one workgroup per CU; a batch of b crops has ceil(b*npad/256) tile rows,
+    and the narrowest linear layers (N = 1024: 4 tile columns) are the ones whose last partial round costs the most.
+    Dynamic programme over batch sizes in [max_batch/2, max_batch + max_batch/8]: minimise the total number of rounds,
+    then the number of batches.  Host-side policy only — results do not depend on the split.
+    """
+    if n <= 0:
+        return []
+    npad = (n_tok + 15) // 16 * 16
+    lo, hi = max(1, max_batch // 2), max_batch + max(1, max_batch // 8)
+
+    def rounds(b):
+        return -(-(-(-b * npad // 256) * 4) // n_cu)
+
+    if n <= hi:
+        return [n]
+    INF = (1 << 60, 1 << 60)
+    best = [INF] * (n + 1)
+    back = [0] * (n + 1)
+    best[0] = (0, 0)
+    for m in range(1, n + 1):
+        for b in range(lo, min(hi, m) + 1):
+            prev = best[m - b]
+            if prev == INF:
+                continue
+            cand = (prev[0] + rounds(b), prev[1] + 1)
+            if cand < best[m]:
+                best[m], back[m] = cand, b
+    if best[n] == INF:            # n below 2*lo: one batch or an even split
+        return [n] if n <= hi else [n // 2, n - n // 2]
+    out, m = [], n
+    while m > 0:
+        out.append(back[m])
+        m -= back[m]
+    return sorted(out, reverse=True)
+
+
 class Timer:
     """HIP-event timer on the current stream (bench.py)."""
 

@@ -112,9 +112,14 @@ class HotPath:
         return crops, ext
 
     def hypothesis_features(self, crops: torch.Tensor) -> torch.Tensor:
+        g = self.crop_res // 14
+        sizes = ops.plan_vit_batches(crops.shape[0], g * g + 5, self.vit_batch)   # whole GEMM tile rounds per batch
         with self.clock.stage("vit_hypotheses"):
-            return torch.cat([self.vit(crops[i:i + self.vit_batch], layer=self.layer, feature_type="patch")
-                              for i in range(0, crops.shape[0], self.vit_batch)], dim=0)
+            out, i = [], 0
+            for b in sizes:
+                out.append(self.vit(crops[i:i + b], layer=self.layer, feature_type="patch"))
+                i += b
+            return torch.cat(out, dim=0)
 
     def run(self, crops: torch.Tensor, masks: torch.Tensor, K: np.ndarray, bboxes: np.ndarray, scales) -> List[ProposalResult]:
         """one pass of the hot path over a batch of proposals (every stage executed for every proposal)"""

@@ -47,14 +47,64 @@ __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w <<
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // ---- wave-level helpers ----------------------------------------------------------------------
+// Value held by lane (l ^ mask), mask = 32, 16, 8, 4, 2, 1, fetched on the VALU only (gfx950): v_permlane32/16_swap for
+// the wave halves / 16-lane rows, DPP inside a row (row_ror:8 is l^8 within 16 lanes; row_half_mirror then
+// quad_perm[3,2,1,0] is l^7^3 = l^4).  __shfl_xor compiles to ds_bpermute_b32 — an LDS-crossbar round trip with a wait
+// per butterfly step, which made the row-dot kernels (bank scan, template scoring, LayerNorm) latency-bound.
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v) {
+    const int i = __float_as_int(v);
+    if constexpr (MASK == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(i, i, false, false);
+        return __int_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+    } else if constexpr (MASK == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(i, i, false, false);
+        return __int_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+    } else if constexpr (MASK == 8) {
+        return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0x128, 0xf, 0xf, true));       // row_ror:8
+    } else if constexpr (MASK == 4) {
+        const int m = __builtin_amdgcn_mov_dpp(i, 0x141, 0xf, 0xf, true);                  // row_half_mirror: l^7
+        return __int_as_float(__builtin_amdgcn_mov_dpp(m, 0x1b, 0xf, 0xf, true));         // quad_perm [3,2,1,0]: ^3
+    } else if constexpr (MASK == 2) {
+        return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0x4e, 0xf, 0xf, true));         // quad_perm [2,3,0,1]
+    } else {
+        return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0xb1, 0xf, 0xf, true));         // quad_perm [1,0,3,2]
+    }
+}
+// xor-butterfly reductions, masks 32 -> 1 (the pairing order is part of the fp32 "dot64" contract with the oracle)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += lane_xor<32>(v);
+    v += lane_xor<16>(v);
+    v += lane_xor<8>(v);
+    v += lane_xor<4>(v);
+    v += lane_xor<2>(v);
+    v += lane_xor<1>(v);
     return v;
 }
+// Four xor-butterfly sums at once: returns, on every lane of 16-lane row u = lane >> 4, wave_sum(v_u) — bit-identical to
+// four separate wave_sum calls (only commutativity of + is used): one v_permlane32_swap gives each wave half its own and
+// its partner's value for two of the rows, one v_permlane16_swap repeats that inside the halves, the last four steps run
+// on the single remaining value.  15 VALU instructions instead of 56.
+__device__ __forceinline__ float wave_sum4(float v0, float v1, float v2, float v3) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_int(v0), __float_as_int(v2), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_int(v1), __float_as_int(v3), false, false);
+    const float t02 = __int_as_float(a[0]) + __int_as_float(a[1]);   // lanes 0-31: row 0, lanes 32-63: row 2
+    const float t13 = __int_as_float(b[0]) + __int_as_float(b[1]);   // lanes 0-31: row 1, lanes 32-63: row 3
+    const auto c = __builtin_amdgcn_permlane16_swap(__float_as_int(t02), __float_as_int(t13), false, false);
+    float w = __int_as_float(c[0]) + __int_as_float(c[1]);           // 16-lane row u holds row u's partial
+    w += lane_xor<8>(w);
+    w += lane_xor<4>(w);
+    w += lane_xor<2>(w);
+    w += lane_xor<1>(w);
+    return w;
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = fmaxf(v, lane_xor<32>(v));
+    v = fmaxf(v, lane_xor<16>(v));
+    v = fmaxf(v, lane_xor<8>(v));
+    v = fmaxf(v, lane_xor<4>(v));
+    v = fmaxf(v, lane_xor<2>(v));
+    v = fmaxf(v, lane_xor<1>(v));
     return v;
 }
 

@@ -28,7 +28,7 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __rest
 
 // ---------------------------------------------------------------------------------------------
 // bank scan: keys[q, r] = sortable16( bf16( bank[r] . query[q] ) )
-template <int NCH, int QT>
+template <int NCH, int QT, bool FULL>   // FULL: D == NCH * 512, every lane's 8-element slot is in range (no per-load test)
 __global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict__ bank,
                                                         const bf16_t* __restrict__ queries,
                                                         uint16_t* __restrict__ keys, int N, int D, int q_begin,
@@ -42,28 +42,38 @@ __global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int base = (c * 64 + lane) * 8;
-            const bool ok = (q_begin + q < Q) && (base < D);
+            const bool ok = (q_begin + q < Q) && (FULL || base < D);
+            const uint4 qw = ok ? *(const uint4*)(queries + (size_t)(q_begin + q) * D + base) : make_uint4(0, 0, 0, 0);
+            const uint32_t w[4] = {qw.x, qw.y, qw.z, qw.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                qv[q][c][e] = ok ? bf2f(queries[(size_t)(q_begin + q) * D + base + e]) : 0.f;
+            for (int e = 0; e < 4; ++e) { qv[q][c][2 * e] = lo_bf(w[e]); qv[q][c][2 * e + 1] = hi_bf(w[e]); }
         }
-    constexpr int RU = 4;  // rows in flight per wave
-    for (int r0 = wave * RU; r0 < N; r0 += nwave * RU) {
-        uint4 raw[RU][NCH];
+    // Balanced partition: wave w owns a contiguous run of floor(N/nwave) (+1 for the first N%nwave waves) rows, streamed in
+    // chunks of RU rows (RU x 2 KB in flight) with the next chunk requested before the current one is reduced.  The host
+    // picks the grid (2..8 workgroups per CU) that leaves the smallest remainder, e.g. 3 per CU for N = 46 037 (0.1 %).
+    constexpr int RU = 4;
+    const int base_rows = N / nwave, rem = N - base_rows * nwave;
+    const int r_begin = wave * base_rows + min(wave, rem);
+    const int r_end = r_begin + base_rows + (wave < rem ? 1 : 0);
+    uint4 bufA[RU][NCH], bufB[RU][NCH];
+    auto fetch = [&](uint4 (&dst)[RU][NCH], int r0) {
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-            const int r = min(r0 + u, N - 1);
+            if (r0 + u >= r_end) break;      // wave-uniform: rows past the run are neither fetched nor stored
+            const int r = r0 + u;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int base = (c * 64 + lane) * 8;
-                raw[u][c] = base < D ? *(const uint4*)(bank + (size_t)r * D + base) : make_uint4(0, 0, 0, 0);
+                dst[u][c] = (FULL || base < D) ? *(const uint4*)(bank + (size_t)r * D + base) : make_uint4(0, 0, 0, 0);
             }
         }
+    };
+    auto reduce_chunk = [&](const uint4 (&raw)[RU][NCH], int r0) {
+        float acc[RU][QT];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-            float acc[QT];
 #pragma unroll
-            for (int q = 0; q < QT; ++q) acc[q] = 0.f;
+            for (int q = 0; q < QT; ++q) acc[u][q] = 0.f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const uint32_t w[4] = {raw[u][c].x, raw[u][c].y, raw[u][c].z, raw[u][c].w};
@@ -72,17 +82,30 @@ __global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict
                     const float x0 = lo_bf(w[e]), x1 = hi_bf(w[e]);
 #pragma unroll
                     for (int q = 0; q < QT; ++q) {
-                        acc[q] = __fmaf_rn(x0, qv[q][c][2 * e], acc[q]);
-                        acc[q] = __fmaf_rn(x1, qv[q][c][2 * e + 1], acc[q]);
+                        acc[u][q] = __fmaf_rn(x0, qv[q][c][2 * e], acc[u][q]);
+                        acc[u][q] = __fmaf_rn(x1, qv[q][c][2 * e + 1], acc[u][q]);
                     }
                 }
             }
+        }
+        // the chunk's four rows are reduced together; 16-lane row u of the wave ends up with row (r0 + u)'s dot product
+        static_assert(RU == 4, "wave_sum4 reduces four rows");
+        const int urow = lane >> 4;
 #pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                const float s = wave_sum(acc[q]);
-                if (lane == 0 && r0 + u < N && q_begin + q < Q)
-                    keys[(size_t)(q_begin + q) * N + r0 + u] = (uint16_t)score_key16(rbf(s));
-            }
+        for (int q = 0; q < QT; ++q) {
+            const float sdot = wave_sum4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
+            if ((lane & 15) == 0 && r0 + urow < r_end && q_begin + q < Q)
+                keys[(size_t)(q_begin + q) * N + r0 + urow] = (uint16_t)score_key16(rbf(sdot));
+        }
+    };
+    // two chunk buffers used alternately (no register copy at the hand-over): B is requested before A is reduced, etc.
+    if (r_begin < r_end) fetch(bufA, r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += 2 * RU) {
+        if (r0 + RU < r_end) fetch(bufB, r0 + RU);
+        reduce_chunk(bufA, r0);
+        if (r0 + RU < r_end) {
+            if (r0 + 2 * RU < r_end) fetch(bufA, r0 + 2 * RU);
+            reduce_chunk(bufB, r0 + RU);
         }
     }
 }
@@ -430,12 +453,29 @@ int fp_cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s) {
 int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int N, int D, int Q, hipStream_t s) {
     FP_REQUIRE(N > 0 && Q > 0 && D % 8 == 0 && D <= 1536, "bank_scan: bad shape N=%d D=%d Q=%d", N, D, Q);
     const int nch = cdiv(D, 512);
-    const int blocks = std::min(cdiv(N, 16), 256 * 8);  // 4 waves x 4 rows per block-iteration
+    // grid: 2..8 workgroups (4 waves each) per CU, whichever leaves the smallest remainder of rows per wave
+    static int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    int blocks = ncu * 2;
+    {
+        double best = 1e30;
+        for (int bpc = 2; bpc <= 8; ++bpc) {
+            const long nw = (long)ncu * bpc * 4;
+            const double waste = (double)(((long)N + nw - 1) / nw * nw) / N;
+            if (waste <= best) { best = waste; blocks = ncu * bpc; }
+        }
+        blocks = std::min(blocks, cdiv(N, 4));
+    }
     for (int qb = 0; qb < Q;) {
         const int left = Q - qb;
-#define FP_SCAN(NCHV, QTV)                                                                                   \
-    hipLaunchKernelGGL((bank_scan_kernel<NCHV, QTV>), dim3(blocks), dim3(256), 0, s, bank, queries, keys, N, D, \
-                       qb, Q)
+#define FP_SCAN(NCHV, QTV)                                                                                          \
+    do {                                                                                                            \
+        if (D == NCHV * 512)                                                                                        \
+            hipLaunchKernelGGL((bank_scan_kernel<NCHV, QTV, true>), dim3(blocks), dim3(256), 0, s, bank, queries,   \
+                               keys, N, D, qb, Q);                                                                  \
+        else                                                                                                        \
+            hipLaunchKernelGGL((bank_scan_kernel<NCHV, QTV, false>), dim3(blocks), dim3(256), 0, s, bank, queries,  \
+                               keys, N, D, qb, Q);                                                                  \
+    } while (0)
         if (left >= 4) {
             if (nch == 1) FP_SCAN(1, 4); else if (nch == 2) FP_SCAN(2, 4); else FP_SCAN(3, 4);
             qb += 4;

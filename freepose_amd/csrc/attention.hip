@@ -303,8 +303,9 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         softmax_exp(0);
         softmax_max(1);
         __builtin_amdgcn_sched_barrier(0);
-        // half 0's ten MFMAs go to the matrix pipe one at a time between slices of half 1's exp / convert work, so the
-        // wave overlaps the two pipes by itself instead of relying on the other waves of the SIMD being out of phase
+        // half 0's ten MFMAs are spread between slices of half 1's exp / convert work.  Measured +-2 % against issuing
+        // them as a block (profiles/r01_ab.md): a SIMD's matrix and vector pipes barely overlap on this part, so the
+        // kernel's bound is MFMA time + VALU time per tile and the lever was removing VALU work, not scheduling it.
         softmax_exp(1);
         pv_half(0);
 #pragma unroll

@@ -15,7 +15,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 // ---- MFMA issue peak: 8 independent accumulators per wave, operands live in registers, no memory traffic ----------
-__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, float seed) {
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, float seed, long long* cyc) {
+    const long long c0 = __builtin_readcyclecounter();   // s_memtime: shader clock
     bf16x8_t a, b;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {                       // non-trivial data: power (and so the clock) depends on the values
@@ -33,6 +34,44 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, f
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 123456.789f) out[0] = s;                   // keep the loop alive
+    if (cyc && blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = __builtin_readcyclecounter() - c0;
+}
+
+// ---- VALU issue rates that bound the attention softmax: v_exp_f32, v_fma_f32, and fma co-issued under MFMAs ----------
+template <int MODE, int NV>   // 0: 8 independent exp2 chains, 1: 8 independent fma chains, 2: per MFMA NV fma (same wave)
+__global__ __launch_bounds__(256) void valu_kernel(float* out, int iters, float seed) {
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = seed * (float)(threadIdx.x % 13 + i) * -0.01f;
+    bf16x8_t a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.01f * (float)(e + 1)); b[e] = (__bf16)(0.02f * (float)(e + 2)); }
+    f32x4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_exp2f(x[i]) - 1.5f;   // exp + one add per element
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = __builtin_fmaf(x[i], 0.999f, 0.001f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {   // 8 independent accumulators: the matrix pipe is issue-bound, not latency-bound
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < NV) x[k] = __builtin_fmaf(x[k], 0.999f, 0.001f);
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += x[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += acc[i][0];
+    if (sum == 123456.789f) out[0] = sum;
 }
 
 // ---- HBM: 16 B per lane, grid-stride -----------------------------------------------------------------------------
@@ -88,8 +127,32 @@ int main() {
 
     // MFMA: 8 waves per CU-workgroup x 4 workgroups per CU
     const int iters = 20000, wgs = ncu * 4;
-    const float ms_mfma = time_ms([&] { hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, 0, sink, iters, 1.0f); }, 5);
+    long long* dcyc;
+    CK(hipMalloc(&dcyc, 8));
+    const float ms_mfma = time_ms([&] { hipLaunchKernelGGL(mfma_peak_kernel, dim3(wgs), dim3(256), 0, 0, sink, iters, 1.0f, dcyc); }, 5);
+    long long hcyc = 0;
+    CK(hipMemcpy(&hcyc, dcyc, 8, hipMemcpyDeviceToHost));
+    (void)hcyc;   // s_memtime ticks; not a usable shader-clock measure on this part (1.06 ticks/ns)
     const double mfma_tf = (double)wgs * 4 /*waves*/ * iters * 8.0 * (2.0 * 16 * 16 * 32) / (ms_mfma * 1e-3) / 1e12;
+
+    // VALU probes: 4 waves per SIMD (16 per CU)
+    const int vit = 4000;
+    const float ms_exp = time_ms([&] { hipLaunchKernelGGL((valu_kernel<0, 0>), dim3(wgs), dim3(256), 0, 0, sink, vit, 1.0f); }, 3);
+    const float ms_fma = time_ms([&] { hipLaunchKernelGGL((valu_kernel<1, 0>), dim3(wgs), dim3(256), 0, 0, sink, vit, 1.0f); }, 3);
+    float ms_mix[5];
+    const int nvs[5] = {0, 1, 2, 4, 8};
+    (void)nvs;
+    ms_mix[0] = time_ms([&] { hipLaunchKernelGGL((valu_kernel<2, 0>), dim3(wgs), dim3(256), 0, 0, sink, vit, 1.0f); }, 3);
+    ms_mix[1] = time_ms([&] { hipLaunchKernelGGL((valu_kernel<2, 1>), dim3(wgs), dim3(256), 0, 0, sink, vit, 1.0f); }, 3);
+    ms_mix[2] = time_ms([&] { hipLaunchKernelGGL((valu_kernel<2, 2>), dim3(wgs), dim3(256), 0, 0, sink, vit, 1.0f); }, 3);
+    ms_mix[3] = time_ms([&] { hipLaunchKernelGGL((valu_kernel<2, 4>), dim3(wgs), dim3(256), 0, 0, sink, vit, 1.0f); }, 3);
+    ms_mix[4] = time_ms([&] { hipLaunchKernelGGL((valu_kernel<2, 8>), dim3(wgs), dim3(256), 0, 0, sink, vit, 1.0f); }, 3);
+    const double wave_instr = (double)wgs * 4 * vit * 8;          // wave-instructions of the probed kind per launch
+    const double simd_clk = 2.4e9;                                 // nominal; the chip may clock lower
+    printf("{\"valu_probe\": {\"exp2_plus_add_ns_per_wave_instr_pair_per_simd\": %.2f, \"fma_ns_per_wave_instr_per_simd\": %.2f, "
+           "\"mfma_with_n_fma_per_mfma_ms\": {\"0\": %.3f, \"1\": %.3f, \"2\": %.3f, \"4\": %.3f, \"8\": %.3f}, \"note\": \"4 waves/SIMD; ns per wave-instruction per SIMD = ms * 1e6 * 1024 / wave_instr; at %.1f GHz 1 ns = %.1f clk\"}}\n",
+           ms_exp * 1e6 * 1024 / wave_instr, ms_fma * 1e6 * 1024 / wave_instr, ms_mix[0], ms_mix[1], ms_mix[2], ms_mix[3], ms_mix[4],
+           simd_clk / 1e9, simd_clk / 1e9);
 
     const size_t bytes = (size_t)2 << 30, n = bytes / 16;
     u32x4_t *A, *B, *Cc;

@@ -42,7 +42,7 @@ def test_gemm_epilogues(M, N, K, epi):
     assert (diff <= tol).all(), f"max diff {diff.max().item()}"
 
 
-@pytest.mark.parametrize("B,npad,H", [(1, 272, 6), (3, 912, 16), (2, 1376, 16)])
+@pytest.mark.parametrize("B,npad,H", [(1, 272, 6), (3, 912, 16), (2, 1376, 16), (52, 1376, 16)])   # last: persistent 256x256 path
 def test_gemm_vt(B, npad, H):
     from freepose_amd import ops
     D = H * 64

@@ -212,3 +212,51 @@ def test_hot_path_batch_and_cli_rows(tmp_path):
     rows = pack_results(r1)
     assert rows.shape == (3, 16) and torch.isfinite(rows).all()
     assert all(np.all(np.diff(r.topk_scores) <= 0) for r in r1)
+
+
+def test_render_templates_cli_roundtrip(tmp_path, monkeypatch):
+    """scripts.render_templates (HIP rasteriser) -> shard tar in the reference's layout -> WebTemplateDataset: the decoded
+    views must equal a direct render (rgb exactly, depth to the u16-millimetre truncation of the format)."""
+    import bench
+    from freepose_amd.mesh_io import load_obj
+    from freepose_amd.src.dataloader.template import WebTemplateDataset
+    from freepose_amd.src.pipeline.retrieval.renderer import MeshRenderer
+    from scripts import render_templates
+    n_views = 12
+    ids = ["mesh_a", "mesh_b"]
+    for k, mid in enumerate(ids):
+        v, f, c = bench.synthetic_mesh(2 + k)
+        d = tmp_path / "mesh_cache" / mid
+        d.mkdir(parents=True)
+        with open(d / f"{mid}.obj", "w") as fh:
+            for p, col in zip(v, c):
+                fh.write(f"v {p[0]:.7f} {p[1]:.7f} {p[2]:.7f} {col[0] / 255:.6f} {col[1] / 255:.6f} {col[2] / 255:.6f}\n")
+            for t in f:
+                fh.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
+    (tmp_path / "list.txt").write_text("\n".join(ids) + "\n")
+    monkeypatch.delenv("SLURM_ARRAY_TASK_ID", raising=False)
+    tar_path = render_templates.run(["--filelist", str(tmp_path / "list.txt"), "--mesh_root", str(tmp_path / "mesh_cache"),
+                                     "--datasets_root", str(tmp_path / "datasets"), "--shards_folder", "sh",
+                                     "--n_views", str(n_views)])
+    assert tar_path.name == "shard-000000.tar" and tar_path.exists()
+    with tarfile.open(tar_path) as tar:
+        names = tar.getnames()
+    assert len(names) == 2 * 2 * n_views and "mesha_0.rgb.png" in names and "meshb_11.depth.png" in names
+    (tmp_path / "list.csv").write_text("model_name\n" + "\n".join(ids) + "\n")
+    ds = WebTemplateDataset(str(tmp_path / "datasets" / "sh"), str(tmp_path / "list.csv"), crop=False, n_views=n_views)
+    s = ds[1]
+    assert s["model_name"] == "meshb" and s["depths"].shape == (n_views, 420, 420)
+    mesh = load_obj(tmp_path / "mesh_cache" / "mesh_b" / "mesh_b.obj")
+    mesh.apply_scale(0.25)
+    direct = MeshRenderer(n_views).render(mesh)
+    assert torch.equal(s["templates"].cpu(), ops_crop_identity(direct.rgb).cpu())
+    d_direct = (direct.depth.cpu().numpy() * 1000).astype(np.uint16).astype(np.float32) / 1000
+    assert np.array_equal(s["depths"].cpu().numpy(), (d_direct.astype(np.float64)).astype(np.float32)) or \
+        np.abs(s["depths"].cpu().numpy() - d_direct).max() < 1e-6
+
+
+def ops_crop_identity(rgb_u8):
+    """what WebTemplateDataset(crop=False) returns for a batch of renders: the full frame through the crop op"""
+    from freepose_amd import ops
+    n, h, w = rgb_u8.shape[0], rgb_u8.shape[1], rgb_u8.shape[2]
+    return ops.crop_resize_pad(rgb_u8, torch.tensor([[0, 0, w, h]] * n, dtype=torch.int32), h, 0.0)

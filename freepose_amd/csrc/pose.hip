@@ -257,6 +257,51 @@ __global__ __launch_bounds__(EXT_THREADS) void depth_extents_kernel(const float*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// RoIAlign forward (torchvision.ops.roi_align, aligned=False) as TrackingRefiner crops the photo with it
+// (src/pipeline/refiner_utils.py:127-132: output 518x518, sampling_ratio=2, spatial_scale 1).  Restated from the
+// published algorithm (torchvision/csrc/ops/cpu/roi_align_kernel.cpp); torchvision is not installable here, so parity with
+// it is pinned only by known-answer tests.  All arithmetic in fp32 in the order written (oracle: same).
+__device__ __forceinline__ float roi_bilinear(const float* __restrict__ in, int H, int W, float y, float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return w1 * in[y_low * W + x_low] + w2 * in[y_low * W + x_high] + w3 * in[y_high * W + x_low] + w4 * in[y_high * W + x_high];
+}
+
+__global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ images, const float* __restrict__ rois,
+                                                        int n, int C, int H, int W, int PH, int PW, int sampling,
+                                                        float spatial_scale, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (roi, c, ph, pw), pw fastest
+    if (idx >= (size_t)n * C * PH * PW) return;
+    const int pw = (int)(idx % PW), ph = (int)((idx / PW) % PH), c = (int)((idx / ((size_t)PW * PH)) % C);
+    const int r = (int)(idx / ((size_t)PW * PH * C));
+    const float* roi = rois + (size_t)r * 5;
+    const int b = (int)roi[0];
+    const float roi_start_w = roi[1] * spatial_scale, roi_start_h = roi[2] * spatial_scale;
+    const float roi_end_w = roi[3] * spatial_scale, roi_end_h = roi[4] * spatial_scale;
+    const float roi_w = fmaxf(roi_end_w - roi_start_w, 1.0f), roi_h = fmaxf(roi_end_h - roi_start_h, 1.0f);
+    const float bin_h = roi_h / (float)PH, bin_w = roi_w / (float)PW;
+    const int grid_h = sampling > 0 ? sampling : (int)ceilf(roi_h / (float)PH);
+    const int grid_w = sampling > 0 ? sampling : (int)ceilf(roi_w / (float)PW);
+    const float count = (float)max(grid_h * grid_w, 1);
+    const float* in = images + ((size_t)b * C + c) * H * W;
+    float acc = 0.f;
+    for (int iy = 0; iy < grid_h; ++iy) {
+        const float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)grid_h;
+        for (int ix = 0; ix < grid_w; ++ix) {
+            const float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)grid_w;
+            acc += roi_bilinear(in, H, W, y, x);
+        }
+    }
+    out[idx] = acc / count;
+}
+
 }  // namespace
 
 int fp_crop_resize_pad_launch(const void* images, int src_u8, int n_img, int C, int H, int W, const int32_t* boxes,
@@ -340,5 +385,18 @@ extern "C" int fp_generate_rotations(int n, double* out) {
         M[3] = 2 * (xy + zw);     M[4] = -x2 + y2 - z2 + w2; M[5] = 2 * (yz - xw);
         M[6] = 2 * (xz - yw);     M[7] = 2 * (yz + xw);      M[8] = -x2 - y2 + z2 + w2;
     }
+    return FP_OK;
+}
+
+extern "C" int fp_roi_align(fp_ctx* ctx, const float* d_images, int n_img, int C, int H, int W, const float* d_rois, int n,
+                            int pooled_h, int pooled_w, int sampling_ratio, float spatial_scale, float* d_out, void* stream) {
+    FP_REQUIRE(ctx && d_images && d_out, "roi_align: null argument");
+    FP_REQUIRE(n_img > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0, "roi_align: bad shape");
+    if (n == 0) return FP_OK;
+    FP_REQUIRE(d_rois, "roi_align: null rois");
+    const size_t total = (size_t)n * C * pooled_h * pooled_w;
+    hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_images,
+                       d_rois, n, C, H, W, pooled_h, pooled_w, sampling_ratio, spatial_scale, d_out);
+    FP_LAUNCH_CHECK();
     return FP_OK;
 }

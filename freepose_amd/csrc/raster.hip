@@ -13,7 +13,7 @@
 //   visibility: 64-bit key (depth bits << 32 | triangle id), atomic MIN -> nearest depth, lowest id on
 //            exact ties; order independent, hence deterministic
 //   colour : per-vertex RGB, perspective-correct: c = fma(b2*iz2,c2, fma(b1*iz1,c1,(b0*iz0)*c0)) * depth
-//            out = (u8) min(255, 2*c + 0.5)        (ambient (2,2,2) saturates, renderer.py:53-55)
+//            out = (u8) min(255, a*c + 0.5)        (ambient light a saturates; a = 2 by default, renderer.py:53-55)
 // Launch shape: vertex kernel (Hn x V threads), triangle kernel (Hn x F threads; small triangles are
 // rasterised by their thread, large ones by a whole wave via a queue), resolve kernel (Hn x pixels).
 #include "../../include/freepose_hip.h"
@@ -25,6 +25,7 @@ struct fp_mesh {
     int32_t* faces = nullptr;  // [F,3]
     uint8_t* colors = nullptr; // [V,4] rgba (a unused)
     int V = 0, F = 0;
+    float ambient = 2.0f;      // scene ambient light factor: 2 in renderer.py:53-55, 5 in tracking_refiner.py:33
 };
 
 namespace {
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __rest
                                                              const int32_t* __restrict__ faces,
                                                              const uint8_t* __restrict__ colors, int V, int W, int Hh,
                                                              const unsigned long long* __restrict__ zb_all,
-                                                             uint8_t* __restrict__ rgb, float* __restrict__ depth) {
+                                                             uint8_t* __restrict__ rgb, float* __restrict__ depth,
+                                                             float ambient) {
     const int h = blockIdx.y;
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= W * Hh) return;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __rest
             float c0 = 255.f, c1 = 255.f, c2 = 255.f;
             if (colors) { c0 = (float)colors[4 * t.i0 + c]; c1 = (float)colors[4 * t.i1 + c]; c2 = (float)colors[4 * t.i2 + c]; }
             const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
-            const float amb = fminf(2.0f * cv + 0.5f, 255.0f);
+            const float amb = fminf(ambient * cv + 0.5f, 255.0f);
             out[c] = (uint8_t)fmaxf(amb, 0.f);
         }
         r = out[0]; g = out[1]; b = out[2];
@@ -266,7 +268,13 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
     hipLaunchKernelGGL(raster_big_kernel, dim3(1024), dim3(256), 0, s, sv, mesh->faces, V, W, Hh, zb, queue, qcount, qcap);
     FP_LAUNCH_CHECK();
     hipLaunchKernelGGL(raster_resolve_kernel, dim3(cdiv(W * Hh, 256), Hn), dim3(256), 0, s, sv, mesh->faces, mesh->colors,
-                       V, W, Hh, zb, d_rgb, d_depth);
+                       V, W, Hh, zb, d_rgb, d_depth, mesh->ambient);
     FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+extern "C" int fp_mesh_set_ambient(fp_mesh* mesh, float ambient) {
+    FP_REQUIRE(mesh && ambient >= 0.f, "mesh_set_ambient: bad argument");
+    mesh->ambient = ambient;
     return FP_OK;
 }

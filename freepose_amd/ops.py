@@ -278,6 +278,23 @@ def crop_resize_pad(images: torch.Tensor, boxes: torch.Tensor, target: int, bbox
     return out
 
 
+def roi_align(images: torch.Tensor, rois: torch.Tensor, output_size, sampling_ratio: int = 2,
+              spatial_scale: float = 1.0) -> torch.Tensor:
+    """torchvision.ops.roi_align(images, rois, output_size, spatial_scale, sampling_ratio, aligned=False):
+    images f32 [N,C,H,W], rois f32 [n,5] (image index, x1, y1, x2, y2) -> f32 [n,C,ph,pw]"""
+    lib = _lib.load()
+    img = _dev(images, torch.float32)
+    r = _dev(rois, torch.float32).reshape(-1, 5).contiguous()
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    N, Cc, H, W = img.shape
+    n = r.shape[0]
+    out = torch.empty((n, Cc, ph, pw), dtype=torch.float32, device=img.device)
+    if n:
+        check(lib.fp_roi_align(context(), ptr(img), N, Cc, H, W, ptr(r), n, int(ph), int(pw), int(sampling_ratio),
+                               float(spatial_scale), ptr(out), current_stream()), "fp_roi_align")
+    return out
+
+
 def generate_rotations(n: int) -> np.ndarray:
     lib = _lib.load()
     out = np.empty((n, 3, 3), dtype=np.float64)
@@ -306,6 +323,11 @@ class Mesh:
         h = C.c_void_p()
         check(self.lib.fp_mesh_upload(context(), ptr(v), v.shape[0], ptr(f), f.shape[0], ptr(c), C.byref(h)), "fp_mesh_upload")
         self.handle, self.V, self.F = h, v.shape[0], f.shape[0]
+
+    def set_ambient(self, ambient: float):
+        """scene ambient light factor (2 = MeshRenderer's scenes, 5 = TrackingRefiner's)"""
+        check(self.lib.fp_mesh_set_ambient(self.handle, float(ambient)), "fp_mesh_set_ambient")
+        return self
 
     def __del__(self):
         try:

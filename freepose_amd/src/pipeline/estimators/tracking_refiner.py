@@ -1,0 +1,109 @@
+"""Drop-in for the GPU-bound part of the reference's `src/pipeline/estimators/tracking_refiner.py`: per-frame pose
+confidence (`pose_confidence`, :70-93) and the inlier count used to pick trustworthy frames (`n_inliers_per_pose`,
+`_get_threshold_for_confidence`, :60-68, :95-104).  Same two device kernels as the main path at other shapes — the ViT
+(ViT-B/14-reg, 518^2, all 12 blocks + final norm = `x_norm_patchtokens`) and the rasteriser (518^2, cropped intrinsics,
+ambient 5) — plus `fp_roi_align` for the photo crop.
+
+Deviations, on purpose: features are computed in bf16 with fp32 accumulation (the reference runs this model in fp32 on
+`dino_device`), the render comes from the HIP rasteriser instead of pyrender/EGL, and the CoTracker / PnP smoothing half of
+the class (out of scope) raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from freepose_amd import ops
+from freepose_amd.mesh_io import mesh_arrays
+from freepose_amd.src.pipeline import refiner_utils
+
+
+class TrackingRefiner:
+    def __init__(self, dino_model="dinov2_vitb14_reg", dino_device="cuda", cotracker_device="cpu", state_dict=None, seed=0):
+        self.dino_device = dino_device
+        self.cotracker_device = cotracker_device
+        self.dinov2 = ops.ViT(dino_model, state_dict=state_dict, seed=seed)
+        self.patch_size = 14
+        self.image_size = int(math.sqrt(1370 - 1) * self.patch_size)     # 518 (tracking_refiner.py:26)
+        self.feats_size = self.image_size // self.patch_size              # 37
+        self._mesh_cache = {}
+
+    # ---- rendering / cropping --------------------------------------------------------------------------------------
+    def _device_mesh(self, mesh) -> ops.Mesh:
+        key = id(mesh)
+        hit = self._mesh_cache.get(key)
+        if hit is None:
+            v, f, c = mesh_arrays(mesh)
+            hit = ops.Mesh(v, f, c).set_ambient(5.0)                     # ambient_light=[5,5,5] (tracking_refiner.py:33)
+            self._mesh_cache = {key: hit}
+        return hit
+
+    def _render(self, mesh, width, height, K, transform):
+        """colour u8 [H,W,3] and metric depth f32 [H,W] of `mesh` under `transform` (object -> OpenCV camera)"""
+        K = np.asarray(K, dtype=np.float64)
+        pose = torch.from_numpy(np.asarray(transform, dtype=np.float32).reshape(1, 4, 4))
+        rgb, depth = ops.rasterize(self._device_mesh(mesh), pose, 1.0, K[0, 0], K[1, 1], K[0, 2], K[1, 2], width, height)
+        return rgb[0], depth[0]
+
+    def _crop_image(self, mesh, image, K, transform):
+        vertices = np.asarray(mesh.vertices)
+        # the reference seeds the global NumPy generator with 42 and draws 100 vertex indices (:45-47); the same legacy
+        # stream without the global side effect
+        pick = np.random.RandomState(42).choice(np.arange(len(vertices)), 100)
+        vertices = torch.from_numpy(np.pad(vertices[pick], ((0, 0), (0, 1)), constant_values=1.).copy()).float()
+        image = refiner_utils.MaybeToTensor()(image)
+        K = torch.from_numpy(np.asarray(K)).view(3, 3).float()
+        transform = torch.from_numpy(np.asarray(transform)).view(1, 4, 4).float()
+        cropped_images, recomputed_bboxes = refiner_utils.crop_image(image, transform, vertices, K, 518, 518)
+        new_Ks = refiner_utils.update_K_with_crop(K, recomputed_bboxes, 518, 518)
+        return cropped_images[0], recomputed_bboxes[0], new_Ks[0]
+
+    # ---- confidence ------------------------------------------------------------------------------------------------
+    def _get_threshold_for_confidence(self, similarity_matrices, top_quantile=0.2):
+        """value above which the top `top_quantile` of the positive similarities lie, on a 50-bin histogram (:60-68)"""
+        counts, values = np.histogram(similarity_matrices[similarity_matrices > 0], bins=50)
+        cutoff_value = counts.sum() * top_quantile
+        cum_ = 0
+        v = values[0]
+        for c, v in zip(counts[::-1], values[:-1][::-1]):
+            cum_ += c
+            if cum_ > cutoff_value:
+                break
+        return v
+
+    def _patch_features(self, chw_01: torch.Tensor) -> torch.Tensor:
+        """x_norm_patchtokens of one image in [0,1] (ImageNet normalisation happens inside the ViT's im2col kernel)"""
+        x = chw_01.unsqueeze(0).to(torch.bfloat16).cuda()
+        f = self.dinov2(x, layer=len_blocks(self.dinov2), feature_type="patch")          # [1, 1369, D]
+        return f[0].float()
+
+    def pose_confidence(self, mesh, photo, K, transform):
+        cropped_photo, _new_bbox, new_K = self._crop_image(mesh, photo, K, transform)
+        rendered, rendered_depth = self._render(mesh, 518, 518, new_K.numpy(), transform)
+        valid = (rendered_depth > 0).float().cpu().numpy()
+        render_valid_37x37_mask = refiner_utils.cubic_resize(valid, (37, 37)) > 0.5           # cv2.INTER_CUBIC (:78)
+        g = self.feats_size
+        photo_feats = self._patch_features(cropped_photo.clamp(0, 1))
+        render_feats = self._patch_features(rendered.permute(2, 0, 1).float().div(255))
+        photo_feats = photo_feats / torch.linalg.norm(photo_feats, dim=-1, keepdim=True)
+        render_feats = render_feats / torch.linalg.norm(render_feats, dim=-1, keepdim=True)
+        cosine_sim = (photo_feats * render_feats).sum(-1).view(g, g).cpu()
+        cosine_sim = cosine_sim * torch.from_numpy(render_valid_37x37_mask).float()
+        return cosine_sim.numpy()
+
+    def n_inliers_per_pose(self, mesh, frames, K, transforms):
+        confidences = np.stack([self.pose_confidence(mesh, frame, K, transform) for frame, transform in zip(frames, transforms)])
+        thr = self._get_threshold_for_confidence(confidences)
+        return (confidences > thr).sum(-1).sum(-1), thr
+
+    # ---- CoTracker / PnP smoothing: outside the hot path (out of scope) --------------------------------------
+    def __getattr__(self, name):
+        if name in ("refine", "refine_poses", "track", "_compute_3d_points", "smooth_poses"):
+            raise NotImplementedError(f"TrackingRefiner.{name}: CoTracker/PnP smoothing is outside the MI355X hot path")
+        raise AttributeError(name)
+
+
+def len_blocks(vit: ops.ViT) -> int:
+    return int(getattr(vit, "depth", 12))

@@ -1,0 +1,119 @@
+"""Drop-in for the parts of the reference's `src/pipeline/refiner_utils.py` that `TrackingRefiner.pose_confidence` uses
+(:26-50 tensor/normalise helpers, :92-132 crop_image, :135-170 update_K_with_crop).  The crop itself runs on the device
+(`fp_roi_align`); the box arithmetic stays the reference's float32 torch expressions on a handful of points.
+
+`cubic_resize` restates `cv2.resize(..., interpolation=cv2.INTER_CUBIC)` for float32 images (the 518->37 validity mask of
+tracking_refiner.py:78): OpenCV is not installable here, so that piece is pinned by known-answer tests only.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from freepose_amd import ops
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+
+
+class MaybeToTensor:
+    """torchvision ToTensor that passes tensors through (refiner_utils.py:26-31): HWC uint8 -> CHW float32 / 255"""
+
+    def __call__(self, pic):
+        if isinstance(pic, torch.Tensor):
+            return pic
+        arr = np.asarray(pic)
+        if arr.ndim == 2:
+            arr = arr[:, :, None]
+        t = torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1)
+        return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t.to(torch.float32)
+
+
+def pil2torch(pic) -> torch.Tensor:
+    """MaybeToTensor + ImageNet normalise (refiner_utils.py:46-49)"""
+    t = MaybeToTensor()(pic)
+    mean = torch.tensor(IMAGENET_DEFAULT_MEAN, dtype=t.dtype, device=t.device).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_DEFAULT_STD, dtype=t.dtype, device=t.device).view(3, 1, 1)
+    return (t - mean) / std
+
+
+def crop_image(image, Ts, points, K, render_width, render_height, lamb=1.4):
+    """refiner_utils.py:92-132 — project the object points, take a centre-symmetric box of the render's aspect ratio
+    enlarged by `lamb`, and RoIAlign the image to (render_height, render_width)."""
+    assert len(image.shape) == 3 and image.shape[0] in [1, 3, 4] and image.dtype == torch.float32
+    assert Ts.shape[1:] == torch.Size([4, 4])
+    assert points.shape[1:] == torch.Size([4])
+    assert K.shape == torch.Size([3, 3])
+    T = torch.matmul(torch.nn.functional.pad(K, (0, 1, 0, 0), value=0.).unsqueeze(0), Ts)
+    points_transformed = torch.matmul(points.unsqueeze(0), T.permute(0, 2, 1))
+    uv = points_transformed[:, :, :2] / torch.maximum(points_transformed[:, :, [2]], torch.tensor(0.01))
+    bboxes = torch.cat([uv.min(dim=1).values, uv.max(dim=1).values], dim=1)
+    centers_transformed = torch.matmul(torch.mean(points, dim=0, keepdim=True).unsqueeze(0), T.permute(0, 2, 1)).squeeze(1)
+    centers_uv = centers_transformed[:, :2] / torch.maximum(centers_transformed[:, [2]], torch.tensor(0.01))
+    dists = torch.maximum((bboxes[:, [0, 1]] - centers_uv).abs_(), (bboxes[:, [2, 3]] - centers_uv).abs_())
+    xdists, ydists = dists[:, 0], dists[:, 1]
+    r = render_width / render_height
+    width = torch.max(xdists, ydists * r) * 2 * lamb
+    height = torch.max(xdists / r, ydists) * 2 * lamb
+    x1, y1 = centers_uv[:, 0] - width / 2, centers_uv[:, 1] - height / 2
+    x2, y2 = centers_uv[:, 0] + width / 2, centers_uv[:, 1] + height / 2
+    bboxes = torch.stack([x1, y1, x2, y2], dim=1)
+    rois = torch.cat([torch.zeros((len(bboxes), 1)), bboxes], 1)
+    crops = ops.roi_align(image.unsqueeze(0), rois, (render_height, render_width), sampling_ratio=2)
+    return crops, bboxes
+
+
+def update_K_with_crop(K, bboxes, render_width, render_height):
+    """refiner_utils.py:135-170 (skew is not handled, as in the reference)"""
+    assert K.shape == torch.Size([3, 3])
+    assert bboxes.shape[1:] == torch.Size([4])
+    new_K = K.unsqueeze(0).repeat(len(bboxes), 1, 1)
+    crop_width = bboxes[:, 2] - bboxes[:, 0]
+    crop_height = bboxes[:, 3] - bboxes[:, 1]
+    crop_cx = (bboxes[:, 0] + bboxes[:, 2]) / 2
+    crop_cy = (bboxes[:, 1] + bboxes[:, 3]) / 2
+    cx = K[0, 2] + (crop_width - 1) / 2 - crop_cx
+    cy = K[1, 2] + (crop_height - 1) / 2 - crop_cy
+    center_x = (crop_width - 1) / 2
+    center_y = (crop_height - 1) / 2
+    orig_cx_diff = cx - center_x
+    orig_cy_diff = cy - center_y
+    scale_x = render_width / crop_width
+    scale_y = render_height / crop_height
+    new_K[:, 0, 0] = scale_x * K[0, 0]
+    new_K[:, 1, 1] = scale_y * K[1, 1]
+    new_K[:, 0, 2] = (render_width - 1) / 2 + scale_x * orig_cx_diff
+    new_K[:, 1, 2] = (render_height - 1) / 2 + scale_y * orig_cy_diff
+    return new_K
+
+
+def _cubic_coeffs(x: np.ndarray, A: float = -0.75) -> np.ndarray:
+    """OpenCV interpolateCubic: 4 taps for the fractional offset x in [0,1)"""
+    c = np.empty(x.shape + (4,), dtype=np.float32)
+    x = x.astype(np.float32)
+    c[..., 0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A
+    c[..., 1] = ((A + 2) * x - (A + 3)) * x * x + 1
+    c[..., 2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1
+    c[..., 3] = 1.0 - c[..., 0] - c[..., 1] - c[..., 2]
+    return c
+
+
+def cubic_resize(img: np.ndarray, dsize) -> np.ndarray:
+    """cv2.resize(img float32 [H,W], dsize=(w,h), interpolation=cv2.INTER_CUBIC): half-pixel centres, a = -0.75, replicated
+    border, separable (rows then columns) in float32"""
+    src = np.asarray(img, dtype=np.float32)
+    H, W = src.shape
+    dw, dh = dsize
+
+    def taps(n_src, n_dst):
+        f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        frac = (f - i0).astype(np.float32)
+        idx = np.clip(i0[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+        return idx, _cubic_coeffs(frac)
+
+    ix, cx = taps(W, dw)
+    iy, cy = taps(H, dh)
+    rows = (src[:, ix] * cx[None, :, :]).sum(-1, dtype=np.float32)          # [H, dw]
+    out = (rows[iy, :] * cy[:, :, None]).sum(1, dtype=np.float32)           # [dh, dw]
+    return out.astype(np.float32)

@@ -112,6 +112,13 @@ int fp_crop_resize_pad(fp_ctx* ctx, const void* d_images, int src_fmt, int n_img
                        const int32_t* d_boxes, int n, float bbox_extend, int target, const uint8_t* d_masks,
                        int mask_mode, void* d_out, int out_fmt, void* stream);
 
+/* ---- f-3: TrackingRefiner photo crop (src/pipeline/refiner_utils.py:92-132 crop_image -> torchvision.ops.roi_align,
+ * output 518x518, sampling_ratio 2, aligned=False) ------------------------------------------------------------------ */
+/* d_images f32 [n_img,C,H,W]; d_rois f32 [n,5] = (image index, x1, y1, x2, y2); d_out f32 [n,C,pooled_h,pooled_w].
+ * sampling_ratio <= 0 selects the adaptive ceil(roi/pooled) grid of the original operator. */
+int fp_roi_align(fp_ctx* ctx, const float* d_images, int n_img, int C, int H, int W, const float* d_rois, int n,
+                 int pooled_h, int pooled_w, int sampling_ratio, float spatial_scale, float* d_out, void* stream);
+
 /* ---- a8/a10: rotation grids and neighbourhood (pose_estimator.py:121-147, online_pose_estimator.py:25-34,55-56) */
 /* super-Fibonacci rotations, fp64 [n,3,3] row-major written to HOST memory (one-off setup, n=600/20000). */
 int fp_generate_rotations(int n, double* h_out);
@@ -126,6 +133,9 @@ int fp_geodesic_select(fp_ctx* ctx, const double* d_grid, int G, const double* h
 int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F,
                    const uint8_t* h_colors, fp_mesh** out);
 int fp_mesh_destroy(fp_mesh* mesh);
+/* ambient light factor of the scene the mesh is rendered in: 2 (default; renderer.py:53-55,80-82) or 5
+ * (tracking_refiner.py:33); output colour = min(255, ambient * interpolated vertex colour) */
+int fp_mesh_set_ambient(fp_mesh* mesh, float ambient);
 /* poses f32 [Hn,4,4] (OpenCV camera frame, object->camera), intrinsics fx,fy,cx,cy, image W x Hh.
  * scale multiplies the vertices (rendering_scale 0.25).  Outputs rgb u8 [Hn,Hh,W,3], depth f32 [Hn,Hh,W]
  * (metric eye depth, 0 = background).  Ambient-only shading, no culling (renderer.py:53-55,66). */

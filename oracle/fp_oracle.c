@@ -372,9 +372,17 @@ void fpo_depth_extents(const float* depth, int Hn, int Hh, int W, double fx, dou
 typedef struct { int xi, yi; float iz, zc; } svert_t;
 static int topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
 
+void fpo_rasterize_amb(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
+                       const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
+                       uint8_t* rgb, float* depth, float ambient);
 void fpo_rasterize(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
                    const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
                    uint8_t* rgb, float* depth) {
+    fpo_rasterize_amb(verts, V, faces, F, colors, poses, Hn, scale, fx, fy, cx, cy, W, Hh, rgb, depth, 2.0f);
+}
+void fpo_rasterize_amb(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
+                       const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
+                       uint8_t* rgb, float* depth, float ambient) {
     const float ZNEAR = 0.05f;
     svert_t* sv = (svert_t*)malloc((size_t)V * sizeof(svert_t));
     uint64_t* zb = (uint64_t*)malloc((size_t)W * Hh * 8);
@@ -452,7 +460,7 @@ void fpo_rasterize(const float* verts, int V, const int32_t* faces, int F, const
                         float c0 = 255.f, c1 = 255.f, c2 = 255.f;
                         if (colors) { c0 = (float)colors[3 * i0 + ch]; c1 = (float)colors[3 * i1 + ch]; c2 = (float)colors[3 * i2 + ch]; }
                         const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
-                        float amb = fminf(2.0f * cv + 0.5f, 255.0f);
+                        float amb = fminf(ambient * cv + 0.5f, 255.0f);
                         if (amb < 0.f) amb = 0.f;
                         col[ch] = (uint8_t)amb;
                     }
@@ -463,4 +471,53 @@ void fpo_rasterize(const float* verts, int V, const int32_t* faces, int F, const
             }
     }
     free(sv); free(zb);
+}
+
+
+/* ---- f-3: RoIAlign forward, aligned=False (torchvision.ops.roi_align as called by src/pipeline/refiner_utils.py:127-132).
+ * Restated from the published operator (torchvision/csrc/ops/cpu/roi_align_kernel.cpp); torchvision itself is not
+ * available in this image, so this piece of the oracle is "parity unpinned" and held by known-answer tests only. */
+static float fpo_roi_bilinear(const float* in, int H, int W, float y, float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return w1 * in[y_low * W + x_low] + w2 * in[y_low * W + x_high] + w3 * in[y_high * W + x_low] + w4 * in[y_high * W + x_high];
+}
+
+int fpo_roi_align(const float* images, int n_img, int C, int H, int W, const float* rois, int n, int PH, int PW, int sampling,
+                  float spatial_scale, float* out) {
+    (void)n_img;
+    for (int r = 0; r < n; ++r) {
+        const float* roi = rois + (size_t)r * 5;
+        const int b = (int)roi[0];
+        const float roi_start_w = roi[1] * spatial_scale, roi_start_h = roi[2] * spatial_scale;
+        const float roi_end_w = roi[3] * spatial_scale, roi_end_h = roi[4] * spatial_scale;
+        const float roi_w = fmaxf(roi_end_w - roi_start_w, 1.0f), roi_h = fmaxf(roi_end_h - roi_start_h, 1.0f);
+        const float bin_h = roi_h / (float)PH, bin_w = roi_w / (float)PW;
+        const int grid_h = sampling > 0 ? sampling : (int)ceilf(roi_h / (float)PH);
+        const int grid_w = sampling > 0 ? sampling : (int)ceilf(roi_w / (float)PW);
+        const int cnt_i = grid_h * grid_w > 1 ? grid_h * grid_w : 1;
+        const float count = (float)cnt_i;
+        for (int c = 0; c < C; ++c) {
+            const float* in = images + ((size_t)b * C + c) * H * W;
+            for (int ph = 0; ph < PH; ++ph)
+                for (int pw = 0; pw < PW; ++pw) {
+                    float acc = 0.f;
+                    for (int iy = 0; iy < grid_h; ++iy) {
+                        const float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)grid_h;
+                        for (int ix = 0; ix < grid_w; ++ix) {
+                            const float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)grid_w;
+                            acc += fpo_roi_bilinear(in, H, W, y, x);
+                        }
+                    }
+                    out[(((size_t)r * C + c) * PH + ph) * PW + pw] = acc / count;
+                }
+        }
+    }
+    return 0;
 }

@@ -184,7 +184,18 @@ def depth_extents(depth: np.ndarray, fx, fy, cx, cy) -> np.ndarray:
     return out
 
 
-def rasterize(verts, faces, colors, poses, scale, fx, fy, cx, cy, W, H):
+def roi_align(images: np.ndarray, rois: np.ndarray, ph: int, pw: int, sampling_ratio: int = 2, spatial_scale: float = 1.0) -> np.ndarray:
+    """torchvision.ops.roi_align(..., aligned=False) restated (parity unpinned: torchvision is absent here)"""
+    img = np.ascontiguousarray(images, dtype=np.float32)
+    r = np.ascontiguousarray(rois, dtype=np.float32).reshape(-1, 5)
+    N, Cc, H, W = img.shape
+    out = np.empty((r.shape[0], Cc, ph, pw), dtype=np.float32)
+    lib().fpo_roi_align(_p(img), C.c_int(N), C.c_int(Cc), C.c_int(H), C.c_int(W), _p(r), C.c_int(r.shape[0]), C.c_int(ph),
+                        C.c_int(pw), C.c_int(sampling_ratio), C.c_float(spatial_scale), _p(out))
+    return out
+
+
+def rasterize(verts, faces, colors, poses, scale, fx, fy, cx, cy, W, H, ambient: float = 2.0):
     v = np.ascontiguousarray(verts, dtype=np.float32)
     f = np.ascontiguousarray(faces, dtype=np.int32)
     c = None if colors is None else np.ascontiguousarray(colors[:, :3], dtype=np.uint8)
@@ -192,6 +203,7 @@ def rasterize(verts, faces, colors, poses, scale, fx, fy, cx, cy, W, H):
     Hn = p.shape[0]
     rgb = np.empty((Hn, H, W, 3), dtype=np.uint8)
     depth = np.empty((Hn, H, W), dtype=np.float32)
-    lib().fpo_rasterize(_p(v), C.c_int(v.shape[0]), _p(f), C.c_int(f.shape[0]), _p(c), _p(p), C.c_int(Hn), C.c_float(scale),
-                        C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_int(W), C.c_int(H), _p(rgb), _p(depth))
+    lib().fpo_rasterize_amb(_p(v), C.c_int(v.shape[0]), _p(f), C.c_int(f.shape[0]), _p(c), _p(p), C.c_int(Hn), C.c_float(scale),
+                            C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_int(W), C.c_int(H), _p(rgb), _p(depth),
+                            C.c_float(ambient))
     return rgb, depth

@@ -1,0 +1,79 @@
+"""SURVEY §8(f)-3 host pieces and oracle restatements that need no GPU: RoIAlign (torchvision semantics), OpenCV bicubic
+resize, the crop / intrinsics arithmetic of refiner_utils and the confidence threshold.  torchvision and cv2 are not
+installable here, so these two restatements are held by known answers (parity unpinned)."""
+import numpy as np
+import torch
+
+from oracle import fp_oracle as fo
+
+
+def _ramp(H, W, a=0.3, b=0.7, c=2.0):
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    return (a * xx + b * yy + c)[None, None].astype(np.float32)
+
+
+def test_roi_align_is_exact_on_linear_images():
+    """bilinear sampling reproduces a linear function exactly and the sampling grid is symmetric in the bin, so the output is
+    the function at the bin centre"""
+    img = _ramp(40, 50)
+    rois = np.array([[0, 5.0, 4.0, 25.0, 20.0], [0, 2.5, 3.25, 40.0, 30.5]], dtype=np.float32)
+    for sampling in (2, 0, 3):
+        out = fo.roi_align(img, rois, 8, 10, sampling)
+        for r, (_, x1, y1, x2, y2) in enumerate(rois):
+            bw, bh = (x2 - x1) / 10, (y2 - y1) / 8
+            ex = 0.3 * (x1 + (np.arange(10) + 0.5) * bw)[None, :] + 0.7 * (y1 + (np.arange(8) + 0.5) * bh)[:, None] + 2.0
+            assert np.abs(out[r, 0] - ex).max() < 2e-5
+
+
+def test_roi_align_borders_and_minimum_size():
+    img = np.ones((1, 2, 16, 16), dtype=np.float32)
+    out = fo.roi_align(img, np.array([[0, -40.0, -40.0, -20.0, -20.0]], dtype=np.float32), 4, 4, 2)
+    assert (out == 0).all()                                       # samples further than one pixel outside contribute zero
+    out = fo.roi_align(img, np.array([[0, 3.0, 3.0, 3.0, 3.0]], dtype=np.float32), 4, 4, 2)
+    assert np.allclose(out, 1.0)                                  # aligned=False: a degenerate RoI is widened to 1x1
+    half = fo.roi_align(img, np.array([[0, -8.0, 0.0, 8.0, 16.0]], dtype=np.float32), 1, 2, 2)
+    assert half[0, 0, 0, 0] < 0.3 and np.isclose(half[0, 0, 0, 1], 1.0)   # left half of the RoI hangs out of the image
+    two = np.stack([np.zeros((1, 8, 8), np.float32), np.ones((1, 8, 8), np.float32)])
+    out = fo.roi_align(two, np.array([[1, 1.0, 1.0, 6.0, 6.0], [0, 1.0, 1.0, 6.0, 6.0]], dtype=np.float32), 3, 3, 2)
+    assert np.allclose(out[0], 1.0) and np.allclose(out[1], 0.0)  # first RoI column selects the image
+
+
+def test_cubic_resize_known_answers():
+    from freepose_amd.src.pipeline.refiner_utils import _cubic_coeffs, cubic_resize
+    c = _cubic_coeffs(np.array([0.5, 0.0, 0.25], dtype=np.float32))
+    assert np.allclose(c[0], [-0.09375, 0.59375, 0.59375, -0.09375]) and np.allclose(c[1], [0, 1, 0, 0])
+    assert np.allclose(c.sum(-1), 1.0)
+    x = np.random.default_rng(0).random((37, 37)).astype(np.float32)
+    assert np.array_equal(cubic_resize(x, (37, 37)), x)           # scale 1: taps (0,1,0,0)
+    assert np.allclose(cubic_resize(np.full((518, 518), 0.7, np.float32), (37, 37)), 0.7, atol=1e-6)
+    m = np.zeros((518, 518), np.float32)
+    m[140:420, 70:350] = 1                                        # block-aligned square: 20 x 20 patches of 14 px
+    r = cubic_resize(m, (37, 37)) > 0.5
+    assert r.sum() == 400 and r[10:30, 5:25].all()
+    # 14x decimation reads the 4x4 neighbourhood of the patch centre: a centre-only blob survives, a corner blob does not
+    m = np.zeros((518, 518), np.float32)
+    m[14 * 3 + 5:14 * 3 + 9, 14 * 4 + 5:14 * 4 + 9] = 1
+    m[14 * 8:14 * 8 + 3, 14 * 9:14 * 9 + 3] = 1
+    r = cubic_resize(m, (37, 37)) > 0.5
+    assert r[3, 4] and not r[8, 9]
+
+
+def test_crop_box_and_intrinsics_arithmetic():
+    from freepose_amd.src.pipeline import refiner_utils as ru
+    K = torch.tensor([[600.0, 0, 320.0], [0, 600.0, 240.0], [0, 0, 1]])
+    # whole 518x518 frame as the crop: focal lengths unchanged, principal point shifted by the reference's -0.5 convention
+    nk = ru.update_K_with_crop(K, torch.tensor([[0.0, 0.0, 518.0, 518.0]]), 518, 518)[0]
+    assert torch.allclose(nk[0, 0], torch.tensor(600.0)) and torch.allclose(nk[0, 2], torch.tensor(319.5))
+    # a half-size crop doubles the focal length and maps the crop centre to the render centre
+    nk = ru.update_K_with_crop(K, torch.tensor([[190.5, 110.5, 449.5, 369.5]]), 518, 518)[0]
+    assert torch.allclose(nk[0, 0], torch.tensor(1200.0)) and torch.allclose(nk[1, 1], torch.tensor(1200.0))
+    assert abs(float(nk[0, 2]) - 258.5) < 1.01 and abs(float(nk[1, 2]) - 258.5) < 1.01
+
+
+def test_confidence_threshold_is_the_top_quantile_bin_edge():
+    from freepose_amd.src.pipeline.estimators.tracking_refiner import TrackingRefiner
+    tr = TrackingRefiner.__new__(TrackingRefiner)                 # no ViT needed for the host-side statistic
+    sims = np.concatenate([np.linspace(0.01, 1.0, 1000), -np.ones(50), np.zeros(50)]).reshape(11, 100)
+    thr = tr._get_threshold_for_confidence(sims, top_quantile=0.2)
+    assert 0.78 <= thr <= 0.81
+    assert abs((sims > thr).sum() / 1000 - 0.2) < 0.03

@@ -47,12 +47,16 @@ class TrackingRefiner:
         rgb, depth = ops.rasterize(self._device_mesh(mesh), pose, 1.0, K[0, 0], K[1, 1], K[0, 2], K[1, 2], width, height)
         return rgb[0], depth[0]
 
-    def _crop_image(self, mesh, image, K, transform):
+    @staticmethod
+    def _sample_points(mesh) -> torch.Tensor:
+        """100 homogeneous object points: the reference seeds the global NumPy generator with 42 and draws vertex indices
+        with np.random.choice (:45-48); the same legacy stream without the global side effect"""
         vertices = np.asarray(mesh.vertices)
-        # the reference seeds the global NumPy generator with 42 and draws 100 vertex indices (:45-47); the same legacy
-        # stream without the global side effect
         pick = np.random.RandomState(42).choice(np.arange(len(vertices)), 100)
-        vertices = torch.from_numpy(np.pad(vertices[pick], ((0, 0), (0, 1)), constant_values=1.).copy()).float()
+        return torch.from_numpy(np.pad(vertices[pick], ((0, 0), (0, 1)), constant_values=1.).copy()).float()
+
+    def _crop_image(self, mesh, image, K, transform):
+        vertices = self._sample_points(mesh)
         image = refiner_utils.MaybeToTensor()(image)
         K = torch.from_numpy(np.asarray(K)).view(3, 3).float()
         transform = torch.from_numpy(np.asarray(transform)).view(1, 4, 4).float()

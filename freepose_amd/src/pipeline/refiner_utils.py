@@ -37,10 +37,10 @@ def pil2torch(pic) -> torch.Tensor:
     return (t - mean) / std
 
 
-def crop_image(image, Ts, points, K, render_width, render_height, lamb=1.4):
-    """refiner_utils.py:92-132 — project the object points, take a centre-symmetric box of the render's aspect ratio
-    enlarged by `lamb`, and RoIAlign the image to (render_height, render_width)."""
-    assert len(image.shape) == 3 and image.shape[0] in [1, 3, 4] and image.dtype == torch.float32
+def crop_boxes(Ts, points, K, render_width, render_height, lamb=1.4):
+    """the box arithmetic of crop_image (refiner_utils.py:98-122): project the object points, take the box that is symmetric
+    about the projected object centre, has the render's aspect ratio and is enlarged by `lamb`.  float32 torch expressions in
+    the reference's order (pinned bit for bit by tests/golden/refiner.npz)."""
     assert Ts.shape[1:] == torch.Size([4, 4])
     assert points.shape[1:] == torch.Size([4])
     assert K.shape == torch.Size([3, 3])
@@ -57,7 +57,14 @@ def crop_image(image, Ts, points, K, render_width, render_height, lamb=1.4):
     height = torch.max(xdists / r, ydists) * 2 * lamb
     x1, y1 = centers_uv[:, 0] - width / 2, centers_uv[:, 1] - height / 2
     x2, y2 = centers_uv[:, 0] + width / 2, centers_uv[:, 1] + height / 2
-    bboxes = torch.stack([x1, y1, x2, y2], dim=1)
+    return torch.stack([x1, y1, x2, y2], dim=1)
+
+
+def crop_image(image, Ts, points, K, render_width, render_height, lamb=1.4):
+    """refiner_utils.py:92-132 — crop_boxes, then RoIAlign (sampling_ratio 2) of the image to (render_height, render_width)
+    on the device"""
+    assert len(image.shape) == 3 and image.shape[0] in [1, 3, 4] and image.dtype == torch.float32
+    bboxes = crop_boxes(Ts, points, K, render_width, render_height, lamb)
     rois = torch.cat([torch.zeros((len(bboxes), 1)), bboxes], 1)
     crops = ops.roi_align(image.unsqueeze(0), rois, (render_height, render_width), sampling_ratio=2)
     return crops, bboxes

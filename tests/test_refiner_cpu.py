@@ -77,3 +77,29 @@ def test_confidence_threshold_is_the_top_quantile_bin_edge():
     thr = tr._get_threshold_for_confidence(sims, top_quantile=0.2)
     assert 0.78 <= thr <= 0.81
     assert abs((sims > thr).sum() / 1000 - 0.2) < 0.03
+
+
+def test_refiner_host_arithmetic_matches_the_reference(golden_dir):
+    """tests/golden/refiner.npz was produced by the reference's own TrackingRefiner._crop_image /
+    refiner_utils.update_K_with_crop / _get_threshold_for_confidence (oracle/gen_golden_refiner.py): the sampled object points,
+    crop boxes, RoIs handed to roi_align, cropped intrinsics and thresholds must match bit for bit."""
+    import types
+
+    from freepose_amd.src.pipeline import refiner_utils as ru
+    from freepose_amd.src.pipeline.estimators.tracking_refiner import TrackingRefiner
+    g = np.load(golden_dir / "refiner.npz")
+    mesh = types.SimpleNamespace(vertices=g["verts"])
+    pts = TrackingRefiner._sample_points(mesh)
+    expect = np.pad(g["verts"][g["pick"]], ((0, 0), (0, 1)), constant_values=1.0).astype(np.float32)
+    assert np.array_equal(pts.numpy(), expect)
+    K = torch.from_numpy(g["K"]).view(3, 3).float()
+    for T, bbox, new_K, rois in zip(g["transforms"], g["bboxes"], g["new_K"], g["rois"]):
+        Ts = torch.from_numpy(T).view(1, 4, 4).float()
+        boxes = ru.crop_boxes(Ts, pts, K, 518, 518)
+        assert np.array_equal(boxes.numpy()[0], bbox)
+        assert np.array_equal(torch.cat([torch.zeros((1, 1)), boxes], 1).numpy(), rois)
+        assert np.array_equal(ru.update_K_with_crop(K, boxes, 518, 518).numpy()[0], new_K)
+    assert np.array_equal(ru.update_K_with_crop(K, torch.from_numpy(g["direct_boxes"]), 518, 518).numpy(), g["direct_new_K"])
+    tr = TrackingRefiner.__new__(TrackingRefiner)
+    for q, thr in zip((0.2, 0.05, 0.5), g["thresholds"]):
+        assert float(tr._get_threshold_for_confidence(g["sims"], top_quantile=q)) == float(thr)

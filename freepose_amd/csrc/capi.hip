@@ -25,6 +25,7 @@ extern "C" int fp_set_option(const char* name, int value) {
     FP_REQUIRE(name, "set_option: null name");
     if (!strcmp(name, "gemm_variant")) g_opts[FP_OPT_GEMM_VARIANT] = value;
     else if (!strcmp(name, "attn_slots")) g_opts[FP_OPT_ATTN_SLOTS] = value;
+    else if (!strcmp(name, "raster_tiled")) g_opts[FP_OPT_RASTER_TILED] = value;
     else { fp_set_error("set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
     return FP_OK;
 }

@@ -131,6 +131,8 @@ __device__ __forceinline__ void tri_pixel(const TriSetup& t, int f, int px, int 
     const float d = tri_depth(t, w0, w1, w2, b0, b1, b2);
     if (!(d > 0.f)) return;
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)f;
+    // (a read-before-atomic "cannot win" test was measured here: the scattered 8-byte loads cost more than the L2 atomics
+    //  they save — 2.4 -> 3.5 ms per 576 views — so the atomic is issued unconditionally)
     atomicMin(&zb[(size_t)py * W + px], key);
 }
 
@@ -211,6 +213,144 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __rest
     o[0] = r; o[1] = g; o[2] = b;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tiled path (images up to 704 px, meshes up to 32 768 triangles): the visibility keys of one screen tile live in LDS, so there is no global
+// visibility buffer (no 8 B/pixel clear, no L2 atomics, no resolve read).  Measured reason: the global-buffer path costs
+// 2.4-3.2 ms per 576 x 420^2 views REGARDLESS of the triangle count (1 280 ... 327 680): its triangle kernel is bound by the
+// ~70 M 64-bit L2 atomics (covered pixels x 2 surfaces), 1.44 ms for 1 280 as for 81 920 triangles.
+//   bin kernel : per (view, triangle) the tile range of its clipped pixel bbox as four nibbles (16 bit), and per chunk of 256
+//                consecutive triangles the OR of their tile masks (64 bit, tiles <= 8 x 8)
+//   tile kernel: one workgroup per (view, tile): LDS keys = ~0; chunks whose mask misses the tile are skipped with one
+//                scalar test; a lane whose triangle overlaps the tile rasterises it into LDS with ds_min_u64 — triangles
+//                with more than BIG_TILE_AREA candidate pixels inside the tile are handed to the whole wave (ballot loop);
+//                then the tile's pixels are resolved (same colour / depth arithmetic) and written once.
+// Same tri_setup / tri_cover / tri_depth, same candidate pixel set (bbox ∩ tile over all tiles = bbox), same 64-bit key and
+// an order-independent minimum: the output is bit-identical to the global-buffer path and to the oracle.
+constexpr int BIN_CHUNK = 256;
+constexpr int BIG_TILE_AREA = 48;
+constexpr uint16_t TBOX_NONE = 0x000f;   // tx0 = 15 > tx1 = 0: overlaps nothing
+
+__global__ __launch_bounds__(BIN_CHUNK) void raster_bin_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
+                                                               int V, int F, int W, int Hh, int T,
+                                                               uint16_t* __restrict__ tbox, unsigned long long* __restrict__ cmask) {
+    __shared__ unsigned long long m_s;
+    const int h = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int f = chunk * BIN_CHUNK + threadIdx.x;
+    if (threadIdx.x == 0) m_s = 0ull;
+    __syncthreads();
+    if (f < F) {
+        const TriSetup t = tri_setup(sv_all + (size_t)h * V, faces, f, W, Hh);
+        uint16_t box = TBOX_NONE;
+        if (t.ok) {
+            const int tx0 = t.bx0 / T, ty0 = t.by0 / T, tx1 = t.bx1 / T, ty1 = t.by1 / T;
+            box = (uint16_t)(tx0 | (ty0 << 4) | (tx1 << 8) | (ty1 << 12));
+            unsigned long long m = 0ull;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) m |= 1ull << (ty * 8 + tx);
+            atomicOr(&m_s, m);
+        }
+        tbox[(size_t)h * F + f] = box;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cmask[(size_t)h * nchunk + chunk] = m_s;
+}
+
+__device__ __forceinline__ void tile_pixel(const TriSetup& t, int f, int px, int py, unsigned long long* tile, int X0, int Y0, int T) {
+    long long w0, w1, w2;
+    if (!tri_cover(t, px, py, w0, w1, w2)) return;
+    float b0, b1, b2;
+    const float d = tri_depth(t, w0, w1, w2, b0, b1, b2);
+    if (!(d > 0.f)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)f;
+    unsigned long long* slot = &tile[(py - Y0) * T + (px - X0)];
+    // stored keys only ever decrease, so a plain (possibly stale) read bounds the current value from above: a key that does
+    // not beat it cannot change the slot (LDS reads are cheap; the same test on the global buffer is a loss, see tri_pixel)
+    if (key >= *(volatile unsigned long long*)slot) return;
+    atomicMin(slot, key);
+}
+
+__global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
+                                                          const uint8_t* __restrict__ colors, int V, int F, int W, int Hh, int T,
+                                                          int ntx, const uint16_t* __restrict__ tbox,
+                                                          const unsigned long long* __restrict__ cmask, int nchunk,
+                                                          uint8_t* __restrict__ rgb, float* __restrict__ depth, float ambient) {
+    extern __shared__ unsigned long long tile[];   // [T*T] visibility keys
+    const int h = blockIdx.y;
+    const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
+    const int X0 = tx * T, Y0 = ty * T;
+    const int X1 = min(W - 1, X0 + T - 1), Y1 = min(Hh - 1, Y0 + T - 1);
+    const SVert* sv = sv_all + (size_t)h * V;
+    for (int p = threadIdx.x; p < T * T; p += blockDim.x) tile[p] = ~0ull;
+    __syncthreads();
+    const int tbit = ty * 8 + tx;
+    const int lane = threadIdx.x & 63;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        if (!((cmask[(size_t)h * nchunk + chunk] >> tbit) & 1ull)) continue;   // workgroup-uniform
+        const int f = chunk * BIN_CHUNK + threadIdx.x;
+        bool mine = false, big = false;
+        TriSetup t;
+        int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+        if (f < F) {
+            const unsigned box = tbox[(size_t)h * F + f];
+            const int bx0 = box & 15, by0 = (box >> 4) & 15, bx1 = (box >> 8) & 15, by1 = (box >> 12) & 15;
+            if (bx0 <= tx && tx <= bx1 && by0 <= ty && ty <= by1) {
+                t = tri_setup(sv, faces, f, W, Hh);
+                x0 = max(t.bx0, X0); y0 = max(t.by0, Y0); x1 = min(t.bx1, X1); y1 = min(t.by1, Y1);
+                mine = t.ok && x0 <= x1 && y0 <= y1;
+                big = mine && (x1 - x0 + 1) * (y1 - y0 + 1) > BIG_TILE_AREA;
+            }
+        }
+        if (mine && !big)
+            for (int py = y0; py <= y1; ++py)
+                for (int px = x0; px <= x1; ++px) tile_pixel(t, f, px, py, tile, X0, Y0, T);
+        // triangles with many candidate pixels in this tile: the whole wave strides over them, one triangle at a time
+        unsigned long long bm = __ballot(big);
+        while (bm) {
+            const int src = __ffsll((long long)bm) - 1;
+            bm &= bm - 1;
+            const int fb = __shfl(f, src, 64);
+            const TriSetup tb = tri_setup(sv, faces, fb, W, Hh);
+            const int ax0 = max(tb.bx0, X0), ay0 = max(tb.by0, Y0), ax1 = min(tb.bx1, X1), ay1 = min(tb.by1, Y1);
+            const int bw = ax1 - ax0 + 1, n = bw * (ay1 - ay0 + 1);
+            for (int i = lane; i < n; i += 64) tile_pixel(tb, fb, ax0 + i % bw, ay0 + i / bw, tile, X0, Y0, T);
+        }
+    }
+    __syncthreads();
+    // resolve the tile: same arithmetic as raster_resolve_kernel
+    const int tw = X1 - X0 + 1, th = Y1 - Y0 + 1;
+    for (int p = threadIdx.x; p < tw * th; p += blockDim.x) {
+        const int ly = p / tw, lx = p - ly * tw;
+        const int px = X0 + lx, py = Y0 + ly;
+        const unsigned long long key = tile[ly * T + lx];
+        float d = 0.f;
+        uint8_t r = 0, g = 0, b = 0;
+        if (key != ~0ull) {
+            const int f = (int)(unsigned)(key & 0xffffffffu);
+            d = __uint_as_float((unsigned)(key >> 32));
+            const TriSetup t = tri_setup(sv, faces, f, W, Hh);
+            long long w0, w1, w2;
+            tri_cover(t, px, py, w0, w1, w2);
+            float b0, b1, b2;
+            const float dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
+            const float q0 = b0 * t.iz0, q1 = b1 * t.iz1, q2 = b2 * t.iz2;
+            uint8_t out[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float c0 = 255.f, c1 = 255.f, c2 = 255.f;
+                if (colors) { c0 = (float)colors[4 * t.i0 + c]; c1 = (float)colors[4 * t.i1 + c]; c2 = (float)colors[4 * t.i2 + c]; }
+                const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
+                const float amb = fminf(ambient * cv + 0.5f, 255.0f);
+                out[c] = (uint8_t)fmaxf(amb, 0.f);
+            }
+            r = out[0]; g = out[1]; b = out[2];
+        }
+        const size_t pix = (size_t)h * W * Hh + (size_t)py * W + px;
+        depth[pix] = d;
+        uint8_t* o = rgb + pix * 3;
+        o[0] = r; o[1] = g; o[2] = b;
+    }
+}
+
 }  // namespace
 
 extern "C" int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F,
@@ -249,19 +389,50 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
     hipStream_t s = (hipStream_t)stream;
     const int V = mesh->V, F = mesh->F;
     SVert* sv;
+    int rc;
+    if ((rc = ctx->get("raster.sv", (size_t)Hn * V * sizeof(SVert), (void**)&sv))) return rc;
+    hipLaunchKernelGGL(raster_vertex_kernel, dim3(cdiv(V, 256), Hn), dim3(256), 0, s, mesh->verts, V, d_poses, Hn, scale,
+                       fx, fy, cx, cy, sv);
+    FP_LAUNCH_CHECK();
+
+    // tile edge: 64 px up to 512-px images, else the smallest multiple of 8 that covers the image with 8 x 8 tiles
+    const int side = W > Hh ? W : Hh;
+    const int T = side <= 512 ? 64 : (cdiv(side, 8) + 7) / 8 * 8;
+    static int env_tiled = [] { const char* e = getenv("FP_RASTER_TILED"); return e ? atoi(e) : 2; }();
+    // measured crossover (576 views, 420^2, profiles/r01_ab.md): tiled 1.7-2.2 ms vs 2.4-2.8 up to 20 k triangles, 2.8 vs 2.3 at
+    // 82 k, 7.6 vs 2.9 at 328 k — with ~1-pixel triangles set-up dominates and the tiled path does it twice (bin + tile).
+    // option: -1/unset = choose by triangle count, 0 = global visibility buffer, 1 = tiled
+    const int mode = fp_opt_get(FP_OPT_RASTER_TILED, env_tiled);
+    const bool tiled = T <= 88 && (mode == 1 || (mode != 0 && F <= 32768));
+    if (tiled) {
+        const int ntx = cdiv(W, T), nty = cdiv(Hh, T), nchunk = cdiv(F, BIN_CHUNK);
+        uint16_t* tbox;
+        unsigned long long* cmask;
+        if ((rc = ctx->get("raster.tbox", (size_t)Hn * F * 2, (void**)&tbox))) return rc;
+        if ((rc = ctx->get("raster.cmask", (size_t)Hn * nchunk * 8, (void**)&cmask))) return rc;
+        hipLaunchKernelGGL(raster_bin_kernel, dim3(nchunk, Hn), dim3(BIN_CHUNK), 0, s, sv, mesh->faces, V, F, W, Hh, T, tbox, cmask);
+        FP_LAUNCH_CHECK();
+        const size_t lds = (size_t)T * T * 8;
+        static bool attr_set = false;
+        if (!attr_set) {
+            FP_HIP(hipFuncSetAttribute((const void*)raster_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 88 * 8));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(raster_tile_kernel, dim3(ntx * nty, Hn), dim3(256), lds, s, sv, mesh->faces, mesh->colors, V, F, W,
+                           Hh, T, ntx, tbox, cmask, nchunk, d_rgb, d_depth, mesh->ambient);
+        FP_LAUNCH_CHECK();
+        return FP_OK;
+    }
+
+    // global visibility-buffer path (large images; A/B reference)
     unsigned long long* zb;
     int* queue;
-    int rc;
     const int qcap = 1 << 20;
-    if ((rc = ctx->get("raster.sv", (size_t)Hn * V * sizeof(SVert), (void**)&sv))) return rc;
     if ((rc = ctx->get("raster.zb", (size_t)Hn * W * Hh * 8, (void**)&zb))) return rc;
     if ((rc = ctx->get("raster.queue", (size_t)qcap * 8 + 64, (void**)&queue))) return rc;
     int* qcount = queue + 2 * qcap;
     FP_HIP(hipMemsetAsync(zb, 0xff, (size_t)Hn * W * Hh * 8, s));
     FP_HIP(hipMemsetAsync(qcount, 0, 4, s));
-    hipLaunchKernelGGL(raster_vertex_kernel, dim3(cdiv(V, 256), Hn), dim3(256), 0, s, mesh->verts, V, d_poses, Hn, scale,
-                       fx, fy, cx, cy, sv);
-    FP_LAUNCH_CHECK();
     hipLaunchKernelGGL(raster_tri_kernel, dim3(cdiv(F, 256), Hn), dim3(256), 0, s, sv, mesh->faces, V, F, W, Hh, zb,
                        queue, qcount, qcap);
     FP_LAUNCH_CHECK();

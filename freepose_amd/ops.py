@@ -28,7 +28,7 @@ def context(device: Optional[int] = None):
 
 
 def set_option(name: str, value: int):
-    """experiment toggle (A/B measurements): 'gemm_variant', 'attn_slots'; value < 0 restores the default"""
+    """experiment toggle (A/B measurements): 'gemm_variant', 'attn_slots', 'raster_tiled'; value < 0 restores the default"""
     check(_lib.load().fp_set_option(name.encode(), int(value)), "fp_set_option")
 
 

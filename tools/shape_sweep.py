@@ -27,9 +27,14 @@ def main():
     for sub in (3, 4, 5, 6, 7):
         v, f, c = bench.synthetic_mesh(sub)
         m = ops.Mesh(v, f, c)
-        ms = timeit(lambda: ops.rasterize(m, poses, 0.25, 600, 600, 210, 210, 420, 420))
-        print(f"raster 576 views 420^2, {len(f):7d} triangles: {ms:7.2f} ms  ({576 * len(f) / ms / 1e6:6.1f} G tri/s, "
-              f"{576 * 420 * 420 * 7 / ms / 1e6:6.0f} GB/s of mandatory writes)", flush=True)
+        res = []
+        for tiled in (1, 0):
+            ops.set_option("raster_tiled", tiled)
+            res.append(timeit(lambda: ops.rasterize(m, poses, 0.25, 600, 600, 210, 210, 420, 420)))
+        ops.set_option("raster_tiled", -1)
+        ms = res[0]
+        print(f"raster 576 views 420^2, {len(f):7d} triangles: tiled {ms:6.2f} ms ({576 * len(f) / ms / 1e6:6.1f} G tri/s, "
+              f"{576 * 420 * 420 * 7 / ms / 1e6:5.0f} GB/s of mandatory writes) | global visibility buffer {res[1]:6.2f} ms", flush=True)
     vit = ops.ViT("dinov2_vitl14_reg", seed=0)
     for (B, H) in ((256, 420), (192, 518), (64, 518), (8, 518), (1, 518)):
         x = torch.rand((B, 3, H, H)).to(torch.bfloat16).cuda()

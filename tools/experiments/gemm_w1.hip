@@ -1,4 +1,6 @@
-// One-wave-per-SIMD bf16 MFMA GEMM (gfx950).  Same math / operand layout / fused epilogues as gemm_bf16.hip.
+// ARCHIVED EXPERIMENT (not built into the library; result in profiles/r01_ab.md): one-wave-per-SIMD bf16 MFMA GEMM (gfx950).
+// Same math / operand layout / fused epilogues as gemm_bf16.hip.  Build check:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I freepose_amd/csrc -c tools/experiments/gemm_w1.hip -o /dev/null
 //
 // Why: the 8-wave 256x256 kernels are bound by operand supply through LDS (profiles/r01_ab.md: 0 bank conflicts, ~50 %
 // MFMA-busy; the DMA fill alone takes ~80 % of the loop time and three different wave schedules converge).  The only
@@ -145,12 +147,13 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_w1_kernel(FpGemmArgs p) {
         else          { if (d) step_body(j, frB, frA, T{}, T{}); else if (m) step_body(j, frB, frA, F{}, T{}); else step_body(j, frB, frA, F{}, F{}); }
     }
 
-    fp_gemm::epilogue<BM, BN, WM, WN, EPI, 4, TM, TN>(p, acc, m0, n0, wm, wn, li, lg);
+    fp_gemm::epilogue<BM, BN, WM, WN, EPI, 4, TM, TN>(p, acc, m0, n0, wm, wn, li, lg,
+                                                     smem + NST * STG + wave * fp_gemm::EPI_STAGE_BYTES);
 }
 
 template <int EPI>
 int launch_w1(const FpGemmArgs& a, hipStream_t stream) {
-    constexpr int SMEM = NST * STG;
+    constexpr int SMEM = NST * STG + NW * fp_gemm::EPI_STAGE_BYTES;
     auto kern = gemm_w1_kernel<EPI>;
     static bool attr_set = false;
     if (!attr_set) {

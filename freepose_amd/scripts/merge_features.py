@@ -8,31 +8,44 @@ from __future__ import annotations
 
 import argparse
 from pathlib import Path
+from typing import Iterable, List, Optional, Tuple
 
 import numpy as np
 
+DATA = Path("data")
+
+
+def bank_row(path: Path) -> Optional[np.ndarray]:
+    """mean descriptor of one mesh, or None (with the reference's console message) when the file is missing or has NaNs"""
+    if not path.exists():
+        print(f"Feature {path} does not exist")
+        return None
+    row = np.load(path).mean(axis=0)
+    if np.isnan(row).any():
+        print(f"Feature {path} contains NaNs")
+        return None
+    return row
+
+
+def collect(folder: Path, mesh_ids: Iterable[str]) -> Tuple[np.ndarray, List[str]]:
+    kept, rows = [], []
+    for mesh_id in mesh_ids:
+        row = bank_row(folder / f"{mesh_id}.npy")
+        if row is not None:
+            kept.append(mesh_id)
+            rows.append(row)
+    return np.stack(rows, axis=0), kept
+
 
 def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--features_folder", type=str, default="objaverse_features_ffa_22")
-    ap.add_argument("--filelist", type=str, default="mesh_cache.txt")
-    args = ap.parse_args(argv)
-    folder = Path("data/datasets/").resolve() / args.features_folder
-    ids = Path(f"data/{args.filelist}").read_text(encoding="utf-8").splitlines()
-    rows, kept = [], []
-    for mesh_id in ids:
-        f = folder / f"{mesh_id}.npy"
-        if not f.exists():
-            print(f"Feature {f} does not exist")
-            continue
-        row = np.mean(np.load(f), axis=0)
-        if np.isnan(row).any():
-            print(f"Feature {f} contains NaNs")
-            continue
-        rows.append(row)
-        kept.append(mesh_id)
-    np.save(f"data/{args.features_folder}.npy", np.stack(rows, axis=0))
-    Path(f"data/{args.features_folder}.ids.txt").write_text("\n".join(kept) + "\n")
+    cli = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    cli.add_argument("--features_folder", type=str, default="objaverse_features_ffa_22")
+    cli.add_argument("--filelist", type=str, default="mesh_cache.txt")
+    opt = cli.parse_args(argv)
+    mesh_ids = (DATA / opt.filelist).read_text(encoding="utf-8").splitlines()
+    bank, kept = collect((DATA / "datasets").resolve() / opt.features_folder, mesh_ids)
+    np.save(DATA / f"{opt.features_folder}.npy", bank)
+    (DATA / f"{opt.features_folder}.ids.txt").write_text("\n".join(kept) + "\n")
 
 
 if __name__ == "__main__":

@@ -66,16 +66,18 @@ class TrackingRefiner:
 
     # ---- confidence ------------------------------------------------------------------------------------------------
     def _get_threshold_for_confidence(self, similarity_matrices, top_quantile=0.2):
-        """value above which the top `top_quantile` of the positive similarities lie, on a 50-bin histogram (:60-68)"""
-        counts, values = np.histogram(similarity_matrices[similarity_matrices > 0], bins=50)
-        cutoff_value = counts.sum() * top_quantile
-        cum_ = 0
-        v = values[0]
-        for c, v in zip(counts[::-1], values[:-1][::-1]):
-            cum_ += c
-            if cum_ > cutoff_value:
+        """lower edge of the histogram bin (50 bins over the positive similarities) at which the mass counted from the top
+        first exceeds `top_quantile` of the total (tracking_refiner.py:60-68)"""
+        counts, edges = np.histogram(similarity_matrices[similarity_matrices > 0], bins=50)
+        budget = counts.sum() * top_quantile
+        seen = 0
+        edge = edges[0]
+        for k in range(len(counts) - 1, -1, -1):
+            seen += counts[k]
+            edge = edges[k]
+            if seen > budget:
                 break
-        return v
+        return edge
 
     def _patch_features(self, chw_01: torch.Tensor) -> torch.Tensor:
         """x_norm_patchtokens of one image in [0,1] (ImageNet normalisation happens inside the ViT's im2col kernel)"""

@@ -37,27 +37,28 @@ def pil2torch(pic) -> torch.Tensor:
     return (t - mean) / std
 
 
+def _project(points_h: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
+    """pixel coordinates of homogeneous points [n,4] under the 3x4 projections P [B,3,4]; depth clamped at 1 cm"""
+    cam = torch.matmul(points_h.unsqueeze(0), P.permute(0, 2, 1))              # [B,n,3]
+    return cam[:, :, :2] / torch.maximum(cam[:, :, [2]], torch.tensor(0.01))
+
+
 def crop_boxes(Ts, points, K, render_width, render_height, lamb=1.4):
-    """the box arithmetic of crop_image (refiner_utils.py:98-122): project the object points, take the box that is symmetric
-    about the projected object centre, has the render's aspect ratio and is enlarged by `lamb`.  float32 torch expressions in
-    the reference's order (pinned bit for bit by tests/golden/refiner.npz)."""
-    assert Ts.shape[1:] == torch.Size([4, 4])
-    assert points.shape[1:] == torch.Size([4])
-    assert K.shape == torch.Size([3, 3])
-    T = torch.matmul(torch.nn.functional.pad(K, (0, 1, 0, 0), value=0.).unsqueeze(0), Ts)
-    points_transformed = torch.matmul(points.unsqueeze(0), T.permute(0, 2, 1))
-    uv = points_transformed[:, :, :2] / torch.maximum(points_transformed[:, :, [2]], torch.tensor(0.01))
-    bboxes = torch.cat([uv.min(dim=1).values, uv.max(dim=1).values], dim=1)
-    centers_transformed = torch.matmul(torch.mean(points, dim=0, keepdim=True).unsqueeze(0), T.permute(0, 2, 1)).squeeze(1)
-    centers_uv = centers_transformed[:, :2] / torch.maximum(centers_transformed[:, [2]], torch.tensor(0.01))
-    dists = torch.maximum((bboxes[:, [0, 1]] - centers_uv).abs_(), (bboxes[:, [2, 3]] - centers_uv).abs_())
-    xdists, ydists = dists[:, 0], dists[:, 1]
-    r = render_width / render_height
-    width = torch.max(xdists, ydists * r) * 2 * lamb
-    height = torch.max(xdists / r, ydists) * 2 * lamb
-    x1, y1 = centers_uv[:, 0] - width / 2, centers_uv[:, 1] - height / 2
-    x2, y2 = centers_uv[:, 0] + width / 2, centers_uv[:, 1] + height / 2
-    return torch.stack([x1, y1, x2, y2], dim=1)
+    """Crop box per pose, as the reference's crop_image derives it (refiner_utils.py:98-122): centred on the projection of
+    the points' centroid, just large enough for every projected point, shaped like the render, scaled by `lamb`.
+    float32 throughout, same operation order as the reference (pinned bit for bit by tests/golden/refiner.npz)."""
+    assert Ts.shape[1:] == torch.Size([4, 4]) and points.shape[1:] == torch.Size([4]) and K.shape == torch.Size([3, 3])
+    P = torch.matmul(torch.nn.functional.pad(K, (0, 1, 0, 0), value=0.).unsqueeze(0), Ts)     # K [I|0] T  -> [B,3,4]
+    uv = _project(points, P)
+    lo_hi = torch.cat([uv.min(dim=1).values, uv.max(dim=1).values], dim=1)                    # [B,4] = umin,vmin,umax,vmax
+    centre = _project(torch.mean(points, dim=0, keepdim=True), P).squeeze(1)                  # [B,2]
+    reach = torch.maximum((lo_hi[:, [0, 1]] - centre).abs_(), (lo_hi[:, [2, 3]] - centre).abs_())
+    reach_x, reach_y = reach[:, 0], reach[:, 1]
+    aspect = render_width / render_height
+    box_w = torch.max(reach_x, reach_y * aspect) * 2 * lamb
+    box_h = torch.max(reach_x / aspect, reach_y) * 2 * lamb
+    half_w, half_h = box_w / 2, box_h / 2
+    return torch.stack([centre[:, 0] - half_w, centre[:, 1] - half_h, centre[:, 0] + half_w, centre[:, 1] + half_h], dim=1)
 
 
 def crop_image(image, Ts, points, K, render_width, render_height, lamb=1.4):
@@ -71,27 +72,21 @@ def crop_image(image, Ts, points, K, render_width, render_height, lamb=1.4):
 
 
 def update_K_with_crop(K, bboxes, render_width, render_height):
-    """refiner_utils.py:135-170 (skew is not handled, as in the reference)"""
-    assert K.shape == torch.Size([3, 3])
-    assert bboxes.shape[1:] == torch.Size([4])
-    new_K = K.unsqueeze(0).repeat(len(bboxes), 1, 1)
-    crop_width = bboxes[:, 2] - bboxes[:, 0]
-    crop_height = bboxes[:, 3] - bboxes[:, 1]
-    crop_cx = (bboxes[:, 0] + bboxes[:, 2]) / 2
-    crop_cy = (bboxes[:, 1] + bboxes[:, 3]) / 2
-    cx = K[0, 2] + (crop_width - 1) / 2 - crop_cx
-    cy = K[1, 2] + (crop_height - 1) / 2 - crop_cy
-    center_x = (crop_width - 1) / 2
-    center_y = (crop_height - 1) / 2
-    orig_cx_diff = cx - center_x
-    orig_cy_diff = cy - center_y
-    scale_x = render_width / crop_width
-    scale_y = render_height / crop_height
-    new_K[:, 0, 0] = scale_x * K[0, 0]
-    new_K[:, 1, 1] = scale_y * K[1, 1]
-    new_K[:, 0, 2] = (render_width - 1) / 2 + scale_x * orig_cx_diff
-    new_K[:, 1, 2] = (render_height - 1) / 2 + scale_y * orig_cy_diff
-    return new_K
+    """Intrinsics of the crop `bboxes` [B,4] (x1,y1,x2,y2) resampled to render_width x render_height, following the
+    reference's convention (refiner_utils.py:135-170: pixel centres at integers, crop centre (w-1)/2, skew ignored)."""
+    assert K.shape == torch.Size([3, 3]) and bboxes.shape[1:] == torch.Size([4])
+    out = K.unsqueeze(0).repeat(len(bboxes), 1, 1)
+    w, h = bboxes[:, 2] - bboxes[:, 0], bboxes[:, 3] - bboxes[:, 1]
+    mid_x, mid_y = (bboxes[:, 0] + bboxes[:, 2]) / 2, (bboxes[:, 1] + bboxes[:, 3]) / 2
+    # principal point inside the (unscaled) crop, then its offset from the crop centre
+    off_x = (K[0, 2] + (w - 1) / 2 - mid_x) - (w - 1) / 2
+    off_y = (K[1, 2] + (h - 1) / 2 - mid_y) - (h - 1) / 2
+    sx, sy = render_width / w, render_height / h
+    out[:, 0, 0] = sx * K[0, 0]
+    out[:, 1, 1] = sy * K[1, 1]
+    out[:, 0, 2] = (render_width - 1) / 2 + sx * off_x
+    out[:, 1, 2] = (render_height - 1) / 2 + sy * off_y
+    return out
 
 
 def _cubic_coeffs(x: np.ndarray, A: float = -0.75) -> np.ndarray:

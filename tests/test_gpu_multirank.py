@@ -1,0 +1,29 @@
+"""The driver's multi-GPU launch shape (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) on a
+single-GPU box: two ranks share the device through the gloo backend (FP_DIST_BACKEND), which exercises the whole rank flow —
+process-group init from the environment, proposal sharding, the all-gather of result rows, barriers, the MAX-reduced
+timing and rank-0 reporting.  Throughput is meaningless here; the 8-GPU numbers come from the driver's RCCL run."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ, FP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--hyp", "24",
+           "--bank", "2000", "--mesh-sub", "3", "--vit-batch", "8"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["cpu_baseline"] is None
+    assert out["value"] > 0 and out["config"]["proposals_per_step_per_gpu"] == 1
+    assert out["roofline"]["bound"] == "mfma" and out["roofline"]["achieved"] > 0

@@ -27,3 +27,13 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["cpu_baseline"] is None
     assert out["value"] > 0 and out["config"]["proposals_per_step_per_gpu"] == 1
     assert out["roofline"]["bound"] == "mfma" and out["roofline"]["achieved"] > 0
+
+
+def test_sharded_bank_topk_two_ranks_on_one_gpu():
+    """bank-row sharding with the candidate all-gather and the HIP merge kernel == unsharded scan, on every rank"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29562", str(ROOT / "tests" / "_multirank_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert "MULTIRANK_BANK_OK 2" in r.stdout

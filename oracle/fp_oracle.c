@@ -8,6 +8,14 @@
  * file FIXES one order — "dot64", below — and the HIP kernels implement the same order, so indices and
  * scores compare bit for bit.  The reference's own bf16 rounding points are kept.
  *
+ * Pinning status (details: DESIGN.md §5):
+ *   pinned by golden vectors produced by the reference's own code here (tests/golden, oracle/gen_golden*.py): crop/resize/pad,
+ *     Proposals, RLE, rotation grids, depth->cloud extents and z, geodesic distance, the estimator's scores, FFA / bank scores
+ *     / top-100 as the reference's torch expressions evaluate them, the TrackingRefiner box / intrinsics / threshold arithmetic;
+ *   PARITY UNPINNED (dependency not installable here, no reference fixtures): the rasteriser vs pyrender/OpenGL (conventions
+ *     restated from renderer.py, held by known-answer tests) and fpo_roi_align vs torchvision.ops.roi_align (restated from
+ *     the published operator, held by known-answer tests).
+ *
  * Build: gcc -O2 -std=c11 -fPIC -shared -ffp-contract=off -o libfp_oracle.so fp_oracle.c -lm
  */
 #include <math.h>

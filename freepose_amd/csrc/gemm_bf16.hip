@@ -272,7 +272,14 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // the default (A/B probing only).
     static int env_var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
     const int var = fp_opt_get(FP_OPT_GEMM_VARIANT, env_var);
-    const bool big = tiles_big >= 192;
+    // The 256x256 kernels run one resident workgroup per CU, so their time goes in whole rounds of `ncu` tiles.  When the last
+    // round would be mostly empty (e.g. 300 tiles on 256 CUs: the ~20-crop batches of the video path) the 128x128 kernel —
+    // ~15-20 % less efficient per flop but 8x finer grained — is faster: measured 0.053 vs 0.068 ms (proj), 0.157 vs 0.192
+    // (fc2), 0.046 vs 0.063 (V) at M = 19 152, while the big tile wins whenever >= ~75 % of its rounds are filled.
+    static int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 8 ? (n & ~7) : 256; }();
+    const long rounds_big = (tiles_big + ncu - 1) / ncu;
+    const bool filled = tiles_big * 4 >= rounds_big * ncu * 3;          // >= 75 % of the big-tile rounds are real work
+    const bool big = tiles_big >= 192 && filled && !(var & 256);        // bit 256 (A/B only): force the 128x128 kernel
 #define FP_GEMM_CASE(V)                                                          \
     case V: return big ? launch_cfg<256, 256, 2, 4, EPI, V>(a, stream)          \
                        : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);

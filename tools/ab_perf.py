@@ -39,7 +39,7 @@ def main():
     gemm_variants = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "6,14,0".split(","))]
     only_gemm = len(sys.argv) > 2
     attn_variants = [2, 3, 4]
-    M = 64 * 1376
+    M = int(sys.argv[3]) if len(sys.argv) > 3 else 64 * 1376
     for (N, K, epi) in [(2048, 1024, 0), (1024, 1024, 2), (4096, 1024, 1), (1024, 4096, 2)]:
         x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
         w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
@@ -53,9 +53,9 @@ def main():
         x = torch.randn(M, 1024, device="cuda").to(torch.bfloat16)
         w = (torch.randn(1024, 1024, device="cuda") * 0.02).to(torch.bfloat16)
         b = torch.zeros(1024, device="cuda").to(torch.bfloat16)
-        vt = torch.empty(64, 16, 64, 1376, device="cuda", dtype=torch.bfloat16)
+        vt = torch.empty(M // 1376 if M % 1376 == 0 else M // 912, 16, 64, 1376 if M % 1376 == 0 else 912, device="cuda", dtype=torch.bfloat16)
         ab("gemm_vt N=1024 K=1024", gemm_variants, lambda v: ops.set_option("gemm_variant", v),
-           lambda: ops.gemm_vt(x, w, b, 1376, 16, out=vt), 2.0 * M * 1024 * 1024)
+           lambda: ops.gemm_vt(x, w, b, 1376 if M % 1376 == 0 else 912, 16, out=vt), 2.0 * M * 1024 * 1024)
     for (B, n_tok) in ([] if only_gemm else [(64, 1374), (64, 905)]):
         npad = (n_tok + 15) // 16 * 16
         qk = torch.randn(B * npad, 2048, device="cuda").to(torch.bfloat16)

@@ -33,9 +33,13 @@ def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, s
     boxes[:, 2:] += boxes[:, :2]                         # xywh -> xyxy (:102)
     proposals = Proposals(image, {"boxes": boxes, "masks": masks}, 420, bbox_extend=bbox_extend)
     rows = []
-    for i, prop in enumerate(proposals.proposals):
+    # one ViT call for all proposals of the image (the reference runs one B = 1 forward per proposal, :112-114)
+    crops = list(proposals.proposals)
+    feats = model.feature_extractor(torch.stack([torch.as_tensor(c) for c in crops]), layer=layer, feature_type="patch") if crops else None
+    for i, prop in enumerate(crops):
         mesh = scene_props[i]["mesh"]
-        out = model(prop, templates.get_template_by_name(mesh), K, boxes[i], scales[i], layer=layer, batch_size=batch_size)
+        out = model(prop, templates.get_template_by_name(mesh), K, boxes[i], scales[i], layer=layer, batch_size=batch_size,
+                    query_feat=feats[i:i + 1])
         TCO = out["TCO"][0]
         b = out["bbox"].cpu().numpy()
         rows.append({"scene_id": int(scene_id), "im_id": int(frame_id), "obj_id": mesh, "score": out["scores"][0],

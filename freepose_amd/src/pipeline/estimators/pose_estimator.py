@@ -90,12 +90,16 @@ class DinoPoseEstimator:
             q = ops.l2_normalize(q)
         return ops.template_score(feats_template, q)
 
-    def forward(self, proposal, template_dict, K, bbox, est_scale, layer=22, batch_size=128, return_query_feat=False):
+    def forward(self, proposal, template_dict, K, bbox, est_scale, layer=22, batch_size=128, return_query_feat=False,
+                query_feat=None):
+        """`query_feat` (optional, [1,P,D]): patch features of `proposal` computed by the caller, e.g. for all proposals of
+        an image in one ViT batch (a B = 1 forward is launch-bound; features do not depend on batch neighbours)."""
         if self.cache_size > 0:
             feats_template = self._get_template_features(template_dict, layer=layer, batch_size=batch_size)
         else:
             feats_template = self._extract_features(template_dict["templates"], layer=layer, batch_size=batch_size)
-        query_feat = self.feature_extractor(proposal[None], layer=layer, feature_type="patch")
+        if query_feat is None:
+            query_feat = self.feature_extractor(proposal[None], layer=layer, feature_type="patch")
         scores = self.score_templates(feats_template, query_feat)
         T = scores.shape[0]
         idx_all = torch.arange(T, dtype=torch.int32, device=scores.device)

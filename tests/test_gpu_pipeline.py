@@ -260,3 +260,51 @@ def ops_crop_identity(rgb_u8):
     from freepose_amd import ops
     n, h, w = rgb_u8.shape[0], rgb_u8.shape[1], rgb_u8.shape[2]
     return ops.crop_resize_pad(rgb_u8, torch.tensor([[0, 0, w, h]] * n, dtype=torch.int32), h, 0.0)
+
+
+def test_dino_inference_rows_batched_equals_one_by_one(tmp_path):
+    """scripts.dino_inference.proposal_rows computes the query features of all proposals of an image in one ViT batch; the
+    rows (scores, R, t) must equal running the estimator proposal by proposal, and keep the reference's CSV fields"""
+    import warnings
+
+    from freepose_amd.scripts.dino_inference import proposal_rows
+    from freepose_amd.src.pipeline.utils import Proposals, mask_to_rle_pytorch
+    from src.pipeline.estimators.pose_estimator import DinoPoseEstimator
+    from src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+    from src.pipeline.retrieval.renderer import MeshRenderer
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fe = DINOv2FeatureExtractor("dinov2_vits14_reg", seed=6)
+    est = DinoPoseEstimator(n_poses=12, cache_size=4, cache_dir=tmp_path / "c", feature_extractor=fe)
+    renders = MeshRenderer(12).render(_mesh(), scale=0.25)
+    crops, _, _ = MeshRenderer.generate_proposals(renders)
+    td = {"templates": crops.float(), "depths": renders.depth, "model_name": "obj_1",
+          "intrinsic": torch.tensor([[600, 0, 210], [0, 600, 210], [0, 0, 1]])}
+
+    class _Templates:
+        def get_template_by_name(self, name):
+            return dict(td, model_name=name)
+
+    rng = np.random.default_rng(3)
+    image = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    props = []
+    for (x, y, w, h) in [(100, 80, 150, 170), (300, 200, 120, 90), (20, 250, 200, 180)]:
+        m = np.zeros((480, 640), dtype=np.uint8)
+        yy, xx = np.mgrid[0:480, 0:640]
+        m[((xx - (x + w / 2)) / (w / 2)) ** 2 + ((yy - (y + h / 2)) / (h / 2)) ** 2 <= 1] = 1
+        props.append({"segmentation": mask_to_rle_pytorch(torch.from_numpy(m[None]))[0], "bbox": [x, y, w, h], "mesh": "obj_1"})
+    K = np.array([[1066.778, 0, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1]])
+    scales = [0.07, 0.1, 0.12]
+    rows = proposal_rows(est, _Templates(), image, K, 48, 1, props, scales, 22, 128, 0.05)
+    assert len(rows) == 3 and set(rows[0]) == {"scene_id", "im_id", "obj_id", "score", "R", "t", "bbox_visib", "scale", "time"}
+    # one by one, without the batched query features
+    from freepose_amd.src.pipeline.utils import rle_to_mask
+    mk = torch.from_numpy(np.stack([rle_to_mask(p["segmentation"]) for p in props]))
+    bx = torch.from_numpy(np.stack([np.array(p["bbox"]) for p in props]))
+    bx[:, 2:] += bx[:, :2]
+    single = Proposals(image, {"boxes": bx, "masks": mk}, 420, bbox_extend=0.05)
+    for i, prop in enumerate(single.proposals):
+        out = est(prop, td, K, bx[i], scales[i], layer=22, batch_size=128)
+        assert float(out["scores"][0]) == float(rows[i]["score"])
+        assert " ".join(str(x) for x in out["TCO"][0][:3, :3].flatten().tolist()) == rows[i]["R"]
+        assert " ".join(str(x * 1000.0) for x in out["TCO"][0][:3, 3].tolist()) == rows[i]["t"]

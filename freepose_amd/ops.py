@@ -80,14 +80,20 @@ class ViT:
             check(self.lib.fp_vit_set_weight(self.handle, name.encode(), ptr(w), w.numel(), s), f"set_weight({name})")
         torch.cuda.synchronize()
 
-    def forward(self, images: torch.Tensor, layer: int = 22, feature_type: str = "cls") -> torch.Tensor:
+    def forward(self, images: torch.Tensor, layer: int = 22, feature_type: str = "cls",
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`out`: optional preallocated contiguous bf16 tensor of the result shape (e.g. a slice along dim 0 of a larger
+        buffer, so chunked calls need no concatenation)"""
         x = _dev(images, torch.bfloat16)
         B, Cc, H, W = x.shape
         assert Cc == 3
         P = (H // self.patch) * (W // self.patch)
         ft = FEATURE_TYPES[feature_type]
         shape = {0: (B, self.dim), 1: (B, self.n_reg, self.dim), 2: (B, P, self.dim)}[ft]
-        out = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+        else:
+            assert tuple(out.shape) == shape and out.dtype == torch.bfloat16 and out.is_contiguous() and out.device == x.device
         if B > 0:
             check(self.lib.fp_vit_forward(self.handle, ptr(x), B, H, W, int(layer), ft, ptr(out), current_stream()),
                   "fp_vit_forward")

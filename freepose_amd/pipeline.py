@@ -115,11 +115,12 @@ class HotPath:
         g = self.crop_res // 14
         sizes = ops.plan_vit_batches(crops.shape[0], g * g + 5, self.vit_batch)   # whole GEMM tile rounds per batch
         with self.clock.stage("vit_hypotheses"):
-            out, i = [], 0
-            for b in sizes:
-                out.append(self.vit(crops[i:i + b], layer=self.layer, feature_type="patch"))
+            feats = torch.empty((crops.shape[0], g * g, self.vit.dim), dtype=torch.bfloat16, device=crops.device)
+            i = 0
+            for b in sizes:      # each chunk writes its slice of the result: no concatenation pass (1.6 GB for 576 crops)
+                self.vit(crops[i:i + b], layer=self.layer, feature_type="patch", out=feats[i:i + b])
                 i += b
-            return torch.cat(out, dim=0)
+            return feats
 
     def run(self, crops: torch.Tensor, masks: torch.Tensor, K: np.ndarray, bboxes: np.ndarray, scales) -> List[ProposalResult]:
         """one pass of the hot path over a batch of proposals (every stage executed for every proposal)"""

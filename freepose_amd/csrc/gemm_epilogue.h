@@ -11,16 +11,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output ulp):
 // erf(z) = 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1/(1 + p z), z >= 0; odd extension.  ~14 VALU ops vs ~40 for erff.
 __device__ __forceinline__ float gelu_erf_poly(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    // z = |x|/sqrt(2) never materialises: 1 + p z = fma(p/sqrt2, |x|, 1) and exp(-z^2) = exp2(x^2 * (-log2(e)/2))
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);
     const float erfabs = fmaf(-poly * t, e, 1.0f);      // erf(|x|/sqrt2)
     const float erfv = copysignf(erfabs, x);
-    return 0.5f * x * (1.0f + erfv);
+    const float hx = 0.5f * x;
+    return fmaf(hx, erfv, hx);                          // 0.5 x (1 + erf)
 }
 
 // bytes of LDS each wave needs for the row-coalescing stage of the non-transposed epilogues (16 rows x 128 B)

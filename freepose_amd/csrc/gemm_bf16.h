@@ -50,7 +50,5 @@ __device__ __forceinline__ void fp_gemm_tile(int block, int nblocks, int tiles_m
 
 // Launch on `stream`. Returns FP_OK / error code (fp_last_error() has the text).
 int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream);
-// anti-phase schedule (gemm_ap.hip): 256x256 tiles only; same preconditions as fp_gemm_bf16
-int fp_gemm_bf16_ap(const FpGemmArgs& a, int epi, hipStream_t stream);
 // name of the kernel variant used for (epi) — for profiles / bench bookkeeping
 const char* fp_gemm_kernel_name(int epi);

@@ -267,7 +267,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // big tile once the grid can fill the chip with it, else the 128x128 tile
     const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
     // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads (8-wave kernels),
-    // 4 = polynomial erf in the GELU epilogue, 8 = 16-wave big tile, 16 = anti-phase kernel, 32 = persistent tile walk,
+    // 4 = polynomial erf in the GELU epilogue, 8 = 16-wave big tile, 32 = persistent tile walk,
     // 64 = streaming epilogue I/O: non-temporal output stores and residual loads (the last two with the 16-wave big tile).  FP_GEMM_VARIANT / fp_set_option override
     // the default (A/B probing only).
     static int env_var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
@@ -283,7 +283,6 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
 #define FP_GEMM_CASE(V)                                                          \
     case V: return big ? launch_cfg<256, 256, 2, 4, EPI, V>(a, stream)          \
                        : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);
-    if (big && (var & 16)) return fp_gemm_bf16_ap(a, EPI, stream);   // anti-phase two-group schedule (gemm_ap.hip)
     if (big && (var & 8)) {   // experimental: 16-wave workgroup (4 waves/SIMD), 64x64 per wave, non-pipelined reads
         {
             switch (var & (32 | 64)) {   // 32: persistent tile walk, 64: streaming (non-temporal) output stores

@@ -1,3 +1,5 @@
+// ARCHIVED EXPERIMENT (not built into the library; results in profiles/r01_ab.md, variant 22).  Build check:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I freepose_amd/csrc -c tools/experiments/gemm_ap.hip -o /dev/null
 // Anti-phase bf16 MFMA GEMM (gfx950): same math, operand layout and fused epilogues as gemm_bf16.hip, different
 // schedule.  rocprofv3 on the double-buffered kernel showed 0 LDS bank conflicts but only ~50 % MFMA-busy: its 8 waves
 // run in lockstep, so the two waves sharing a SIMD want the matrix pipe at the same time and the memory path at the

@@ -253,7 +253,7 @@ def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
         "P*D*2 bytes per crop; one crop per call here = 512 threads summing in the oracle's fixed order: latency-bound")
     add("bank_scan_topk", stage_ms.get("bank_scan_topk", 0), "hbm", args.bank * D * 2.0 * args.steps,
         f"one pass over the bf16 bank per step, shared by its Q = {args.proposals_per_step} queries; the stage is scan + exact "
-        "top-100 select (single-query select is latency-bound, ~55 us); the scan kernel alone: 15.9 us = 5.9 TB/s "
+        "top-100 select (single-query select is latency-bound, ~43 us); the scan kernel alone: 15.9 us = 5.9 TB/s "
         "(profiles/r01_scan_kernel_stats.csv)")
     add("rasterize", stage_ms.get("rasterize", 0), "hbm", (H * 420 * 420 * 7.0 + n_vert * 32.0 + n_tri * 12.0) * n_prop,
         f"mandatory rgb+depth writes; {H * n_tri * n_prop / max(stage_ms.get('rasterize', 1e9), 1e-9) / 1e6:.1f} G triangle set-ups/s")

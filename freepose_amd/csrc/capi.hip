@@ -419,9 +419,10 @@ extern "C" int fp_bank_topk(fp_ctx* ctx, const void* d_bank, int N, int D, const
     hipStream_t s = (hipStream_t)stream;
     uint16_t* keys;
     int rc;
-    if ((rc = ctx->get("topk.keys", (size_t)Q * N * 2, (void**)&keys))) return rc;
-    if ((rc = fp_bank_scan((const bf16_t*)d_bank, (const bf16_t*)d_queries, keys, N, D, Q, s))) return rc;
-    return fp_topk_select(keys, N, Q, k, idx_offset, d_out_scores, d_out_idx, s);
+    const int ldk = (N + 7) & ~7;   // key rows padded to 16 bytes (vector staging in the select kernel)
+    if ((rc = ctx->get("topk.keys", (size_t)Q * ldk * 2, (void**)&keys))) return rc;
+    if ((rc = fp_bank_scan((const bf16_t*)d_bank, (const bf16_t*)d_queries, keys, ldk, N, D, Q, s))) return rc;
+    return fp_topk_select(keys, ldk, N, Q, k, idx_offset, d_out_scores, d_out_idx, s);
 }
 
 extern "C" int fp_topk_merge(fp_ctx* ctx, const float* cs, const int32_t* ci, int Q, int C, int k, float* os,

@@ -33,8 +33,8 @@ int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* ou
 int fp_l2norm_rows(const bf16_t* X, bf16_t* Y, int rows, int D, hipStream_t s);
 // retrieval.hip
 int fp_cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s);
-int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int N, int D, int Q, hipStream_t s);
-int fp_topk_select(const uint16_t* keys, int N, int Q, int k, int idx_offset, float* out_scores, int* out_idx,
+int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int ldk, int N, int D, int Q, hipStream_t s);
+int fp_topk_select(const uint16_t* keys, int ldk, int N, int Q, int k, int idx_offset, float* out_scores, int* out_idx,
                    hipStream_t s);
 int fp_topk_merge_launch(const float* cs, const int* ci, int Q, int C, int k, float* out_scores, int* out_idx,
                          hipStream_t s);

@@ -32,7 +32,7 @@ template <int NCH, int QT, bool FULL>   // FULL: D == NCH * 512, every lane's 8-
 __global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict__ bank,
                                                         const bf16_t* __restrict__ queries,
                                                         uint16_t* __restrict__ keys, int N, int D, int q_begin,
-                                                        int Q) {
+                                                        int Q, int ldk) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict
         for (int q = 0; q < QT; ++q) {
             const float sdot = wave_sum4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
             if ((lane & 15) == 0 && r0 + urow < r_end && q_begin + q < Q)
-                keys[(size_t)(q_begin + q) * N + r0 + urow] = (uint16_t)score_key16(rbf(sdot));
+                keys[(size_t)(q_begin + q) * ldk + r0 + urow] = (uint16_t)score_key16(rbf(sdot));
         }
     };
     // two chunk buffers used alternately (no register copy at the hand-over): B is requested before A is reduced, etc.
@@ -139,15 +139,27 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh, int& total) {
     return base + x - v;
 }
 
-__global__ __launch_bounds__(SEL_T) void topk_select_kernel(const uint16_t* __restrict__ keys, int N, int k,
+// LDSKEYS: the query's whole key row (N x 2 B; 92 KB for the 46 037-row bank) is staged into LDS once with coalesced loads
+// and every later pass (two histograms, the ordered compaction's count and write sweeps) reads LDS — the global-read form
+// spent its 54 us in four latency-bound sweeps, two of them with a 90-byte stride between neighbouring threads.
+template <bool LDSKEYS>
+__global__ __launch_bounds__(SEL_T) void topk_select_kernel(const uint16_t* __restrict__ keys, int ldk, int N, int k,
                                                             int idx_offset, float* __restrict__ out_scores,
                                                             int* __restrict__ out_idx) {
+    extern __shared__ uint16_t lkeys[];   // [ldk] when LDSKEYS (rows are padded to 8 keys: 16-byte staging loads)
     __shared__ int hist[256];
     __shared__ int sh[SEL_T / 64 + 2];
     __shared__ int s_hi, s_T, s_gt;
     __shared__ unsigned long long cand[KMAX];
     const int q = blockIdx.x, tid = threadIdx.x;
-    const uint16_t* kq = keys + (size_t)q * N;
+    const uint16_t* kq = keys + (size_t)q * ldk;
+    if constexpr (LDSKEYS) {
+        const uint4* src = (const uint4*)kq;
+        uint4* dst = (uint4*)lkeys;
+        for (int i = tid; i < ldk / 8; i += SEL_T) dst[i] = src[i];   // pad keys (>= N) are never read below
+        __syncthreads();
+        kq = lkeys;
+    }
     const int per = (N + SEL_T - 1) / SEL_T;
     const int lo = tid * per, hi = min(lo + per, N);
 
@@ -450,7 +462,7 @@ int fp_cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s) {
 }
 
 // keys: workspace [Q, N] u16
-int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int N, int D, int Q, hipStream_t s) {
+int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int ldk, int N, int D, int Q, hipStream_t s) {
     FP_REQUIRE(N > 0 && Q > 0 && D % 8 == 0 && D <= 1536, "bank_scan: bad shape N=%d D=%d Q=%d", N, D, Q);
     const int nch = cdiv(D, 512);
     // grid: 2..8 workgroups (4 waves each) per CU, whichever leaves the smallest remainder of rows per wave
@@ -471,10 +483,10 @@ int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int 
     do {                                                                                                            \
         if (D == NCHV * 512)                                                                                        \
             hipLaunchKernelGGL((bank_scan_kernel<NCHV, QTV, true>), dim3(blocks), dim3(256), 0, s, bank, queries,   \
-                               keys, N, D, qb, Q);                                                                  \
+                               keys, N, D, qb, Q, ldk);                                                             \
         else                                                                                                        \
             hipLaunchKernelGGL((bank_scan_kernel<NCHV, QTV, false>), dim3(blocks), dim3(256), 0, s, bank, queries,  \
-                               keys, N, D, qb, Q);                                                                  \
+                               keys, N, D, qb, Q, ldk);                                                             \
     } while (0)
         if (left >= 4) {
             if (nch == 1) FP_SCAN(1, 4); else if (nch == 2) FP_SCAN(2, 4); else FP_SCAN(3, 4);
@@ -489,10 +501,21 @@ int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int 
     return FP_OK;
 }
 
-int fp_topk_select(const uint16_t* keys, int N, int Q, int k, int idx_offset, float* out_scores, int* out_idx,
+int fp_topk_select(const uint16_t* keys, int ldk, int N, int Q, int k, int idx_offset, float* out_scores, int* out_idx,
                    hipStream_t s) {
     FP_REQUIRE(k > 0 && k <= KMAX && k <= N, "topk: k=%d out of range (N=%d, max %d)", k, N, KMAX);
-    hipLaunchKernelGGL(topk_select_kernel, dim3(Q), dim3(SEL_T), 0, s, keys, N, k, idx_offset, out_scores, out_idx);
+    FP_REQUIRE(ldk >= N && ldk % 8 == 0, "topk: key row stride %d must be >= N and a multiple of 8", ldk);
+    const size_t key_bytes = (size_t)ldk * 2;
+    if (key_bytes <= 128 * 1024) {   // the key row fits beside the candidate buffer: all passes from LDS
+        static bool attr_set = false;
+        if (!attr_set) {
+            FP_HIP(hipFuncSetAttribute((const void*)topk_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(topk_select_kernel<true>, dim3(Q), dim3(SEL_T), key_bytes, s, keys, ldk, N, k, idx_offset, out_scores, out_idx);
+    } else {
+        hipLaunchKernelGGL(topk_select_kernel<false>, dim3(Q), dim3(SEL_T), 0, s, keys, ldk, N, k, idx_offset, out_scores, out_idx);
+    }
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -50,7 +50,12 @@ SIGNATURES = {
     "fp_generate_rotations": (c_int, [c_int, c_void_p]),
     "fp_geodesic_select": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_double, c_void_p, P(c_int), c_void_p]),
     "fp_mesh_upload": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, P(c_void_p)]),
+    "fp_mesh_upload_textured": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                        P(c_void_p)]),
     "fp_mesh_set_ambient": (c_int, [c_void_p, c_float]),
+    "fp_mesh_set_shading": (c_int, [c_void_p, c_int]),
+    "fp_project_vertices": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p,
+                                    c_void_p, c_void_p]),
     "fp_mesh_destroy": (c_int, [c_void_p]),
     "fp_rasterize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
                              c_int, c_void_p, c_void_p, c_void_p]),

@@ -12,8 +12,20 @@
 //   depth  : b_i = float(E_i)/float(area2) ; izp = fma(b2,iz2, fma(b1,iz1, b0*iz0)) ; depth = 1/izp
 //   visibility: 64-bit key (depth bits << 32 | triangle id), atomic MIN -> nearest depth, lowest id on
 //            exact ties; order independent, hence deterministic
-//   colour : per-vertex RGB, perspective-correct: c = fma(b2*iz2,c2, fma(b1*iz1,c1,(b0*iz0)*c0)) * depth
-//            out = (u8) min(255, a*c + 0.5)        (ambient light a saturates; a = 2 by default, renderer.py:53-55)
+//   base colour of the visible fragment, q_i = b_i*iz_i:
+//            vertex colours : cv = fma(q2,c2, fma(q1,c1, q0*c0)) * depth                      (0..255 units)
+//            textured mesh  : per-corner UV, U = fma(q2,u2, fma(q1,u1, q0*u0)) * depth (same for V); bilinear filter of mip
+//                             level 0, REPEAT wrap, texel centres at integer + 0.5, v = 1 at the image's first row:
+//                             x = U*tw - 0.5, y = (1-V)*th - 0.5, (x0,y0) = floor, w = frac;
+//                             top = fma(wx, t01-t00, t00), bot = fma(wx, t11-t10, t10), val = fma(wy, bot-top, top); c = val*Kd
+//                             texel value = DEC[u8] (sRGB -> linear, 256-entry table: decode before filtering) when shade = 1,
+//                             float(u8)/255.f when shade = 0
+//   output : shade 1 (default, "gamma"): u8 = #{k in 1..255 : THR[k] <= a*c}, THR[k] = ((k-.5)/255)^2.2, i.e.
+//            round(255 (a c)^(1/2.2)) found by table search so that host oracle and device agree bit for bit (vertex: c = cv/255)
+//            shade 0 ("linear", the round-1 rule): (u8) min(255, a*cv + 0.5)                  (textured: cv = c*255)
+//            a = ambient light factor: 2 by default (renderer.py:53-55), 5 in tracking_refiner.py:33.
+//   pyrender's fragment shader is third-party and absent from /root/reference: the shading rule is STATED here, not pinned
+//   (DESIGN.md §5).  GL would minify through trilinear mip-maps; level 0 only is a documented deviation.
 // Launch shape: vertex kernel (Hn x V threads), triangle kernel (Hn x F threads; small triangles are
 // rasterised by their thread, large ones by a whole wave via a queue), resolve kernel (Hn x pixels).
 #include "../../include/freepose_hip.h"
@@ -24,6 +36,12 @@ struct fp_mesh {
     float* verts = nullptr;    // [V,3]
     int32_t* faces = nullptr;  // [F,3]
     uint8_t* colors = nullptr; // [V,4] rgba (a unused)
+    float* uv = nullptr;       // [F,3,2] per-corner texture coordinates (textured meshes)
+    uint8_t* tex = nullptr;    // [th,tw,4] rgba diffuse texture
+    float* tables = nullptr;   // DEC[256] sRGB->linear, THR[256] gamma-encode thresholds
+    int th = 0, tw = 0;
+    float kd[3] = {1.f, 1.f, 1.f};   // material diffuse factor (MTL Kd / glTF baseColorFactor)
+    int shade = 1;             // 1 = gamma rule, 0 = linear (see the contract above)
     int V = 0, F = 0;
     float ambient = 2.0f;      // scene ambient light factor: 2 in renderer.py:53-55, 5 in tracking_refiner.py:33
 };
@@ -69,6 +87,7 @@ struct TriSetup {
     int bx0, by0, bx1, by1;  // pixel bbox, inclusive, clipped
     int i0, i1, i2;          // vertex ids after orientation normalisation
     bool ok;
+    bool swapped;            // corners 1 and 2 were exchanged (per-corner attributes follow)
 };
 
 __device__ __forceinline__ bool topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
@@ -80,6 +99,7 @@ __device__ __forceinline__ TriSetup tri_setup(const SVert* __restrict__ sv, cons
     SVert a = sv[i0], b = sv[i1], c = sv[i2];
     t.ok = (a.zc > ZNEAR) && (b.zc > ZNEAR) && (c.zc > ZNEAR);
     long long area2 = (long long)(b.xi - a.xi) * (c.yi - a.yi) - (long long)(b.yi - a.yi) * (c.xi - a.xi);
+    t.swapped = area2 < 0;
     if (area2 < 0) {
         SVert tmp = b; b = c; c = tmp;
         int ti = i1; i1 = i2; i2 = ti;
@@ -136,6 +156,88 @@ __device__ __forceinline__ void tri_pixel(const TriSetup& t, int f, int px, int 
     atomicMin(&zb[(size_t)py * W + px], key);
 }
 
+// ---- shading of the visible fragment (shared by both visibility strategies; arithmetic = the contract in the header) ----
+struct ShadeArgs {
+    const uint8_t* colors;   // [V,4] or null
+    const float* uv;         // [F,3,2] or null
+    const uint8_t* tex;      // [th,tw,4] or null
+    int th, tw;
+    float kd0, kd1, kd2;
+    float ambient;
+    int shade;
+};
+
+// largest k in [0,255] with thr[k] <= x (thr[0] = 0); the pow() estimate only decides how many table steps are taken
+__device__ __forceinline__ uint8_t encode_gamma(float x, const float* thr) {
+    if (!(x > 0.f)) return 0;
+    int k = (int)(255.0f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(fminf(x, 1.0f)) * 0.45454545f) + 0.5f);
+    k = min(max(k, 0), 255);
+    while (k < 255 && thr[k + 1] <= x) ++k;
+    while (k > 0 && thr[k] > x) --k;
+    return (uint8_t)k;
+}
+__device__ __forceinline__ int wrapi(int a, int n) { const int m = a % n; return m < 0 ? m + n : m; }
+
+// tab: DEC[256] then THR[256] (LDS copy)
+__device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetup& t, int f, float q0, float q1, float q2,
+                                               float dd, const float* tab, uint8_t (&out)[3]) {
+    const float* dec = tab;
+    const float* thr = tab + 256;
+    if (s.uv) {
+        const float* tc = s.uv + (size_t)f * 6;
+        const int k1 = t.swapped ? 2 : 1, k2 = t.swapped ? 1 : 2;
+        const float U = fmaf(q2, tc[2 * k2], fmaf(q1, tc[2 * k1], q0 * tc[0])) * dd;
+        const float Vv = fmaf(q2, tc[2 * k2 + 1], fmaf(q1, tc[2 * k1 + 1], q0 * tc[1])) * dd;
+        float x = fmaf(U, (float)s.tw, -0.5f), y = fmaf(1.0f - Vv, (float)s.th, -0.5f);
+        x = fminf(fmaxf(x, -1.0e6f), 1.0e6f); y = fminf(fmaxf(y, -1.0e6f), 1.0e6f);
+        if (!(x == x)) x = 0.f;
+        if (!(y == y)) y = 0.f;
+        const float xf = floorf(x), yf = floorf(y);
+        const float wx = x - xf, wy = y - yf;
+        const int x0 = wrapi((int)xf, s.tw), x1 = wrapi((int)xf + 1, s.tw);
+        const int y0 = wrapi((int)yf, s.th), y1 = wrapi((int)yf + 1, s.th);
+        const uint32_t e00 = *(const uint32_t*)(s.tex + ((size_t)y0 * s.tw + x0) * 4), e01 = *(const uint32_t*)(s.tex + ((size_t)y0 * s.tw + x1) * 4);
+        const uint32_t e10 = *(const uint32_t*)(s.tex + ((size_t)y1 * s.tw + x0) * 4), e11 = *(const uint32_t*)(s.tex + ((size_t)y1 * s.tw + x1) * 4);
+        const float kd[3] = {s.kd0, s.kd1, s.kd2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int b00 = (e00 >> (8 * c)) & 255, b01 = (e01 >> (8 * c)) & 255, b10 = (e10 >> (8 * c)) & 255, b11 = (e11 >> (8 * c)) & 255;
+            const float t00 = s.shade ? dec[b00] : (float)b00 / 255.f, t01 = s.shade ? dec[b01] : (float)b01 / 255.f;
+            const float t10 = s.shade ? dec[b10] : (float)b10 / 255.f, t11 = s.shade ? dec[b11] : (float)b11 / 255.f;
+            const float top = fmaf(wx, t01 - t00, t00), bot = fmaf(wx, t11 - t10, t10);
+            const float cl = fmaf(wy, bot - top, top) * kd[c];
+            if (s.shade) out[c] = encode_gamma(s.ambient * cl, thr);
+            else out[c] = (uint8_t)fmaxf(fminf(s.ambient * (cl * 255.f) + 0.5f, 255.0f), 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float c0 = 255.f, c1 = 255.f, c2 = 255.f;
+            if (s.colors) { c0 = (float)s.colors[4 * t.i0 + c]; c1 = (float)s.colors[4 * t.i1 + c]; c2 = (float)s.colors[4 * t.i2 + c]; }
+            const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
+            if (s.shade) out[c] = encode_gamma(s.ambient * (cv * (1.0f / 255.f)), thr);
+            else out[c] = (uint8_t)fmaxf(fminf(s.ambient * cv + 0.5f, 255.0f), 0.f);
+        }
+    }
+}
+
+// resolve one pixel whose visibility key is `key`: depth and colour of the winning triangle
+__device__ __forceinline__ void resolve_pixel(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, const ShadeArgs& s,
+                                              const float* tab, unsigned long long key, int px, int py, int W, int Hh, float& d,
+                                              uint8_t (&out)[3]) {
+    d = 0.f;
+    out[0] = out[1] = out[2] = 0;
+    if (key == ~0ull) return;
+    const int f = (int)(unsigned)(key & 0xffffffffu);
+    d = __uint_as_float((unsigned)(key >> 32));
+    const TriSetup t = tri_setup(sv, faces, f, W, Hh);
+    long long w0, w1, w2;
+    tri_cover(t, px, py, w0, w1, w2);
+    float b0, b1, b2;
+    const float dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
+    shade_fragment(s, t, f, b0 * t.iz0, b1 * t.iz1, b2 * t.iz2, dd, tab, out);
+}
+
 __global__ __launch_bounds__(256) void raster_tri_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
                                                          int V, int F, int W, int Hh,
                                                          unsigned long long* __restrict__ zb_all,
@@ -176,41 +278,25 @@ __global__ __launch_bounds__(256) void raster_big_kernel(const SVert* __restrict
 }
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __restrict__ sv_all,
-                                                             const int32_t* __restrict__ faces,
-                                                             const uint8_t* __restrict__ colors, int V, int W, int Hh,
+                                                             const int32_t* __restrict__ faces, ShadeArgs sh,
+                                                             const float* __restrict__ tables, int V, int W, int Hh,
                                                              const unsigned long long* __restrict__ zb_all,
-                                                             uint8_t* __restrict__ rgb, float* __restrict__ depth,
-                                                             float ambient) {
+                                                             uint8_t* __restrict__ rgb, float* __restrict__ depth) {
+    __shared__ float tab[512];
+    tab[threadIdx.x] = tables[threadIdx.x];
+    tab[threadIdx.x + 256] = tables[threadIdx.x + 256];
+    __syncthreads();
     const int h = blockIdx.y;
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= W * Hh) return;
     const unsigned long long key = zb_all[(size_t)h * W * Hh + pix];
-    float d = 0.f;
-    uint8_t r = 0, g = 0, b = 0;
-    if (key != ~0ull) {
-        const int f = (int)(unsigned)(key & 0xffffffffu);
-        d = __uint_as_float((unsigned)(key >> 32));
-        const TriSetup t = tri_setup(sv_all + (size_t)h * V, faces, f, W, Hh);
-        long long w0, w1, w2;
-        const int py = pix / W, px = pix - py * W;
-        tri_cover(t, px, py, w0, w1, w2);
-        float b0, b1, b2;
-        const float dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
-        const float q0 = b0 * t.iz0, q1 = b1 * t.iz1, q2 = b2 * t.iz2;
-        uint8_t out[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float c0 = 255.f, c1 = 255.f, c2 = 255.f;
-            if (colors) { c0 = (float)colors[4 * t.i0 + c]; c1 = (float)colors[4 * t.i1 + c]; c2 = (float)colors[4 * t.i2 + c]; }
-            const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
-            const float amb = fminf(ambient * cv + 0.5f, 255.0f);
-            out[c] = (uint8_t)fmaxf(amb, 0.f);
-        }
-        r = out[0]; g = out[1]; b = out[2];
-    }
+    const int py = pix / W, px = pix - py * W;
+    float d;
+    uint8_t out[3];
+    resolve_pixel(sv_all + (size_t)h * V, faces, sh, tab, key, px, py, W, Hh, d, out);
     depth[(size_t)h * W * Hh + pix] = d;
     uint8_t* o = rgb + ((size_t)h * W * Hh + pix) * 3;
-    o[0] = r; o[1] = g; o[2] = b;
+    o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -270,11 +356,14 @@ __device__ __forceinline__ void tile_pixel(const TriSetup& t, int f, int px, int
 }
 
 __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
-                                                          const uint8_t* __restrict__ colors, int V, int F, int W, int Hh, int T,
+                                                          ShadeArgs sh, const float* __restrict__ tables, int V, int F, int W, int Hh, int T,
                                                           int ntx, const uint16_t* __restrict__ tbox,
                                                           const unsigned long long* __restrict__ cmask, int nchunk,
-                                                          uint8_t* __restrict__ rgb, float* __restrict__ depth, float ambient) {
-    extern __shared__ unsigned long long tile[];   // [T*T] visibility keys
+                                                          uint8_t* __restrict__ rgb, float* __restrict__ depth) {
+    extern __shared__ unsigned long long tile[];   // [T*T] visibility keys, then DEC/THR tables (512 floats)
+    float* tab = (float*)(tile + T * T);
+    tab[threadIdx.x] = tables[threadIdx.x];
+    tab[threadIdx.x + 256] = tables[threadIdx.x + 256];
     const int h = blockIdx.y;
     const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
     const int X0 = tx * T, Y0 = ty * T;
@@ -321,40 +410,41 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
     for (int p = threadIdx.x; p < tw * th; p += blockDim.x) {
         const int ly = p / tw, lx = p - ly * tw;
         const int px = X0 + lx, py = Y0 + ly;
-        const unsigned long long key = tile[ly * T + lx];
-        float d = 0.f;
-        uint8_t r = 0, g = 0, b = 0;
-        if (key != ~0ull) {
-            const int f = (int)(unsigned)(key & 0xffffffffu);
-            d = __uint_as_float((unsigned)(key >> 32));
-            const TriSetup t = tri_setup(sv, faces, f, W, Hh);
-            long long w0, w1, w2;
-            tri_cover(t, px, py, w0, w1, w2);
-            float b0, b1, b2;
-            const float dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
-            const float q0 = b0 * t.iz0, q1 = b1 * t.iz1, q2 = b2 * t.iz2;
-            uint8_t out[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float c0 = 255.f, c1 = 255.f, c2 = 255.f;
-                if (colors) { c0 = (float)colors[4 * t.i0 + c]; c1 = (float)colors[4 * t.i1 + c]; c2 = (float)colors[4 * t.i2 + c]; }
-                const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
-                const float amb = fminf(ambient * cv + 0.5f, 255.0f);
-                out[c] = (uint8_t)fmaxf(amb, 0.f);
-            }
-            r = out[0]; g = out[1]; b = out[2];
-        }
+        float d;
+        uint8_t out[3];
+        resolve_pixel(sv, faces, sh, tab, tile[ly * T + lx], px, py, W, Hh, d, out);
         const size_t pix = (size_t)h * W * Hh + (size_t)py * W + px;
         depth[pix] = d;
         uint8_t* o = rgb + pix * 3;
-        o[0] = r; o[1] = g; o[2] = b;
+        o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
     }
+}
+
+// vertex stage export (fp_project_vertices)
+__global__ void raster_export_kernel(const SVert* __restrict__ sv, size_t n, int32_t* __restrict__ xy, float* __restrict__ zc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SVert v = sv[i];
+    xy[2 * i] = v.xi; xy[2 * i + 1] = v.yi;
+    zc[i] = v.zc;
 }
 
 }  // namespace
 
-extern "C" int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F,
-                              const uint8_t* h_colors, fp_mesh** out) {
+static int mesh_tables(fp_mesh* m) {
+    // DEC[i] = sRGB -> linear of i/255 ; THR[k] = ((k - 0.5)/255)^2.2 (THR[0] = 0): double precision, rounded to float once
+    float tab[512];
+    for (int i = 0; i < 256; ++i) {
+        const double sv = (double)i / 255.0;
+        tab[i] = (float)(sv <= 0.04045 ? sv / 12.92 : pow((sv + 0.055) / 1.055, 2.4));
+        tab[256 + i] = i == 0 ? 0.f : (float)pow(((double)i - 0.5) / 255.0, 2.2);
+    }
+    FP_HIP(hipMalloc((void**)&m->tables, sizeof(tab)));
+    FP_HIP(hipMemcpy(m->tables, tab, sizeof(tab), hipMemcpyHostToDevice));
+    return FP_OK;
+}
+
+static int mesh_geometry(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F, fp_mesh** out) {
     FP_REQUIRE(ctx && h_verts && h_faces && out && V > 0 && F > 0, "mesh_upload: bad argument");
     for (int i = 0; i < 3 * F; ++i) FP_REQUIRE(h_faces[i] >= 0 && h_faces[i] < V, "mesh_upload: face index out of range");
     fp_mesh* m = new fp_mesh();
@@ -363,6 +453,17 @@ extern "C" int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const in
     FP_HIP(hipMalloc((void**)&m->faces, (size_t)F * 12));
     FP_HIP(hipMemcpy(m->verts, h_verts, (size_t)V * 12, hipMemcpyHostToDevice));
     FP_HIP(hipMemcpy(m->faces, h_faces, (size_t)F * 12, hipMemcpyHostToDevice));
+    int rc = mesh_tables(m);
+    if (rc) return rc;
+    *out = m;
+    return FP_OK;
+}
+
+extern "C" int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F,
+                              const uint8_t* h_colors, fp_mesh** out) {
+    fp_mesh* m = nullptr;
+    int rc = mesh_geometry(ctx, h_verts, V, h_faces, F, &m);
+    if (rc) return rc;
     if (h_colors) {
         std::vector<uint8_t> rgba((size_t)V * 4, 255);
         for (int i = 0; i < V; ++i) { rgba[4 * i] = h_colors[3 * i]; rgba[4 * i + 1] = h_colors[3 * i + 1]; rgba[4 * i + 2] = h_colors[3 * i + 2]; }
@@ -372,12 +473,60 @@ extern "C" int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const in
     *out = m;
     return FP_OK;
 }
+
+extern "C" int fp_mesh_upload_textured(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F,
+                                       const float* h_uv, const uint8_t* h_texture, int th, int tw, const float* h_kd3,
+                                       fp_mesh** out) {
+    FP_REQUIRE(h_uv && h_texture && th > 0 && tw > 0 && th <= 16384 && tw <= 16384, "mesh_upload_textured: bad texture argument");
+    fp_mesh* m = nullptr;
+    int rc = mesh_geometry(ctx, h_verts, V, h_faces, F, &m);
+    if (rc) return rc;
+    std::vector<uint8_t> rgba((size_t)th * tw * 4, 255);
+    for (size_t i = 0; i < (size_t)th * tw; ++i) { rgba[4 * i] = h_texture[3 * i]; rgba[4 * i + 1] = h_texture[3 * i + 1]; rgba[4 * i + 2] = h_texture[3 * i + 2]; }
+    FP_HIP(hipMalloc((void**)&m->tex, rgba.size()));
+    FP_HIP(hipMemcpy(m->tex, rgba.data(), rgba.size(), hipMemcpyHostToDevice));
+    FP_HIP(hipMalloc((void**)&m->uv, (size_t)F * 24));
+    FP_HIP(hipMemcpy(m->uv, h_uv, (size_t)F * 24, hipMemcpyHostToDevice));
+    m->th = th; m->tw = tw;
+    if (h_kd3) { m->kd[0] = h_kd3[0]; m->kd[1] = h_kd3[1]; m->kd[2] = h_kd3[2]; }
+    *out = m;
+    return FP_OK;
+}
 extern "C" int fp_mesh_destroy(fp_mesh* m) {
     if (!m) return FP_OK;
     if (m->verts) (void)hipFree(m->verts);
     if (m->faces) (void)hipFree(m->faces);
     if (m->colors) (void)hipFree(m->colors);
+    if (m->uv) (void)hipFree(m->uv);
+    if (m->tex) (void)hipFree(m->tex);
+    if (m->tables) (void)hipFree(m->tables);
     delete m;
+    return FP_OK;
+}
+
+static ShadeArgs shade_args(const fp_mesh* m) {
+    ShadeArgs a;
+    a.colors = m->colors; a.uv = m->uv; a.tex = m->tex; a.th = m->th; a.tw = m->tw;
+    a.kd0 = m->kd[0]; a.kd1 = m->kd[1]; a.kd2 = m->kd[2];
+    a.ambient = m->ambient; a.shade = m->shade;
+    return a;
+}
+
+extern "C" int fp_project_vertices(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx,
+                                   float fy, float cx, float cy, int32_t* d_xy, float* d_zc, void* stream) {
+    FP_REQUIRE(ctx && mesh && d_poses && d_xy && d_zc, "project_vertices: null argument");
+    if (Hn == 0) return FP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int V = mesh->V;
+    SVert* sv;
+    int rc;
+    if ((rc = ctx->get("raster.sv", (size_t)Hn * V * sizeof(SVert), (void**)&sv))) return rc;
+    hipLaunchKernelGGL(raster_vertex_kernel, dim3(cdiv(V, 256), Hn), dim3(256), 0, s, mesh->verts, V, d_poses, Hn, scale,
+                       fx, fy, cx, cy, sv);
+    FP_LAUNCH_CHECK();
+    const size_t n = (size_t)Hn * V;
+    hipLaunchKernelGGL(raster_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sv, n, d_xy, d_zc);
+    FP_LAUNCH_CHECK();
     return FP_OK;
 }
 
@@ -412,14 +561,14 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
         if ((rc = ctx->get("raster.cmask", (size_t)Hn * nchunk * 8, (void**)&cmask))) return rc;
         hipLaunchKernelGGL(raster_bin_kernel, dim3(nchunk, Hn), dim3(BIN_CHUNK), 0, s, sv, mesh->faces, V, F, W, Hh, T, tbox, cmask);
         FP_LAUNCH_CHECK();
-        const size_t lds = (size_t)T * T * 8;
+        const size_t lds = (size_t)T * T * 8 + 2048;   // visibility keys + DEC/THR tables
         static bool attr_set = false;
         if (!attr_set) {
-            FP_HIP(hipFuncSetAttribute((const void*)raster_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 88 * 8));
+            FP_HIP(hipFuncSetAttribute((const void*)raster_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 88 * 8 + 2048));
             attr_set = true;
         }
-        hipLaunchKernelGGL(raster_tile_kernel, dim3(ntx * nty, Hn), dim3(256), lds, s, sv, mesh->faces, mesh->colors, V, F, W,
-                           Hh, T, ntx, tbox, cmask, nchunk, d_rgb, d_depth, mesh->ambient);
+        hipLaunchKernelGGL(raster_tile_kernel, dim3(ntx * nty, Hn), dim3(256), lds, s, sv, mesh->faces, shade_args(mesh), mesh->tables,
+                           V, F, W, Hh, T, ntx, tbox, cmask, nchunk, d_rgb, d_depth);
         FP_LAUNCH_CHECK();
         return FP_OK;
     }
@@ -438,8 +587,8 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
     FP_LAUNCH_CHECK();
     hipLaunchKernelGGL(raster_big_kernel, dim3(1024), dim3(256), 0, s, sv, mesh->faces, V, W, Hh, zb, queue, qcount, qcap);
     FP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(raster_resolve_kernel, dim3(cdiv(W * Hh, 256), Hn), dim3(256), 0, s, sv, mesh->faces, mesh->colors,
-                       V, W, Hh, zb, d_rgb, d_depth, mesh->ambient);
+    hipLaunchKernelGGL(raster_resolve_kernel, dim3(cdiv(W * Hh, 256), Hn), dim3(256), 0, s, sv, mesh->faces, shade_args(mesh),
+                       mesh->tables, V, W, Hh, zb, d_rgb, d_depth);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }
@@ -447,5 +596,10 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
 extern "C" int fp_mesh_set_ambient(fp_mesh* mesh, float ambient) {
     FP_REQUIRE(mesh && ambient >= 0.f, "mesh_set_ambient: bad argument");
     mesh->ambient = ambient;
+    return FP_OK;
+}
+extern "C" int fp_mesh_set_shading(fp_mesh* mesh, int mode) {
+    FP_REQUIRE(mesh && (mode == 0 || mode == 1), "mesh_set_shading: mode must be 0 (linear) or 1 (gamma)");
+    mesh->shade = mode;
     return FP_OK;
 }

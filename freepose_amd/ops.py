@@ -321,14 +321,32 @@ def geodesic_select(grid_f64: torch.Tensor, R_prev: np.ndarray, thresh_deg: floa
 
 
 class Mesh:
-    def __init__(self, vertices: np.ndarray, faces: np.ndarray, colors: Optional[np.ndarray] = None):
+    """device copy of a triangle mesh.  `colors` u8 [V,3] selects vertex colours; `uv` f32 [F,3,2] + `texture` u8 [th,tw,3]
+    (+ optional diffuse factor `kd` [3]) select per-fragment texture sampling; neither = white."""
+
+    def __init__(self, vertices: np.ndarray, faces: np.ndarray, colors: Optional[np.ndarray] = None, uv: Optional[np.ndarray] = None,
+                 texture: Optional[np.ndarray] = None, kd=None):
         self.lib = _lib.load()
         v = np.ascontiguousarray(vertices, dtype=np.float32)
         f = np.ascontiguousarray(faces, dtype=np.int32)
-        c = np.ascontiguousarray(colors[:, :3], dtype=np.uint8) if colors is not None else None
         h = C.c_void_p()
-        check(self.lib.fp_mesh_upload(context(), ptr(v), v.shape[0], ptr(f), f.shape[0], ptr(c), C.byref(h)), "fp_mesh_upload")
+        if uv is not None and texture is not None:
+            t = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 3, 2)
+            if t.shape[0] != f.shape[0]:
+                raise ValueError(f"uv must be per-corner [F,3,2]; got {t.shape} for {f.shape[0]} faces")
+            x = np.ascontiguousarray(np.asarray(texture)[:, :, :3], dtype=np.uint8)
+            k = None if kd is None else np.ascontiguousarray(kd, dtype=np.float32).reshape(3)
+            check(self.lib.fp_mesh_upload_textured(context(), ptr(v), v.shape[0], ptr(f), f.shape[0], ptr(t), ptr(x), x.shape[0],
+                                                   x.shape[1], ptr(k), C.byref(h)), "fp_mesh_upload_textured")
+        else:
+            c = np.ascontiguousarray(colors[:, :3], dtype=np.uint8) if colors is not None else None
+            check(self.lib.fp_mesh_upload(context(), ptr(v), v.shape[0], ptr(f), f.shape[0], ptr(c), C.byref(h)), "fp_mesh_upload")
         self.handle, self.V, self.F = h, v.shape[0], f.shape[0]
+
+    def set_shading(self, mode: int):
+        """1 = gamma output rule (default), 0 = linear (csrc/raster.hip header)"""
+        check(self.lib.fp_mesh_set_shading(self.handle, int(mode)), "fp_mesh_set_shading")
+        return self
 
     def set_ambient(self, ambient: float):
         """scene ambient light factor (2 = MeshRenderer's scenes, 5 = TrackingRefiner's)"""
@@ -353,6 +371,19 @@ def rasterize(mesh: Mesh, poses: torch.Tensor, scale: float, fx: float, fy: floa
         check(lib.fp_rasterize(context(), mesh.handle, ptr(p), Hn, float(scale), float(fx), float(fy), float(cx), float(cy),
                                int(W), int(H), ptr(rgb), ptr(depth), current_stream()), "fp_rasterize")
     return rgb, depth
+
+
+def project_vertices(mesh: Mesh, poses: torch.Tensor, scale: float, fx: float, fy: float, cx: float, cy: float):
+    """vertex stage of the rasteriser: (xy i32 [Hn,V,2] window coordinates in 1/256 px, zc f32 [Hn,V]) on device"""
+    lib = _lib.load()
+    p = _dev(torch.as_tensor(poses), torch.float32)
+    Hn = p.shape[0]
+    xy = torch.zeros((Hn, mesh.V, 2), dtype=torch.int32, device=p.device)
+    zc = torch.zeros((Hn, mesh.V), dtype=torch.float32, device=p.device)
+    if Hn:
+        check(lib.fp_project_vertices(context(), mesh.handle, ptr(p), Hn, float(scale), float(fx), float(fy), float(cx), float(cy),
+                                      ptr(xy), ptr(zc), current_stream()), "fp_project_vertices")
+    return xy, zc
 
 
 def depth_extents(depth: torch.Tensor, fx: float, fy: float, cx: float, cy: float) -> torch.Tensor:

@@ -93,8 +93,49 @@ def merge_topk(cand_scores: torch.Tensor, cand_idx: torch.Tensor, k: int) -> Tup
     return torch.from_numpy(np.take_along_axis(s, order, 1)), torch.from_numpy(np.take_along_axis(i, order, 1))
 
 
+PAD_SCORE = float("-inf")          # sentinel candidates of a shard with fewer than k rows: sort behind every real score ...
+PAD_INDEX = 2 ** 31 - 1            # ... and behind every real index
+
+
+def pad_candidates(s: torch.Tensor, i: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pad per-rank candidate lists [Q, kk <= k] to [Q, k] so that every rank contributes equally-shaped tensors to the
+    all-gather (shards differ in size by one row; with k > rows-per-shard the unpadded shapes would differ and hang RCCL)"""
+    kk = s.shape[1]
+    if kk == k:
+        return s, i
+    ps = torch.full((s.shape[0], k), PAD_SCORE, dtype=s.dtype, device=s.device)
+    pi = torch.full((i.shape[0], k), PAD_INDEX, dtype=i.dtype, device=i.device)
+    ps[:, :kk], pi[:, :kk] = s, i
+    return ps, pi
+
+
 def sharded_bank_topk(local_topk_fn, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """bank-row sharding: `local_topk_fn(queries, k)` returns this rank's (scores, GLOBAL indices); one all-gather
-    of Q*k pairs, then the same merge on every rank."""
-    s, i = local_topk_fn(queries, k)
+    """bank-row sharding: `local_topk_fn(queries, k)` returns this rank's (scores, GLOBAL indices), at most k and padded
+    here to exactly k; one all-gather of Q*k pairs, then the same merge on every rank.  k must not exceed the bank size."""
+    s, i = pad_candidates(*local_topk_fn(queries, k), k)
     return merge_topk(all_gather_cat(s, dim=1), all_gather_cat(i, dim=1), k)
+
+
+def soft_vote_reduce(scores: torch.Tensor, idx: torch.Tensor, frame_ids: torch.Tensor, n_rows: int):
+    """Video soft-vote as a sharded reduction (scripts/extract_proposals_ground_video.py:154-159,186-190: per frame and
+    object a dense [N] vector that is zero except at the frame's top-k rows, mean over frames, top-1 per object).
+
+    scores f32 / idx i32 [F_local, n_obj, k]: the sparse per-frame lists of THIS rank's frames; frame_ids i64 [F_local]
+    their global frame numbers.  The sparse lists are all-gathered (k*8 bytes per frame-object), and every rank builds the
+    same dense mean: frames are accumulated in ascending frame order with one float32 add per (frame, row) — a fixed order,
+    so all ranks (and a single-rank run) get bit-identical means; ties go to the lowest row.  Returns
+    (best_row i64 [n_obj], best_score f32 [n_obj], mean f32 [n_obj, n_rows])."""
+    F_loc, n_obj, k = scores.shape
+    s = all_gather_rows(scores.reshape(F_loc, n_obj * k).contiguous())
+    i = all_gather_rows(idx.reshape(F_loc, n_obj * k).contiguous())
+    f = all_gather_rows(frame_ids.reshape(F_loc, 1).to(scores.device))[:, 0]
+    order = torch.argsort(f, stable=True)
+    s, i = s[order].reshape(-1, n_obj, k), i[order].reshape(-1, n_obj, k).long()
+    acc = torch.zeros((n_obj, n_rows), dtype=torch.float32, device=scores.device)
+    for fr in range(s.shape[0]):
+        acc.scatter_add_(1, i[fr], s[fr])            # a frame's top-k rows are distinct: no colliding adds
+    acc /= float(s.shape[0])
+    best = acc.max(dim=1).values
+    rows = torch.arange(n_rows, device=acc.device)[None].expand(n_obj, -1)
+    best_row = torch.where(acc == best[:, None], rows, torch.full_like(rows, n_rows)).min(dim=1).values
+    return best_row, best, acc

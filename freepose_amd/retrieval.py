@@ -32,11 +32,13 @@ class TemplateBank:
         return cls(np.load(npy_path), ids, shard)
 
     def _local_topk(self, queries, k):
-        kk = min(k, self.hi - self.lo)
+        kk = min(k, self.hi - self.lo)          # a shard may hold fewer than k rows; sharded_bank_topk pads to k
         return ops.bank_topk(self.rows, queries, kk, idx_offset=self.lo)
 
     def topk(self, queries: torch.Tensor, k: int = 100):
-        """queries bf16 [Q,D] (already F.normalize'd FFA descriptors) -> (scores f32 [Q,k], idx i32 [Q,k])"""
+        """queries bf16 [Q,D] (already F.normalize'd FFA descriptors) -> (scores f32 [Q,k], idx i32 [Q,k]); k is clamped to
+        the bank size (torch.topk would raise; the reference always asks for 100 of 46 037)"""
+        k = min(int(k), self.N)
         if self.sharded:
             return parallel.sharded_bank_topk(self._local_topk, queries, k)
         return self._local_topk(queries, k)
@@ -70,14 +72,25 @@ class TemplateBank:
         names = [self.mesh_ids[j] if self.mesh_ids else int(j) for j in rows]
         return names, best_s[:, 0].cpu().numpy().tolist(), rows, fine
 
-    def soft_vote(self, per_frame_queries: List[torch.Tensor], k: int = 100):
-        """video soft-vote (ground_video.py:154-159,186-190): dense [N] score vectors with only each frame's top-k
-        filled, mean over frames, per-object arg-max.  per_frame_queries[f] is bf16 [n_obj, D]."""
-        n_obj = per_frame_queries[0].shape[0]
-        acc = torch.zeros((n_obj, self.N), dtype=torch.float32, device="cuda")
-        for q in per_frame_queries:
-            s, i = self.topk(q, min(k, self.N))
-            acc.scatter_add_(1, i.long(), s)
-        acc /= len(per_frame_queries)
-        best = acc.max(dim=1)
-        return best.indices.cpu().numpy(), best.values.cpu().numpy()
+    def frame_votes(self, queries: torch.Tensor, k: int = 100, topk: int = 0):
+        """sparse soft-vote contribution of ONE frame: (scores f32 [n_obj,k], rows i32 [n_obj,k]) — the coarse top-k scores
+        (topk == 0, ground_video.py:155-159) or each candidate's mean top-`topk` per-view score (:160-170)"""
+        s, i = self.topk(queries, k)
+        if topk:
+            s = ops.rerank_views(self.views, self.view_offsets, i, queries, topk)
+        return s, i
+
+    def soft_vote(self, per_frame_queries: List[torch.Tensor], k: int = 100, topk: int = 0, frame_ids: Optional[Sequence[int]] = None):
+        """video soft-vote (ground_video.py:154-159,186-190): dense [N] score vectors with only each frame's top-k filled,
+        mean over frames, per-object arg-max.  per_frame_queries[f] is bf16 [n_obj, D].  With `frame_ids` (the global numbers
+        of the frames THIS rank holds) the vote is a collective: sparse lists are all-gathered and every rank reduces them in
+        frame order (parallel.soft_vote_reduce) — identical result on all ranks and to a single-rank run.
+        Returns (best row per object, its mean score)."""
+        votes = [self.frame_votes(q, k, topk) for q in per_frame_queries]
+        s = torch.stack([v[0] for v in votes])
+        i = torch.stack([v[1] for v in votes])
+        fid = torch.arange(len(votes), dtype=torch.int64) if frame_ids is None else torch.as_tensor(list(frame_ids), dtype=torch.int64)
+        if frame_ids is None and parallel.world()[1] > 1:
+            raise ValueError("soft_vote under torch.distributed needs frame_ids (which frames this rank holds)")
+        rows, best, _ = parallel.soft_vote_reduce(s, i, fid, self.N)
+        return rows.cpu().numpy(), best.cpu().numpy()

@@ -25,6 +25,18 @@ from freepose_amd.src.pipeline.utils import Proposals, rle_to_mask
 CSV_COLUMNS = ["scene_id", "im_id", "obj_id", "score", "R", "t", "bbox_visib", "scale", "time"]
 
 
+def pose_row(scene_id, im_id, obj_id, score, TCO, bbox_xyxy, scale, t_scale=1000.0, time_value=0.2):
+    """one CSV record, formatted like the reference (image script :113-127: t in millimetres, time 0.2; video script
+    scripts/dino_inference_video.py:160-176: t_scale 1, time -1).  Pinned by tests/golden/csv_rows.npz."""
+    TCO = np.asarray(TCO, dtype=np.float64)
+    b = [int(x) for x in np.asarray(bbox_xyxy).reshape(-1)[:4]]
+    return {"scene_id": int(scene_id), "im_id": int(im_id), "obj_id": obj_id, "score": np.float32(score),
+            "R": " ".join(str(x) for x in TCO[:3, :3].flatten().tolist()),
+            "t": " ".join(str(x * t_scale) if t_scale != 1 else str(x) for x in TCO[:3, 3].tolist()),
+            "bbox_visib": " ".join(str(x) for x in [b[0], b[1], b[2] - b[0], b[3] - b[1]]),
+            "scale": scale, "time": time_value}
+
+
 def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, scales, layer, batch_size, bbox_extend,
                   t_scale=1000.0, time_value=0.2):
     """pose rows for the proposals of ONE image (the per-proposal hot loop, reference :104-127)."""
@@ -40,13 +52,8 @@ def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, s
         mesh = scene_props[i]["mesh"]
         out = model(prop, templates.get_template_by_name(mesh), K, boxes[i], scales[i], layer=layer, batch_size=batch_size,
                     query_feat=feats[i:i + 1])
-        TCO = out["TCO"][0]
-        b = out["bbox"].cpu().numpy()
-        rows.append({"scene_id": int(scene_id), "im_id": int(frame_id), "obj_id": mesh, "score": out["scores"][0],
-                     "R": " ".join(str(x) for x in TCO[:3, :3].flatten().tolist()),
-                     "t": " ".join(str(x * t_scale) for x in TCO[:3, 3].tolist()),
-                     "bbox_visib": " ".join(str(x) for x in [b[0], b[1], b[2] - b[0], b[3] - b[1]]),
-                     "scale": scales[i], "time": time_value})
+        rows.append(pose_row(scene_id, frame_id, mesh, out["scores"][0], out["TCO"][0], out["bbox"].cpu().numpy(), scales[i],
+                             t_scale=t_scale, time_value=time_value))
     return rows
 
 

@@ -28,7 +28,7 @@ from freepose_amd.src.dataloader.template import WebTemplateDataset
 from freepose_amd.src.pipeline.estimators.online_pose_estimator import DinoOnlinePoseEstimator
 from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
 from freepose_amd.src.pipeline.utils import Proposals, rle_to_mask
-from freepose_amd.scripts.dino_inference import CSV_COLUMNS
+from freepose_amd.scripts.dino_inference import CSV_COLUMNS, pose_row
 
 
 def guessed_intrinsics(h: int, w: int) -> np.ndarray:
@@ -114,11 +114,9 @@ def main(args):
         recs = []
         for r in packed.numpy():
             f, o = int(r[0]), int(r[1])
-            b = r[15:19]
-            recs.append({"scene_id": 0, "im_id": f, "obj_id": mesh_ids[o], "score": np.float32(r[2]),
-                         "R": " ".join(str(x) for x in r[3:12].tolist()), "t": " ".join(str(x) for x in r[12:15].tolist()),
-                         "bbox_visib": " ".join(str(int(x)) for x in [b[0], b[1], b[2] - b[0], b[3] - b[1]]),
-                         "scale": scales[o], "time": -1})
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = r[3:12].reshape(3, 3), r[12:15]
+            recs.append(pose_row(0, f, mesh_ids[o], r[2], T, r[15:19], scales[o], t_scale=1, time_value=-1))
         results_dir.mkdir(parents=True, exist_ok=True)
         pd.DataFrame(recs, columns=CSV_COLUMNS).to_csv(out_csv, index=False, header=True)
 

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from freepose_amd import ops
-from freepose_amd.mesh_io import mesh_arrays
+from freepose_amd.mesh_io import device_mesh, mesh_signature
 from freepose_amd.src.pipeline import refiner_utils
 
 
@@ -32,13 +32,13 @@ class TrackingRefiner:
 
     # ---- rendering / cropping --------------------------------------------------------------------------------------
     def _device_mesh(self, mesh) -> ops.Mesh:
-        key = id(mesh)
+        # keyed by identity AND content: the pipeline scales meshes in place (online_pose_estimator.py:60,64) and ids are recycled
+        key, sig = id(mesh), mesh_signature(mesh)
         hit = self._mesh_cache.get(key)
-        if hit is None:
-            v, f, c = mesh_arrays(mesh)
-            hit = ops.Mesh(v, f, c).set_ambient(5.0)                     # ambient_light=[5,5,5] (tracking_refiner.py:33)
+        if hit is None or hit[1] != sig:
+            hit = (device_mesh(mesh).set_ambient(5.0), sig)              # ambient_light=[5,5,5] (tracking_refiner.py:33)
             self._mesh_cache = {key: hit}
-        return hit
+        return hit[0]
 
     def _render(self, mesh, width, height, K, transform):
         """colour u8 [H,W,3] and metric depth f32 [H,W] of `mesh` under `transform` (object -> OpenCV camera)"""

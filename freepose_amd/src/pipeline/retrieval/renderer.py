@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from freepose_amd import ops
-from freepose_amd.mesh_io import mesh_arrays
+from freepose_amd.mesh_io import device_mesh, mesh_signature
 from freepose_amd.src.utils.bbox_utils import CropResizePad
 
 
@@ -84,13 +84,12 @@ class MeshRenderer:
     def _device_mesh(self, mesh) -> ops.Mesh:
         if isinstance(mesh, ops.Mesh):
             return mesh
-        key = id(mesh)
+        key, sig = id(mesh), mesh_signature(mesh)
         hit = self._mesh_cache.get(key)
-        v, f, c = mesh_arrays(mesh)
-        if hit is not None and hit[1] == (v.shape, f.shape, float(np.abs(v).sum())):
+        if hit is not None and hit[1] == sig:
             return hit[0]
-        dm = ops.Mesh(v, f, c)
-        self._mesh_cache = {key: (dm, (v.shape, f.shape, float(np.abs(v).sum())))}  # keep one: meshes are large
+        dm = device_mesh(mesh)
+        self._mesh_cache = {key: (dm, sig)}  # keep one: meshes are large
         return dm
 
     def _render(self, mesh, poses, thirds, scale=1.0) -> RenderBatch:

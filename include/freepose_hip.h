@@ -134,10 +134,26 @@ int fp_geodesic_select(fp_ctx* ctx, const double* d_grid, int G, const double* h
 /* vertices f32 [V,3], faces i32 [F,3], per-vertex colours u8 [V,3] or NULL (white).  All host pointers. */
 int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F,
                    const uint8_t* h_colors, fp_mesh** out);
+/* textured mesh, as pyrender.Mesh.from_trimesh(mesh) receives it from trimesh.load(obj, force='mesh') (renderer.py:43-45,70-72;
+ * scripts/dino_inference_video.py:93-101, scripts/render_templates.py:58-66): per-corner texture coordinates uv f32 [F,3,2]
+ * (OBJ `vt` convention: v up), diffuse texture u8 [th,tw,3] (image rows top to bottom), material diffuse factor kd f32 [3] or
+ * NULL (= 1,1,1).  Fragments are shaded with a perspective-correct bilinear texture fetch (REPEAT wrap, mip level 0); the
+ * exact arithmetic is the contract at the top of csrc/raster.hip.  All host pointers. */
+int fp_mesh_upload_textured(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F, const float* h_uv,
+                            const uint8_t* h_texture, int th, int tw, const float* h_kd3, fp_mesh** out);
 int fp_mesh_destroy(fp_mesh* mesh);
 /* ambient light factor of the scene the mesh is rendered in: 2 (default; renderer.py:53-55,80-82) or 5
- * (tracking_refiner.py:33); output colour = min(255, ambient * interpolated vertex colour) */
+ * (tracking_refiner.py:33) */
 int fp_mesh_set_ambient(fp_mesh* mesh, float ambient);
+/* output transfer: 1 (default) = gamma rule, u8 = round(255 (ambient c)^(1/2.2)) with sRGB-decoded texels (how a PBR ambient
+ * term reaches the frame buffer); 0 = linear rule, u8 = min(255, 255 ambient c + .5).  pyrender's shader is third-party and
+ * not in the reference tree, so neither is pinned; both are bit-exact against the oracle. */
+int fp_mesh_set_shading(fp_mesh* mesh, int mode);
+/* vertex stage of the rasteriser alone: window coordinates in 24.8 fixed point d_xy i32 [Hn,V,2] (x right, y down, pixel
+ * centres at +0.5; 0,0 for vertices at or behind the near plane) and camera-frame depth d_zc f32 [Hn,V].  Conventions pinned
+ * against the reference's K -> OpenGL projection (bop_toolkit_lib/renderer_py.py:186-231, renderer.py:37-41). */
+int fp_project_vertices(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx, float fy,
+                        float cx, float cy, int32_t* d_xy, float* d_zc, void* stream);
 /* poses f32 [Hn,4,4] (OpenCV camera frame, object->camera), intrinsics fx,fy,cx,cy, image W x Hh.
  * scale multiplies the vertices (rendering_scale 0.25).  Outputs rgb u8 [Hn,Hh,W,3], depth f32 [Hn,Hh,W]
  * (metric eye depth, 0 = background).  Ambient-only shading, no culling (renderer.py:53-55,66). */

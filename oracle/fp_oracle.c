@@ -380,18 +380,81 @@ void fpo_depth_extents(const float* depth, int Hn, int Hh, int W, double fx, dou
 typedef struct { int xi, yi; float iz, zc; } svert_t;
 static int topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
 
-void fpo_rasterize_amb(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
-                       const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
-                       uint8_t* rgb, float* depth, float ambient);
-void fpo_rasterize(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
-                   const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
-                   uint8_t* rgb, float* depth) {
-    fpo_rasterize_amb(verts, V, faces, F, colors, poses, Hn, scale, fx, fy, cx, cy, W, Hh, rgb, depth, 2.0f);
+/* Shading contract (shared with raster.hip; pyrender's shader is not in /root/reference, so this is a stated rule, not a pin):
+ *   base colour of a fragment, in [0,1]:
+ *     textured mesh : perspective-correct per-corner UV (U = fma(q2,u2, fma(q1,u1, q0*u0)) * depth, q_i = b_i*iz_i), bilinear
+ *                     filter of mip level 0 with REPEAT wrap, texel centres at integer+0.5, v = 1 is the image's first row:
+ *                     x = U*tw - 0.5, y = (1-V)*th - 0.5 ; (x0,y0) = floor ; weights (x-x0, y-y0) ;
+ *                     top = fma(wx, t01-t00, t00), bot = fma(wx, t11-t10, t10), val = fma(wy, bot-top, top) ; c = val*Kd
+ *                     texel value: shade 1 -> DEC[u8] (sRGB -> linear through a 256-entry table, i.e. decode BEFORE filtering, GL's
+ *                     SRGB8 behaviour), shade 0 -> float(u8)/255.f
+ *     vertex colours: cv = fma(q2,c2, fma(q1,c1, q0*c0)) * depth  (0..255 units, as before)
+ *   output: shade 0 (linear, the round-1 rule): u8(min(255, ambient*cv + 0.5))            [textured: cv = c*255.f]
+ *           shade 1 (gamma, default): u8 = #{ k in 1..255 : THR[k] <= ambient*c }, THR[k] = ((k-0.5)/255)^2.2 — i.e.
+ *           round(255 * x^(1/2.2)) evaluated by table search so host and device agree bit for bit      [vertex: c = cv*(1/255.f)] */
+static float g_dec[256], g_thr[256];
+static int g_tables_ready = 0;
+static void shade_tables(void) {
+    if (g_tables_ready) return;
+    for (int i = 0; i < 256; ++i) {
+        const double s = (double)i / 255.0;
+        g_dec[i] = (float)(s <= 0.04045 ? s / 12.92 : pow((s + 0.055) / 1.055, 2.4));
+        g_thr[i] = i == 0 ? 0.f : (float)pow(((double)i - 0.5) / 255.0, 2.2);
+    }
+    g_tables_ready = 1;
 }
+void fpo_shade_tables(float* dec256, float* thr256) { shade_tables(); memcpy(dec256, g_dec, 1024); memcpy(thr256, g_thr, 1024); }
+static uint8_t encode_gamma(float x) {
+    int lo = 0, hi = 255;                      /* largest k with THR[k] <= x (THR[0] = 0 <= x for x >= 0; NaN / negative -> 0) */
+    if (!(x > 0.f)) return 0;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (g_thr[mid] <= x) lo = mid; else hi = mid - 1; }
+    return (uint8_t)lo;
+}
+static int wrapi(int a, int n) { int m = a % n; return m < 0 ? m + n : m; }
+
+void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
+                       const float* uv /* [F,3,2] or NULL */, const uint8_t* tex /* [th,tw,3] or NULL */, int th, int tw,
+                       const float* kd3 /* or NULL = 1,1,1 */, const float* poses, int Hn, float scale, float fx, float fy,
+                       float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade);
 void fpo_rasterize_amb(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
                        const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
                        uint8_t* rgb, float* depth, float ambient) {
+    fpo_rasterize_tex(verts, V, faces, F, colors, NULL, NULL, 0, 0, NULL, poses, Hn, scale, fx, fy, cx, cy, W, Hh, rgb, depth, ambient, 0);
+}
+
+/* vertex stage alone: fixed-point 24.8 window coordinates (image convention: x right, y down, pixel centres at +0.5) and the
+ * camera-frame depth Zc.  Pinned against the reference's own K -> OpenGL projection (bop_toolkit_lib/renderer_py.py:186-231
+ * with the OpenCV->OpenGL flip of renderer.py:37-41) by tests/test_golden_cpu.py. */
+void fpo_project_vertices(const float* verts, int V, const float* poses, int Hn, float scale, float fx, float fy, float cx,
+                          float cy, int32_t* xy /* [Hn,V,2] */, float* zc /* [Hn,V] */) {
     const float ZNEAR = 0.05f;
+    for (int h = 0; h < Hn; ++h) {
+        const float* P = poses + (size_t)h * 16;
+        for (int i = 0; i < V; ++i) {
+            const float sx = scale * verts[3 * i], sy = scale * verts[3 * i + 1], sz = scale * verts[3 * i + 2];
+            const float Xc = fmaf(P[0], sx, fmaf(P[1], sy, fmaf(P[2], sz, P[3])));
+            const float Yc = fmaf(P[4], sx, fmaf(P[5], sy, fmaf(P[6], sz, P[7])));
+            const float Zc = fmaf(P[8], sx, fmaf(P[9], sy, fmaf(P[10], sz, P[11])));
+            int xi = 0, yi = 0;
+            if (Zc > ZNEAR) {
+                const float iz = 1.0f / Zc;
+                float u = fmaf(fx, Xc * iz, cx), v = fmaf(fy, Yc * iz, cy);
+                u = fminf(fmaxf(u, -30000.f), 30000.f); v = fminf(fmaxf(v, -30000.f), 30000.f);
+                xi = (int)rintf(u * 256.0f); yi = (int)rintf(v * 256.0f);
+            }
+            xy[((size_t)h * V + i) * 2] = xi; xy[((size_t)h * V + i) * 2 + 1] = yi;
+            zc[(size_t)h * V + i] = Zc;
+        }
+    }
+}
+
+void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors, const float* uv,
+                       const uint8_t* tex, int th, int tw, const float* kd3, const float* poses, int Hn, float scale, float fx,
+                       float fy, float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade) {
+    const float ZNEAR = 0.05f;
+    const int textured = uv && tex && th > 0 && tw > 0;
+    const float kd[3] = {kd3 ? kd3[0] : 1.f, kd3 ? kd3[1] : 1.f, kd3 ? kd3[2] : 1.f};
+    shade_tables();
     svert_t* sv = (svert_t*)malloc((size_t)V * sizeof(svert_t));
     uint64_t* zb = (uint64_t*)malloc((size_t)W * Hh * 8);
     for (int h = 0; h < Hn; ++h) {
@@ -452,9 +515,10 @@ void fpo_rasterize_amb(const float* verts, int V, const int32_t* faces, int F, c
                     const int f = (int)(uint32_t)(key & 0xffffffffu);
                     uint32_t db = (uint32_t)(key >> 32); memcpy(&d, &db, 4);
                     int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+                    int k0 = 0, k1 = 1, k2 = 2;                       /* corner order follows the orientation swap */
                     svert_t a = sv[i0], b = sv[i1], c = sv[i2];
                     int64_t area2 = (int64_t)(b.xi - a.xi) * (c.yi - a.yi) - (int64_t)(b.yi - a.yi) * (c.xi - a.xi);
-                    if (area2 < 0) { svert_t t = b; b = c; c = t; int ti = i1; i1 = i2; i2 = ti; area2 = -area2; }
+                    if (area2 < 0) { svert_t t = b; b = c; c = t; int ti = i1; i1 = i2; i2 = ti; k1 = 2; k2 = 1; area2 = -area2; }
                     const int64_t sx = (int64_t)px * 256 + 128, sy = (int64_t)py * 256 + 128;
                     const int64_t w0 = (int64_t)(c.xi - b.xi) * (sy - b.yi) - (int64_t)(c.yi - b.yi) * (sx - b.xi);
                     const int64_t w1 = (int64_t)(a.xi - c.xi) * (sy - c.yi) - (int64_t)(a.yi - c.yi) * (sx - c.xi);
@@ -464,13 +528,36 @@ void fpo_rasterize_amb(const float* verts, int V, const int32_t* faces, int F, c
                     const float izp = fmaf(b2, c.iz, fmaf(b1, b.iz, b0 * a.iz));
                     const float dd = 1.0f / izp;
                     const float q0 = b0 * a.iz, q1 = b1 * b.iz, q2 = b2 * c.iz;
-                    for (int ch = 0; ch < 3; ++ch) {
-                        float c0 = 255.f, c1 = 255.f, c2 = 255.f;
-                        if (colors) { c0 = (float)colors[3 * i0 + ch]; c1 = (float)colors[3 * i1 + ch]; c2 = (float)colors[3 * i2 + ch]; }
-                        const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
-                        float amb = fminf(ambient * cv + 0.5f, 255.0f);
-                        if (amb < 0.f) amb = 0.f;
-                        col[ch] = (uint8_t)amb;
+                    if (textured) {
+                        const float* t = uv + (size_t)f * 6;
+                        float U = fmaf(q2, t[2 * k2], fmaf(q1, t[2 * k1], q0 * t[2 * k0])) * dd;
+                        float Vv = fmaf(q2, t[2 * k2 + 1], fmaf(q1, t[2 * k1 + 1], q0 * t[2 * k0 + 1])) * dd;
+                        float x = fmaf(U, (float)tw, -0.5f), y = fmaf(1.0f - Vv, (float)th, -0.5f);
+                        x = fminf(fmaxf(x, -1.0e6f), 1.0e6f); y = fminf(fmaxf(y, -1.0e6f), 1.0e6f);
+                        if (!(x == x)) x = 0.f;
+                        if (!(y == y)) y = 0.f;
+                        const float xf = floorf(x), yf = floorf(y);
+                        const float wx = x - xf, wy = y - yf;
+                        const int x0 = wrapi((int)xf, tw), x1 = wrapi((int)xf + 1, tw);
+                        const int y0 = wrapi((int)yf, th), y1 = wrapi((int)yf + 1, th);
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const uint8_t e00 = tex[((size_t)y0 * tw + x0) * 3 + ch], e01 = tex[((size_t)y0 * tw + x1) * 3 + ch];
+                            const uint8_t e10 = tex[((size_t)y1 * tw + x0) * 3 + ch], e11 = tex[((size_t)y1 * tw + x1) * 3 + ch];
+                            const float t00 = shade ? g_dec[e00] : (float)e00 / 255.f, t01 = shade ? g_dec[e01] : (float)e01 / 255.f;
+                            const float t10 = shade ? g_dec[e10] : (float)e10 / 255.f, t11 = shade ? g_dec[e11] : (float)e11 / 255.f;
+                            const float top = fmaf(wx, t01 - t00, t00), bot = fmaf(wx, t11 - t10, t10);
+                            const float cl = fmaf(wy, bot - top, top) * kd[ch];
+                            if (shade) col[ch] = encode_gamma(ambient * cl);
+                            else { float amb = fminf(ambient * (cl * 255.f) + 0.5f, 255.0f); if (amb < 0.f) amb = 0.f; col[ch] = (uint8_t)amb; }
+                        }
+                    } else {
+                        for (int ch = 0; ch < 3; ++ch) {
+                            float c0 = 255.f, c1 = 255.f, c2 = 255.f;
+                            if (colors) { c0 = (float)colors[3 * i0 + ch]; c1 = (float)colors[3 * i1 + ch]; c2 = (float)colors[3 * i2 + ch]; }
+                            const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
+                            if (shade) col[ch] = encode_gamma(ambient * (cv * (1.0f / 255.f)));
+                            else { float amb = fminf(ambient * cv + 0.5f, 255.0f); if (amb < 0.f) amb = 0.f; col[ch] = (uint8_t)amb; }
+                        }
                     }
                 }
                 depth[((size_t)h * Hh + py) * W + px] = d;

@@ -195,15 +195,41 @@ def roi_align(images: np.ndarray, rois: np.ndarray, ph: int, pw: int, sampling_r
     return out
 
 
-def rasterize(verts, faces, colors, poses, scale, fx, fy, cx, cy, W, H, ambient: float = 2.0):
+def rasterize(verts, faces, colors, poses, scale, fx, fy, cx, cy, W, H, ambient: float = 2.0, shade: int = 1, uv=None, texture=None,
+              kd=None):
+    """colors u8 [V,3] | None; uv f32 [F,3,2] + texture u8 [th,tw,3] select the textured path; shade 1 = gamma rule, 0 = linear"""
     v = np.ascontiguousarray(verts, dtype=np.float32)
     f = np.ascontiguousarray(faces, dtype=np.int32)
     c = None if colors is None else np.ascontiguousarray(colors[:, :3], dtype=np.uint8)
     p = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+    t = None if uv is None else np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 6)
+    x = None if texture is None else np.ascontiguousarray(texture[:, :, :3], dtype=np.uint8)
+    k = None if kd is None else np.ascontiguousarray(kd, dtype=np.float32)
+    th, tw = (x.shape[0], x.shape[1]) if x is not None else (0, 0)
+    assert t is None or t.shape[0] == f.shape[0]
     Hn = p.shape[0]
     rgb = np.empty((Hn, H, W, 3), dtype=np.uint8)
     depth = np.empty((Hn, H, W), dtype=np.float32)
-    lib().fpo_rasterize_amb(_p(v), C.c_int(v.shape[0]), _p(f), C.c_int(f.shape[0]), _p(c), _p(p), C.c_int(Hn), C.c_float(scale),
-                            C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_int(W), C.c_int(H), _p(rgb), _p(depth),
-                            C.c_float(ambient))
+    lib().fpo_rasterize_tex(_p(v), C.c_int(v.shape[0]), _p(f), C.c_int(f.shape[0]), _p(c), _p(t), _p(x), C.c_int(th), C.c_int(tw),
+                            _p(k), _p(p), C.c_int(Hn), C.c_float(scale), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                            C.c_int(W), C.c_int(H), _p(rgb), _p(depth), C.c_float(ambient), C.c_int(shade))
     return rgb, depth
+
+
+def project_vertices(verts, poses, scale, fx, fy, cx, cy):
+    """vertex stage of the rasteriser: (xy i32 [Hn,V,2] in 1/256 px, zc f32 [Hn,V])"""
+    v = np.ascontiguousarray(verts, dtype=np.float32)
+    p = np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 16)
+    Hn, V = p.shape[0], v.shape[0]
+    xy = np.empty((Hn, V, 2), dtype=np.int32)
+    zc = np.empty((Hn, V), dtype=np.float32)
+    lib().fpo_project_vertices(_p(v), C.c_int(V), _p(p), C.c_int(Hn), C.c_float(scale), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                               C.c_float(cy), _p(xy), _p(zc))
+    return xy, zc
+
+
+def shade_tables():
+    dec = np.empty(256, np.float32)
+    thr = np.empty(256, np.float32)
+    lib().fpo_shade_tables(_p(dec), _p(thr))
+    return dec, thr

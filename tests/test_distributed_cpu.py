@@ -49,6 +49,31 @@ def _worker(rank, world, port, tmp):
     s_ref, i_ref = fo.bank_topk(bank_bits, q_bits, k)
     assert np.array_equal(i.numpy(), i_ref) and np.array_equal(s.numpy(), s_ref)
 
+    # k larger than the smaller shard (751 vs 750 rows): per-rank lists are padded with sentinels to equal shapes
+    s2, i2 = parallel.sharded_bank_topk(local, None, 751)
+    s2_ref, i2_ref = fo.bank_topk(bank_bits, q_bits, 751)
+    assert np.array_equal(i2.numpy(), i2_ref) and np.array_equal(s2.numpy(), s2_ref)
+    assert int(i2.max()) < N and bool(torch.isfinite(s2).all())
+
+    # ---- video soft-vote as a sharded reduction (extract_proposals_ground_video.py:154-159,186-190) -------------
+    n_frames, n_obj, kk = 7, 3, 20
+    fr_q = fo.l2norm_rows(fo.to_bf16_bits(rng.standard_normal((n_frames * n_obj, D)).astype(np.float32))).reshape(n_frames, n_obj, D)
+    lists = [fo.bank_topk(bank_bits, fr_q[f], kk) for f in range(n_frames)]
+    mine = parallel.shard_items(n_frames, rank, world)
+    best_row, best, mean = parallel.soft_vote_reduce(torch.from_numpy(np.stack([lists[f][0] for f in mine])),
+                                                     torch.from_numpy(np.stack([lists[f][1] for f in mine])),
+                                                     torch.tensor(mine, dtype=torch.int64), N)
+    dense = np.zeros((n_frames, n_obj, N), np.float32)      # the reference's dense formulation, frame order, float32
+    for f in range(n_frames):
+        for o in range(n_obj):
+            dense[f, o, lists[f][1][o]] = lists[f][0][o]
+    acc = np.zeros((n_obj, N), np.float32)
+    for f in range(n_frames):
+        acc = acc + dense[f]
+    acc = acc / np.float32(n_frames)
+    assert np.array_equal(mean.numpy(), acc)
+    assert np.array_equal(best_row.numpy(), acc.argmax(axis=1)) and np.array_equal(best.numpy(), acc.max(axis=1))
+
     # ---- proposal / object sharding: round-robin items, variable rows per rank ---------------------------
     items = parallel.shard_items(7, rank, world)
     assert items == ([0, 2, 4, 6], [1, 3, 5])[rank]

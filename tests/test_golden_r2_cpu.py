@@ -1,0 +1,210 @@
+"""Round-2 pins (no GPU): the oracle's vertex stage against the reference tree's own K -> OpenGL projection, the CSV row format
+against the reference's own formatting statements, known answers of the oracle's texture sampling, and the OBJ/MTL reader.
+Fixtures: oracle/gen_golden_r2.py -> tests/golden/{projection,csv_rows}.npz."""
+import io
+
+import numpy as np
+import pytest
+
+from oracle import fp_oracle as fo
+from tests._meshes import checker_gradient_texture, textured_cube, write_textured_obj
+
+
+def _g(golden_dir, name):
+    return np.load(golden_dir / name, allow_pickle=True)
+
+
+# ---- a11: vertex stage vs bop_toolkit_lib/renderer_py.py:186-231 + renderer.py:37-41 ------------------------
+def test_vertex_stage_matches_reference_projection(golden_dir):
+    g = _g(golden_dir, "projection.npz")
+    for name in g["names"]:
+        K, (W, H), scale = g[f"{name}_K"], g[f"{name}_WH"], float(g[f"{name}_scale"])
+        xy, zc = fo.project_vertices(g[f"{name}_verts"], g[f"{name}_poses"], scale, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        ref_xy, ref_z = g[f"{name}_xy"], g[f"{name}_zeye"]
+        vis = (ref_z > 0.06) & (np.abs(ref_xy).max(axis=-1) < 20000)       # in front of the near plane (0.05), not clamped
+        assert vis.mean() > 0.8
+        # window coordinates: pixel centres at +0.5, x right, y down; 24.8 fixed point => |err| <= half a sub-pixel + fp32 noise
+        err = np.abs(xy.astype(np.float64) / 256.0 - ref_xy)[vis]
+        assert err.max() <= 0.5 / 256 + 1e-3 * np.abs(ref_xy[vis]).max() / 1000, (name, err.max())
+        # eye depth is the camera-frame z (linear, metres), not a normalised depth-buffer value
+        assert np.allclose(zc[vis], ref_z[vis], rtol=2e-6, atol=1e-7)
+        assert (xy[ref_z < 0.04] == 0).all()                                 # at / behind the near plane: dropped
+
+
+def test_rendered_depth_is_eye_depth_at_projected_vertex(golden_dir):
+    """a fronto-parallel quad at z = 1.3 rendered by the oracle: depth image == 1.3 inside, 0 outside, and its silhouette
+    ends where the reference projection puts the quad's corners (pixel p is covered iff its centre p + .5 is inside)"""
+    v = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    P = np.eye(4, dtype=np.float32)
+    P[:3, 3] = [0.013, -0.021, 1.3]
+    fx, fy, cx, cy, W, H = 600.0, 590.0, 210.0, 200.0, 420, 400
+    _, d = fo.rasterize(v, f, None, P[None], 0.25, fx, fy, cx, cy, W, H)
+    u0, u1 = fx * (-0.25 + 0.013) / 1.3 + cx, fx * (0.25 + 0.013) / 1.3 + cx
+    v0, v1 = fy * (-0.25 - 0.021) / 1.3 + cy, fy * (0.25 - 0.021) / 1.3 + cy
+    cols = np.where((d[0] > 0).any(axis=0))[0]
+    rows = np.where((d[0] > 0).any(axis=1))[0]
+    assert cols.min() == int(np.ceil(u0 - 0.5)) and cols.max() == int(np.floor(u1 - 0.5 - 1e-9))
+    assert rows.min() == int(np.ceil(v0 - 0.5)) and rows.max() == int(np.floor(v1 - 0.5 - 1e-9))
+    assert np.allclose(d[0][d[0] > 0], 1.3, rtol=1e-6)
+
+
+# ---- a12: CSV rows vs scripts/dino_inference.py:113-130 and scripts/dino_inference_video.py:160-182 -----------
+def test_csv_rows_match_reference_format(golden_dir):
+    import pandas as pd
+    from freepose_amd.scripts.dino_inference import CSV_COLUMNS, pose_row
+    g = _g(golden_dir, "csv_rows.npz")
+    meshes, scales = [str(m) for m in g["meshes"]], [float(s) for s in g["scales"]]
+    rows = [pose_row("48", 7 + i, meshes[i], g["scores"][i][0], g["tco"][i], g["bbox"][i], scales[i]) for i in range(4)]
+    buf = io.StringIO()
+    pd.DataFrame(rows, columns=CSV_COLUMNS).to_csv(buf, index=False, header=True)
+    assert buf.getvalue() == str(g["image_csv"])
+    rows = [pose_row(0, fr, meshes[o], g["scores"][2 * fr + o][0], g["tco"][2 * fr + o], g["bbox"][2 * fr + o], scales[o],
+                     t_scale=1, time_value=-1) for fr in range(2) for o in range(2)]
+    buf = io.StringIO()
+    pd.DataFrame(rows, columns=CSV_COLUMNS).to_csv(buf, index=False, header=True)
+    assert buf.getvalue() == str(g["video_csv"])
+    # the bop_toolkit reader expects exactly 9 comma-separated fields (bop_toolkit_lib/inout.py:297-347)
+    for line in buf.getvalue().strip().splitlines():
+        assert len(line.split(",")) == 9
+
+
+# ---- a11: texture sampling known answers (oracle; the HIP kernels are compared bit for bit in test_gpu_raster_textured.py) ----
+def _quad(z=1.0):
+    v = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    P = np.eye(4, dtype=np.float32)
+    P[2, 3] = z
+    return v, f, P
+
+
+def test_texel_pattern_survives_linear_shading():
+    """8 x 8 texture on a fronto-parallel quad covering exactly 8 x 8 blocks of 5 x 5 pixels: block centres coincide with
+    texel centres, so bilinear filtering returns the texel itself; OBJ convention: v = 1 is the image's first row, and the
+    camera looks along +z with y down, so object +y is image-down."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    tex = rng.integers(0, 256, size=(8, 8, 3), dtype=np.uint8)
+    v, f, P = _quad(1.0)
+    # quad spans x,y in [-0.5, 0.5] * ... : scale 0.1 -> [-0.1, 0.1] m at z = 1 with f = 200 -> 40 px wide, centred at 20
+    uv_corner = {0: (0.0, 1.0), 1: (1.0, 1.0), 2: (1.0, 0.0), 3: (0.0, 0.0)}      # top-left vertex (x-, y-) gets v = 1
+    uv = np.array([[uv_corner[i] for i in tri] for tri in f], np.float32)
+    rgb, d = fo.rasterize(v, f, None, P[None], 0.1, 200.0, 200.0, 20.0, 20.0, 40, 40, ambient=1.0, shade=0, uv=uv, texture=tex)
+    assert (d[0] > 0).all()
+    centres = rgb[0][2::5, 2::5]
+    assert np.array_equal(centres, tex)
+    # wrap = REPEAT: shifting every coordinate by whole periods changes nothing
+    rgb2, _ = fo.rasterize(v, f, None, P[None], 0.1, 200.0, 200.0, 20.0, 20.0, 40, 40, ambient=1.0, shade=0, uv=uv + [2.0, -3.0], texture=tex)
+    assert np.array_equal(rgb2, rgb)
+    # reversing a triangle's winding (orientation swap inside the rasteriser) must carry the corner attributes along
+    f2, uv2 = f.copy(), uv.copy()
+    f2[1] = f2[1][[0, 2, 1]]
+    uv2[1] = uv2[1][[0, 2, 1]]
+    rgb3, _ = fo.rasterize(v, f2, None, P[None], 0.1, 200.0, 200.0, 20.0, 20.0, 40, 40, ambient=1.0, shade=0, uv=uv2, texture=tex)
+    assert np.array_equal(rgb3, rgb)
+    # between two texel centres the filter is the linear blend
+    a, b = tex[3, 2].astype(np.float64), tex[3, 3].astype(np.float64)
+    mid = rgb[0][3 * 5 + 2, 2 * 5 + 2 + 2].astype(np.float64)          # 2 px right of texel (3,2)'s centre: weight 0.4
+    assert np.abs(mid - (0.6 * a + 0.4 * b)).max() <= 1.0
+
+
+def test_gamma_shading_rule_and_material_factor():
+    dec, thr = fo.shade_tables()
+    assert dec[0] == 0 and abs(dec[255] - 1) < 1e-6 and abs(dec[128] - 0.21586) < 1e-4 and (np.diff(dec) > 0).all()
+    assert (np.diff(thr[1:]) > 0).all()
+    tex = np.zeros((4, 4, 3), np.uint8)
+    tex[..., 0], tex[..., 1], tex[..., 2] = 64, 128, 250
+    v, f, P = _quad(1.0)
+    uv = np.array([[(0.1, 0.1), (0.9, 0.1), (0.9, 0.9)], [(0.1, 0.1), (0.9, 0.9), (0.1, 0.9)]], np.float32)
+    for amb, kd in ((2.0, None), (5.0, None), (2.0, (0.5, 1.0, 0.25))):
+        rgb, _ = fo.rasterize(v, f, None, P[None], 0.1, 200.0, 200.0, 20.0, 20.0, 40, 40, ambient=amb, shade=1, uv=uv, texture=tex, kd=kd)
+        k = np.ones(3) if kd is None else np.array(kd)
+        lin = np.array([dec[64], dec[128], dec[250]], np.float64) * k * amb
+        want = np.clip(np.round(255.0 * np.clip(lin, 0, 1) ** (1 / 2.2)), 0, 255)
+        assert np.abs(rgb[0, 20, 20].astype(np.float64) - want).max() <= 1, (amb, kd)
+    # vertex colours go through the same transfer: 2 * (64/255) -> (0.50)^(1/2.2) * 255 = 186
+    col = np.full((4, 3), 64, np.uint8)
+    rgb, _ = fo.rasterize(v, f, col, P[None], 0.1, 200.0, 200.0, 20.0, 20.0, 40, 40, ambient=2.0, shade=1)
+    assert abs(int(rgb[0, 20, 20, 0]) - round(255 * (2 * 64 / 255) ** (1 / 2.2))) <= 1
+    rgb, _ = fo.rasterize(v, f, col, P[None], 0.1, 200.0, 200.0, 20.0, 20.0, 40, 40, ambient=2.0, shade=0)
+    assert int(rgb[0, 20, 20, 0]) == 128
+
+
+def test_texture_lookup_is_perspective_correct():
+    """a quad tilted about the vertical axis: the screen-space midpoint between its left and right edges shows the texel at
+    the perspective-correct u (< 0.5 towards the far edge), not the affine one"""
+    n = 64
+    tex = np.zeros((n, n, 3), np.uint8)
+    tex[..., 0] = np.arange(n)[None, :] * 4              # red encodes the column
+    v, f, _ = _quad()
+    uv = np.array([[(0, 1), (1, 1), (1, 0)], [(0, 1), (1, 0), (0, 0)]], np.float32)
+    th = np.deg2rad(55.0)
+    P = np.eye(4, dtype=np.float32)
+    P[:3, :3] = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+    P[2, 3] = 1.0
+    fx = 300.0
+    rgb, d = fo.rasterize(v, f, None, P[None], 0.25, fx, fx, 100.0, 100.0, 200, 200, ambient=1.0, shade=0, uv=uv, texture=tex)
+    row = 100
+    cols = np.where(d[0, row] > 0)[0]
+    px = (cols.min() + cols.max()) // 2
+    # analytic: pixel centre -> ray -> intersection with the quad's plane -> object x in [-0.25, 0.25] -> u
+    xn = (px + 0.5 - 100.0) / fx
+    # points on the quad: X = R @ (s, y, 0) + t ; x/z = xn  =>  s*cos = xn*(1 - s*sin)
+    s = xn / (np.cos(th) + xn * np.sin(th))
+    u = (s / 0.25 + 1) / 2
+    want = (u * n - 0.5) * 4
+    assert abs(float(rgb[0, row, px, 0]) - want) <= 4.5
+    affine_u = 0.5
+    assert abs(u - affine_u) > 0.05                      # the test distinguishes the two
+
+
+# ---- mesh reader -------------------------------------------------------------------------------------------------
+def test_load_obj_keeps_per_corner_uv_texture_and_kd(tmp_path):
+    from freepose_amd.mesh_io import load_obj, mesh_appearance, mesh_signature
+    tex = checker_gradient_texture(64)
+    path = write_textured_obj(tmp_path / "m", "cube", tex, kd=(0.8, 0.6, 1.0))
+    m = load_obj(path)
+    v, f, uv = textured_cube()
+    assert np.array_equal(m.faces, f) and np.allclose(m.vertices, v)
+    assert m.uv.shape == (12, 3, 2) and np.allclose(m.uv, uv, atol=1e-6)       # seams keep their own coordinates per corner
+    assert np.array_equal(m.texture, tex) and np.allclose(m.kd, [0.8, 0.6, 1.0])
+    app = mesh_appearance(m)
+    assert set(app) == {"uv", "texture", "kd"}
+    sig = mesh_signature(m)
+    m.apply_scale(0.25)
+    assert mesh_signature(m) != sig                      # in-place scaling invalidates device-mesh caches
+
+
+def test_load_obj_multi_material_atlas(tmp_path):
+    from PIL import Image
+    from freepose_amd.mesh_io import load_obj
+    d = tmp_path / "mm"
+    d.mkdir()
+    t0 = np.full((8, 8, 3), (200, 10, 10), np.uint8)
+    Image.fromarray(t0, "RGB").save(d / "a.png")
+    (d / "m.mtl").write_text("newmtl red\nKd 1 1 1\nmap_Kd a.png\nnewmtl blue\nKd 0.0 0.0 1.0\n")
+    (d / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+                             "usemtl red\nf 1/1 2/2 3/3\nusemtl blue\nf 1 3 4\n")
+    m = load_obj(d / "m.obj")
+    assert m.texture is not None and m.uv.shape == (2, 3, 2)
+    h, w = m.texture.shape[:2]
+
+    def texel(u, v):
+        return m.texture[min(h - 1, int((1 - v) * h)), min(w - 1, int(u * w))]
+    assert tuple(texel(*m.uv[0].mean(axis=0))) == (200, 10, 10)
+    assert tuple(texel(*m.uv[1].mean(axis=0))) == (0, 0, 255)
+
+
+def test_trimesh_like_texture_visual_is_honoured():
+    """objects shaped like trimesh.Trimesh with TextureVisuals (per-vertex uv + material.image) must not render white"""
+    import types
+    from PIL import Image
+    from freepose_amd.mesh_io import mesh_appearance
+    v, f, uv = textured_cube()
+    vv = v[f.reshape(-1)]                                 # trimesh duplicates vertices per (v, vt) pair
+    ff = np.arange(len(vv), dtype=np.int32).reshape(-1, 3)
+    img = Image.fromarray(checker_gradient_texture(32), "RGB")
+    mat = types.SimpleNamespace(image=img, diffuse=np.array([255, 128, 255, 255], np.uint8))
+    mesh = types.SimpleNamespace(vertices=vv, faces=ff, visual=types.SimpleNamespace(uv=uv.reshape(-1, 2), material=mat))
+    app = mesh_appearance(mesh)
+    assert np.allclose(app["uv"], uv) and app["texture"].shape == (32, 32, 3)
+    assert np.allclose(app["kd"], [1.0, 128 / 255, 1.0])

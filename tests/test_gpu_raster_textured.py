@@ -1,0 +1,183 @@
+"""GPU parity (through the C ABI) for the round-2 rasteriser work: per-fragment UV texture sampling (both visibility
+strategies, both shading rules, bit for bit against oracle/fp_oracle.c), the vertex-stage export against the oracle and the
+reference-projection golden, the render_templates round trip on a textured OBJ, and the WebTemplateDataset mirror against the
+golden produced by the REFERENCE's loader on the same synthetic shard."""
+import hashlib
+import tarfile
+
+import numpy as np
+import pytest
+import torch
+
+from tests._meshes import checker_gradient_texture, textured_cube, write_textured_obj
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _poses(n, seed=0):
+    from oracle import fp_oracle as fo
+    P = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    P[:, :3, :3] = fo.generate_rotations(n)
+    P[:, :3, 3] = [0, 0, 1.1]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    P[n - 1, :3, 3] = [0.25, -0.15, 0.8]         # partly off-screen, strongly minified / magnified mix
+    P[0, :3, 3] = [0.0, 0.0, 0.45]               # very close: magnification (bilinear weights matter)
+    _ = rng
+    return P
+
+
+@pytest.mark.parametrize("W,H,shade,ambient,kd", [(420, 420, 1, 2.0, None), (420, 420, 0, 2.0, None), (518, 518, 1, 5.0, (0.9, 0.5, 1.0)),
+                                                  (300, 200, 0, 1.0, (1.0, 1.0, 0.25)), (704, 480, 1, 2.0, None)])
+def test_textured_cube_bit_exact_both_strategies(W, H, shade, ambient, kd):
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    v, f, uv = textured_cube()
+    tex = checker_gradient_texture(256)
+    poses = _poses(6)
+    fx = 600.0 * W / 420
+    rgb_o, d_o = fo.rasterize(v, f, None, poses, 0.25, fx, fx, W / 2, H / 2, W, H, ambient=ambient, shade=shade, uv=uv, texture=tex, kd=kd)
+    mesh = ops.Mesh(v, f, uv=uv, texture=tex, kd=kd).set_ambient(ambient).set_shading(shade)
+    try:
+        for mode in (1, 0):
+            ops.set_option("raster_tiled", mode)
+            rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(poses), 0.25, fx, fx, W / 2, H / 2, W, H)
+            assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32)), f"depth differs (tiled={mode})"
+            diff = rgb_g.cpu().numpy() != rgb_o
+            assert not diff.any(), f"rgb differs at {int(diff.sum())} values (tiled={mode})"
+    finally:
+        ops.set_option("raster_tiled", -1)
+    cov = d_o > 0
+    assert cov.mean() > 0.1
+    # the texture is really on screen: many distinct colours, not a flat fill
+    assert len(np.unique(rgb_o[cov].reshape(-1, 3), axis=0)) > 500
+
+
+def test_textured_dense_mesh_and_repeat_wrap_bit_exact():
+    """displaced icosphere (20 480 triangles) with spherical uv scaled x3 (REPEAT wrap in play, seam triangles span a period)"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    from tests.test_gpu_retrieval import _icosphere
+    v, f = _icosphere(5)
+    v = (v * (1 + 0.15 * np.sin(5 * v[:, :1]))).astype(np.float32)
+    f = f.astype(np.int32)
+    p = v / np.linalg.norm(v, axis=1, keepdims=True)
+    vuv = np.stack([np.arctan2(p[:, 1], p[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(p[:, 2], -1, 1)) / np.pi], axis=1)
+    uv = (3.0 * vuv[f.reshape(-1)]).reshape(-1, 3, 2).astype(np.float32)
+    tex = checker_gradient_texture(128, cells=16, seed=8)
+    poses = _poses(4)
+    poses[0, :3, 3] = [0, 0, 1.1]
+    rgb_o, d_o = fo.rasterize(v, f, None, poses, 0.25, 600, 600, 210, 210, 420, 420, uv=uv, texture=tex)
+    mesh = ops.Mesh(v, f, uv=uv, texture=tex)
+    try:
+        for mode in (1, 0):
+            ops.set_option("raster_tiled", mode)
+            rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(poses), 0.25, 600, 600, 210, 210, 420, 420)
+            assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
+            assert np.array_equal(rgb_g.cpu().numpy(), rgb_o)
+    finally:
+        ops.set_option("raster_tiled", -1)
+
+
+def test_texel_pattern_known_answer_on_device():
+    """same construction as the oracle's CPU known-answer test: texel centres land on pixel centres -> exact texels"""
+    from freepose_amd import ops
+    rng = np.random.Generator(np.random.PCG64(9))
+    tex = rng.integers(0, 256, size=(8, 8, 3), dtype=np.uint8)
+    v = np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    corner = {0: (0.0, 1.0), 1: (1.0, 1.0), 2: (1.0, 0.0), 3: (0.0, 0.0)}
+    uv = np.array([[corner[i] for i in tri] for tri in f], np.float32)
+    P = np.eye(4, dtype=np.float32)
+    P[2, 3] = 1.0
+    mesh = ops.Mesh(v, f, uv=uv, texture=tex).set_ambient(1.0).set_shading(0)
+    rgb, d = ops.rasterize(mesh, torch.from_numpy(P[None]), 0.1, 200.0, 200.0, 20.0, 20.0, 40, 40)
+    assert bool((d > 0).all())
+    assert np.array_equal(rgb[0].cpu().numpy()[2::5, 2::5], tex)
+
+
+def test_project_vertices_matches_oracle_and_reference_golden(golden_dir):
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    g = np.load(golden_dir / "projection.npz", allow_pickle=True)
+    for name in g["names"]:
+        K, scale = g[f"{name}_K"], float(g[f"{name}_scale"])
+        verts, poses = g[f"{name}_verts"], g[f"{name}_poses"].astype(np.float32)
+        faces = np.array([[0, 1, 2]], np.int32)
+        mesh = ops.Mesh(verts, faces)
+        xy_g, zc_g = ops.project_vertices(mesh, torch.from_numpy(poses), scale, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        xy_o, zc_o = fo.project_vertices(verts, poses, scale, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        assert np.array_equal(xy_g.cpu().numpy(), xy_o)
+        assert np.array_equal(zc_g.cpu().numpy().view(np.uint32), zc_o.view(np.uint32))
+        ref_xy, ref_z = g[f"{name}_xy"], g[f"{name}_zeye"]
+        vis = (ref_z > 0.06) & (np.abs(ref_xy).max(axis=-1) < 20000)
+        err = np.abs(xy_g.cpu().numpy().astype(np.float64) / 256.0 - ref_xy)[vis]
+        assert err.max() <= 0.5 / 256 + 1e-3 * np.abs(ref_xy[vis]).max() / 1000
+
+
+def test_render_templates_roundtrip_textured_obj(tmp_path, monkeypatch):
+    """OBJ + MTL + PNG texture -> scripts.render_templates -> shard -> WebTemplateDataset: views equal a direct textured
+    render, which equals the oracle's textured render of the same arrays"""
+    from freepose_amd.mesh_io import load_obj
+    from freepose_amd.src.dataloader.template import WebTemplateDataset
+    from freepose_amd.src.pipeline.retrieval.renderer import MeshRenderer
+    from oracle import fp_oracle as fo
+    from scripts import render_templates
+    from tests.test_gpu_pipeline import ops_crop_identity
+    n_views = 8
+    tex = checker_gradient_texture(128)
+    write_textured_obj(tmp_path / "mesh_cache" / "cube_t", "cube_t", tex, kd=(1.0, 0.8, 0.9))
+    (tmp_path / "list.txt").write_text("cube_t\n")
+    monkeypatch.delenv("SLURM_ARRAY_TASK_ID", raising=False)
+    tar_path = render_templates.run(["--filelist", str(tmp_path / "list.txt"), "--mesh_root", str(tmp_path / "mesh_cache"),
+                                     "--datasets_root", str(tmp_path / "datasets"), "--shards_folder", "sh", "--n_views", str(n_views)])
+    with tarfile.open(tar_path) as tar:
+        assert "cubet_0.rgb.png" in tar.getnames()
+    (tmp_path / "list.csv").write_text("model_name\ncube_t\n")
+    s = WebTemplateDataset(str(tmp_path / "datasets" / "sh"), str(tmp_path / "list.csv"), crop=False, n_views=n_views)[0]
+    mesh = load_obj(tmp_path / "mesh_cache" / "cube_t" / "cube_t.obj")
+    assert mesh.uv is not None and mesh.texture is not None
+    r = MeshRenderer(n_views)
+    direct = r.render(mesh, scale=0.25)
+    assert torch.equal(s["templates"].cpu(), ops_crop_identity(direct.rgb).cpu())
+    rgb_o, d_o = fo.rasterize(mesh.vertices, mesh.faces, None, np.array(r.mesh_poses, np.float32), 0.25, 600, 600, 210, 210, 420, 420,
+                              uv=mesh.uv, texture=mesh.texture, kd=mesh.kd)
+    assert np.array_equal(direct.rgb.cpu().numpy(), rgb_o)
+    assert np.array_equal(direct.depth.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
+    assert len(np.unique(rgb_o[d_o > 0].reshape(-1, 3), axis=0)) > 300
+
+
+def test_web_template_dataset_matches_reference_golden(tmp_path, golden_dir):
+    """the reference's WebTemplateDataset.get_template_by_name (src/dataloader/template.py:46-99) was run on the shard that
+    tests/synth_shard.py writes (oracle/gen_golden_r2.py); the mirror must return the same tensors: crops bit for bit
+    (incl. bbox_extend, the < 100 px fallback square and empty views), masks, depths, boxes, dtypes, names"""
+    from freepose_amd.src.dataloader.template import WebTemplateDataset
+    from tests import synth_shard
+    g = np.load(golden_dir / "template_dataset.npz", allow_pickle=True)
+    names = synth_shard.write_shard(tmp_path)
+    assert names == [str(n) for n in g["names"]]
+    for ext in (0, 0.05):
+        ds = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), bbox_extend=ext)
+        e = ds.get_template_by_name(names[1])
+        t = e["templates"].cpu().numpy()
+        key = f"e{ext}"
+        assert t.shape == (600, 3, 420, 420) and str(e["templates"].dtype) == str(g["templates_dtype"])
+        assert np.array_equal(t[:3], g[f"{key}_templates_first3"])
+        assert np.array_equal(t[::40, :, ::7, ::7], g[f"{key}_templates_sample"])
+        bad = [i for i in range(600) if sha(t[i]) != str(g[f"{key}_templates_sha"][i])]
+        assert not bad, f"crops differ from the reference at views {bad[:10]} (bbox_extend={ext})"
+        if ext == 0:
+            m = e["masks"].cpu().numpy()
+            d = e["depths"].cpu().numpy()
+            assert m.dtype == np.bool_ and str(e["depths"].dtype) == str(g["depths_dtype"])
+            assert [sha(x) for x in m] == [str(x) for x in g["masks_sha"]]
+            assert [sha(x) for x in d] == [str(x) for x in g["depths_sha"]]
+            assert np.array_equal(m.reshape(600, -1).sum(1), g["mask_counts"])
+            assert np.array_equal(e["bboxes"].cpu().numpy(), g["bboxes"])
+            assert np.array_equal(e["intrinsic"].numpy(), g["intrinsic"]) and e["intrinsic"].dtype == torch.int64
+            assert e["model_name"] == str(g["model_name"]) and e["tar_file"] == str(g["tar_file"])
+    nc = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), crop=False).get_template_by_name(names[0])
+    assert [sha(x) for x in nc["templates"].cpu().numpy()[:20]] == [str(x) for x in g["nocrop_templates_sha"]]

@@ -62,3 +62,31 @@ def test_pos_embed_interpolation_shapes_and_identity():
     assert out.shape == (1, 901, 64) and torch.equal(out[:, 0], pe[:, 0])
     out16 = vit_ref.interpolate_pos_encoding(pe, 16, 16)                 # 224 px
     assert out16.shape == (1, 257, 64)
+
+
+def _truncate(sd, depth):
+    """first `depth` blocks of a hub-layout state dict (a shallower model with the same widths)"""
+    return {k: v for k, v in sd.items() if not k.startswith("blocks.") or int(k.split(".")[1]) < depth}
+
+
+@pytest.mark.parametrize("model,dim,heads,res", [("dinov2_vitl14_reg", 1024, 16, 518), ("dinov2_vitl14_reg", 1024, 16, 420),
+                                                 ("dinov2_vitb14_reg", 768, 12, 518), ("dinov2_vitb14_reg", 768, 12, 420)])
+def test_vit_ref_matches_transformers_at_vitl_and_vitb_widths(model, dim, heads, res):
+    """the restatement at the widths the pipeline uses (ViT-L/14-reg: retrieval + pose, ViT-B/14-reg: TrackingRefiner), two
+    blocks deep, at both resolutions (518: native 37 x 37 pos-embed grid, 420: bicubic-antialias resize to 30 x 30), with
+    non-trivial LayerScale so that ls1 / ls2 are not interchangeable"""
+    sd = _truncate(_sd(model, 5), 2)
+    g = torch.Generator().manual_seed(11)
+    for i in range(2):
+        sd[f"blocks.{i}.ls1.gamma"] = 0.5 + torch.rand(dim, generator=g)
+        sd[f"blocks.{i}.ls2.gamma"] = 0.5 + torch.rand(dim, generator=g)
+    m = _hf(sd, dim, 2, heads, 4)
+    x = torch.rand(1, 3, res, res, generator=torch.Generator().manual_seed(7))
+    ref = _hf_forward(m, x, 22)                       # layer > depth: all (two) blocks, then the final norm
+    mine = vit_ref.vit_forward(sd, x, layer=22, feature_type="patch")
+    P = (res // 14) ** 2
+    assert mine.shape == (1, P, dim) and ref.shape == (1, P + 5, dim)
+    rel = (mine - ref[:, 5:]).abs().max().item() / ref[:, 5:].abs().max().item()
+    assert rel <= 1e-4, rel                           # fp32 summation-order noise only (measured ~1e-6)
+    cls = vit_ref.vit_forward(sd, x, layer=1, feature_type="cls")
+    assert (cls - _hf_forward(m, x, 1)[:, 0]).abs().max().item() <= 1e-4 * ref.abs().max().item()

@@ -246,7 +246,9 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
     FP_REQUIRE(feature_type >= 0 && feature_type <= 2, "vit_forward: feature_type %d", feature_type);
     FP_REQUIRE(v->cls && v->pos && v->pe_b && v->normw && v->normb && (a.n_reg == 0 || v->reg),
                "vit_forward: embedding / final-norm weights not set");
-    const int L = std::min(std::max(layer, 0), a.depth);  // layer > depth: loop never breaks (dino.py:18-21)
+    // dino.py:18-21 breaks when blk_idx + 1 == layer: a layer outside [1, depth] (too large, zero or negative) never matches,
+    // so all blocks run
+    const int L = (layer >= 1 && layer <= a.depth) ? layer : a.depth;
     for (int i = 0; i < L; ++i) {
         const VitBlockW& w = v->blk[i];
         FP_REQUIRE(w.n1w && w.n1b && w.qkvw && w.qkvb && w.projw && w.projb && w.n2w && w.n2b && w.fc1w && w.fc1b &&

@@ -107,6 +107,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
             glds16(gW + offW[it] + kb, sb + BM * ROWB + (it * NW + wave) * 1024);
     };
 
+    auto stage_x = [&](int buf, int kt) {
+        char* sb = smem + buf * STAGE;
+        const size_t kb = (size_t)kt * ROWB;
+#pragma unroll
+        for (int it = 0; it < IX; ++it) glds16(gX + offX[it] + kb, sb + (it * NW + wave) * 1024);
+    };
+    auto stage_w = [&](int buf, int kt) {
+        char* sb = smem + buf * STAGE;
+        const size_t kb = (size_t)kt * ROWB;
+#pragma unroll
+        for (int it = 0; it < IW; ++it) glds16(gW + offW[it] + kb, sb + BM * ROWB + (it * NW + wave) * 1024);
+    };
+
     // ---- per-lane fragment read offsets (bytes inside a stage, before the k-step XOR) -----------
     const int li = lane & 15, lg = lane >> 4;
     // R operand rows: permuted  rl = (li>>2)*4*TR + 4*f + (li&3)
@@ -166,17 +179,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
             for (int kt = 0; kt < nkt; ++kt, ++g) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (kt + 1 < nkt) stage((g + 1) & 1, kt + 1);
-                else if (has_next) {
-                    set_tile(tile + tstride, m0n, n0n);
-                    stage((g + 1) & 1, 0);
-                }
+                const bool more = kt + 1 < nkt;
+                if (!more && has_next) set_tile(tile + tstride, m0n, n0n);
+                const bool do_stage = more || has_next;
+                const int nbuf = (g + 1) & 1, nk = more ? kt + 1 : 0;
                 const char* sb = smem + (g & 1) * STAGE;
+                if constexpr ((VAR & 128) == 0) {
+                    if (do_stage) stage(nbuf, nk);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
+                    for (int kk = 0; kk < 2; ++kk) {
+                        bf16x8_t fr[TR], fc[TC];
+                        load_frags(sb, kk, fr, fc);
+                        mma_block(fr, fc);
+                    }
+                } else {
+                    // split DMA issue: the X pieces go out behind the first fragment reads (their LDS latency covers the issue),
+                    // the W pieces behind the first MFMA block; MFMA blocks run at raised priority.  Measured in tools/gemm_lab.hip:
+                    // +4 % at K = 4096 / 8192, neutral at K = 1024.
                     bf16x8_t fr[TR], fc[TC];
-                    load_frags(sb, kk, fr, fc);
+                    load_frags(sb, 0, fr, fc);
+                    if (do_stage) stage_x(nbuf, nk);
+                    __builtin_amdgcn_s_setprio(1);
                     mma_block(fr, fc);
+                    __builtin_amdgcn_s_setprio(0);
+                    if (do_stage) stage_w(nbuf, nk);
+                    load_frags(sb, 1, fr, fc);
+                    __builtin_amdgcn_s_setprio(1);
+                    mma_block(fr, fc);
+                    __builtin_amdgcn_s_setprio(0);
                 }
             }
             fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage);
@@ -288,7 +318,8 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
             switch (var & (32 | 64)) {   // 32: persistent tile walk, 64: streaming (non-temporal) output stores
                 case 32: return launch_cfg<256, 256, 4, 4, EPI, 4 | 32>(a, stream);
                 case 64: return launch_cfg<256, 256, 4, 4, EPI, 4 | 64>(a, stream);
-                case 96: return launch_cfg<256, 256, 4, 4, EPI, 4 | 96>(a, stream);
+                case 96: return (var & 128) ? launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128>(a, stream)
+                                            : launch_cfg<256, 256, 4, 4, EPI, 4 | 96>(a, stream);
                 default: return launch_cfg<256, 256, 4, 4, EPI, 4>(a, stream);
             }
         }

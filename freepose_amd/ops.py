@@ -42,10 +42,10 @@ def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------
 VIT_ARCHS = {
-    # name: (dim, depth, heads, n_reg)
-    "dinov2_vits14": (384, 12, 6, 0), "dinov2_vits14_reg": (384, 12, 6, 4),
-    "dinov2_vitb14": (768, 12, 12, 0), "dinov2_vitb14_reg": (768, 12, 12, 4),
-    "dinov2_vitl14": (1024, 24, 16, 0), "dinov2_vitl14_reg": (1024, 24, 16, 4),
+    # name: (dim, depth, heads, n_reg).  Only the *_reg hub models: they interpolate the position embedding with
+    # antialias=True, offset 0 (what fp_vit_forward implements); the non-reg hub entries use antialias=False and
+    # interpolate_offset=0.1 and are not used by the reference (dino.py:8, tracking_refiner.py:23).
+    "dinov2_vits14_reg": (384, 12, 6, 4), "dinov2_vitb14_reg": (768, 12, 12, 4), "dinov2_vitl14_reg": (1024, 24, 16, 4),
 }
 FEATURE_TYPES = {"cls": 0, "reg": 1, "patch": 2}
 

@@ -27,8 +27,8 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # RCCL ("nccl") on GPUs; FP_DIST_BACKEND=gloo lets several ranks share one GPU (single-GPU test boxes)
+            backend = os.environ.get("FP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -53,6 +53,12 @@ def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
 def shard_items(n: int, rank: int, world_size: int) -> List[int]:
     """round-robin item ids (proposals, frames, objects): balances cost that grows with the index"""
     return list(range(rank, n, world_size))
+
+
+def shard_chunk(n: int, rank: int, world_size: int) -> List[int]:
+    """contiguous chunk of item ids (frames of one video when each rank tracks its own stretch of the clip)"""
+    lo, hi = shard_range(n, rank, world_size)
+    return list(range(lo, hi))
 
 
 def all_gather_cat(t: torch.Tensor, dim: int = 0) -> torch.Tensor:

@@ -20,6 +20,7 @@ from freepose_amd import parallel
 from freepose_amd.src.dataloader.bop import BOPDataset
 from freepose_amd.src.dataloader.template import WebTemplateDataset
 from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
+from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
 from freepose_amd.src.pipeline.utils import Proposals, rle_to_mask
 
 CSV_COLUMNS = ["scene_id", "im_id", "obj_id", "score", "R", "t", "bbox_visib", "scale", "time"]
@@ -68,6 +69,8 @@ def run(argv=None):
     ap.add_argument("--batch_size", type=int, default=128)
     ap.add_argument("--cache_size", type=int, default=50)
     ap.add_argument("--save_all_cache", action="store_true")
+    ap.add_argument("--n_views", type=int, default=600)                      # not in the reference: views per mesh (600 there)
+    ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")        # not in the reference: backbone
     args = ap.parse_args(argv)
 
     rank, world, _ = parallel.init_from_env()
@@ -79,9 +82,11 @@ def run(argv=None):
     out_csv = out_dir / (f"pose_outputs_{task}.csv" if world == 1 else f"pose_outputs_{task}_r{rank}.csv")
 
     dataset = BOPDataset(f"data/datasets/{args.dataset}/", args.split)
-    templates = WebTemplateDataset("data/datasets/objaverse_shards", "data/mesh_cache.csv", bbox_extend=args.bbox_extend)
-    model = DinoPoseEstimator(n_poses=600, cache_size=args.cache_size, save_all=args.save_all_cache,
-                              cache_dir=f"./data/cache_{task}_{args.dataset}_r{rank}")
+    templates = WebTemplateDataset("data/datasets/objaverse_shards", "data/mesh_cache.csv", bbox_extend=args.bbox_extend,
+                                   n_views=args.n_views)
+    extractor = None if args.model == "dinov2_vitl14_reg" else DINOv2FeatureExtractor(args.model)
+    model = DinoPoseEstimator(n_poses=args.n_views, cache_size=args.cache_size, save_all=args.save_all_cache,
+                              cache_dir=f"./data/cache_{task}_{args.dataset}_r{rank}", feature_extractor=extractor)
     props = json.loads((res_dir / args.proposals).read_text())
 
     per_task = 30
@@ -103,6 +108,7 @@ def run(argv=None):
         rows += proposal_rows(model, templates, entry["image"], entry["intrinsic"], sid, fid, sp, scales, args.layer,
                               args.batch_size, args.bbox_extend)
     pd.DataFrame(rows, columns=CSV_COLUMNS).to_csv(out_csv, index=False, header=True)
+    return out_csv
 
 
 if __name__ == "__main__":

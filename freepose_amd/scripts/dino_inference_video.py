@@ -4,9 +4,13 @@ Drop-in for the reference CLI (scripts/dino_inference_video.py:43-182, flags :23
 render-and-compare with `prev_pose` chaining; pose CSV out (t in metres, scene_id 0, time -1).
 
 Multi-GPU (new): frames of one object are sequentially dependent through prev_pose (reference :122,155-156), so a
-torch.distributed.run launch shards OBJECTS across ranks — exact w.r.t. the reference — and all-gathers the 13-float pose rows.
+torch.distributed.run launch shards OBJECTS across ranks — exact w.r.t. the reference — and all-gathers the 19-float pose rows.
 `--no_rescore` (coarse pose per frame, frames independent) shards FRAMES instead; the reference's own --no_rescore reads
 a key the coarse estimator never returns, here it simply emits the coarse top-1 pose.
+`--frame_chunks` (new, DEVIATES from the reference): each rank tracks a contiguous stretch of the clip and re-initialises
+with a coarse estimate at the head of its stretch (SURVEY §8e option 4) — this is what lets a single-object clip use all
+8 GPUs; poses on chunk-initial frames (and possibly after) differ from a sequential run, so the CSV name gets `_chunked<N>`.
+`--n_views`, `--model`, `--n_fine_poses` (new, default to the reference's constants 600 / dinov2_vitl14_reg / 20000).
 """
 from __future__ import annotations
 
@@ -27,6 +31,7 @@ from freepose_amd.mesh_io import load_obj
 from freepose_amd.src.dataloader.template import WebTemplateDataset
 from freepose_amd.src.pipeline.estimators.online_pose_estimator import DinoOnlinePoseEstimator
 from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
+from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
 from freepose_amd.src.pipeline.utils import Proposals, rle_to_mask
 from freepose_amd.scripts.dino_inference import CSV_COLUMNS, pose_row
 
@@ -38,7 +43,8 @@ def guessed_intrinsics(h: int, w: int) -> np.ndarray:
 
 def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, obj_ids, args, rescoring=True,
                   frame_ids=None):
-    """pose rows [(frame, obj, score, TCO, bbox)] for the given objects over the given frames (all by default)."""
+    """pose rows [(frame, obj, score, TCO, bbox)] for the given objects over the given frames (all by default).  With
+    rescoring the first frame visited starts from a coarse estimate (prev_pose None), every later one from its predecessor."""
     prev = {o: None for o in obj_ids}
     rows = []
     for f in (range(len(frames)) if frame_ids is None else frame_ids):
@@ -66,17 +72,22 @@ def main(args):
     video_dir = (Path("data") / "datasets" / "videos" / args.video).resolve()
     frames = sorted(p for p in video_dir.iterdir() if p.suffix.lower() in (".jpg", ".jpeg"))
     results_dir = (Path("data") / "results" / "videos" / args.video).resolve()
+    chunked = bool(args.frame_chunks) and world > 1 and not args.no_rescore
     out_csv = results_dir / args.proposals.replace(
-        ".json", f"_dinopose_layer_{args.layer}_bbext_{args.bbox_extend}_depth_{args.depth_method}.csv")
+        ".json", f"_dinopose_layer_{args.layer}_bbext_{args.bbox_extend}_depth_{args.depth_method}"
+                 + (f"_chunked{world}" if chunked else "") + ".csv")
 
-    templates = WebTemplateDataset("data/datasets/objaverse_shards", "data/mesh_cache.csv", bbox_extend=args.bbox_extend)
+    templates = WebTemplateDataset("data/datasets/objaverse_shards", "data/mesh_cache.csv", bbox_extend=args.bbox_extend,
+                                   n_views=args.n_views)
     templates.get_template_by_name = functools.lru_cache(maxsize=args.template_cache_size)(templates.get_template_by_name)
     cache_dir = Path("data") / f"cache_{os.environ.get('SLURM_JOB_ID', 0)}_{args.video}_r{rank}"
+    extractor = None if args.model == "dinov2_vitl14_reg" else DINOv2FeatureExtractor(args.model)
     if args.no_rescore:
-        model = DinoPoseEstimator(n_poses=600, cache_size=args.cache_size, save_all=args.save_all_cache, cache_dir=cache_dir)
+        model = DinoPoseEstimator(n_poses=args.n_views, cache_size=args.cache_size, save_all=args.save_all_cache,
+                                  cache_dir=cache_dir, feature_extractor=extractor)
     else:
-        model = DinoOnlinePoseEstimator(n_coarse_poses=600, n_fine_poses=20000, cache_size=args.cache_size,
-                                        save_all=args.save_all_cache, cache_dir=cache_dir)
+        model = DinoOnlinePoseEstimator(n_coarse_poses=args.n_views, n_fine_poses=args.n_fine_poses, cache_size=args.cache_size,
+                                        save_all=args.save_all_cache, cache_dir=cache_dir, feature_extractor=extractor)
 
     props = json.loads((results_dir / args.proposals).read_text())
     n_objects = len(list(takewhile(lambda x: x["image_id"] == 0, props)))
@@ -103,6 +114,12 @@ def main(args):
     if args.no_rescore:   # frames independent -> shard frames
         rows = track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, list(range(n_objects)), args,
                              rescoring=False, frame_ids=parallel.shard_items(n_frames, rank, world))
+    elif chunked:         # DEVIATES: every rank tracks its own stretch of the clip, coarse re-init at the stretch head
+        if rank == 0:
+            print(f"[dino_inference_video] --frame_chunks: {world} chunks with a coarse re-initialisation each; poses deviate "
+                  "from a sequential run on chunk-initial frames (SURVEY 8e option 4)", flush=True)
+        rows = track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, list(range(n_objects)), args,
+                             frame_ids=parallel.shard_chunk(n_frames, rank, world))
     else:                 # prev_pose chains frames -> shard objects
         rows = track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K,
                              parallel.shard_items(n_objects, rank, world), args)
@@ -134,8 +151,18 @@ def build_parser():
     ap.add_argument("--no_rescore", action="store_true")
     ap.add_argument("--cache_size", type=int, default=50)
     ap.add_argument("--save_all_cache", action="store_true")
+    # not in the reference (defaults reproduce it): template views per mesh = coarse hypotheses, backbone, fine grid size,
+    # and the deviating frame-chunk mode
+    ap.add_argument("--n_views", type=int, default=600)
+    ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")
+    ap.add_argument("--n_fine_poses", type=int, default=20000)
+    ap.add_argument("--frame_chunks", action="store_true")
     return ap
 
 
+def run(argv=None):
+    return main(build_parser().parse_args(argv))
+
+
 if __name__ == "__main__":
-    main(build_parser().parse_args())
+    run()

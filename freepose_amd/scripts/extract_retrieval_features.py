@@ -41,6 +41,8 @@ def main(argv=None):
     ap.add_argument("--layer", type=int, default=22)
     ap.add_argument("--mesh_per_job", type=int, default=100)
     ap.add_argument("--batch_size", type=int, default=128)
+    ap.add_argument("--n_views", type=int, default=600)                      # not in the reference: views per mesh (600 there)
+    ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")        # not in the reference: backbone
     args = ap.parse_args(argv)
 
     shards_path = Path("data/datasets").resolve() / args.shards_folder
@@ -49,8 +51,8 @@ def main(argv=None):
     filelist_path = Path("data").resolve() / args.filelist
 
     rank, world, _ = parallel.init_from_env()
-    model = DINOv2FeatureExtractor()
-    dataset = WebTemplateDataset(shards_path.as_posix(), filelist_path.as_posix(), crop=False)
+    model = DINOv2FeatureExtractor(args.model)
+    dataset = WebTemplateDataset(shards_path.as_posix(), filelist_path.as_posix(), crop=False, n_views=args.n_views)
 
     if "SLURM_ARRAY_TASK_ID" in os.environ:
         job = int(os.environ["SLURM_ARRAY_TASK_ID"])

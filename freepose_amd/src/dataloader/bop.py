@@ -17,7 +17,9 @@ class BOPDataset:
             split = f"{split}_primesense"
         self.path = Path(root_dir).resolve()
         self.split = split
-        meta = self.path / f"{split}_metadata.json"
+        # own cache file: the reference writes `<split>_metadata.json` with a different schema (base_bop.py:60-106) and would
+        # fail on ours with a KeyError (and vice versa)
+        meta = self.path / f"{split}_metadata_fp.json"
         self.meta_data = pd.read_json(meta) if meta.exists() else self._index(meta)
 
     def _index(self, meta_path: Path) -> pd.DataFrame:

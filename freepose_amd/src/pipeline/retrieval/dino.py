@@ -15,10 +15,9 @@ import torch
 
 from freepose_amd import ops
 
-_CKPT_NAMES = {
-    "dinov2_vits14": "dinov2_vits14_pretrain.pth", "dinov2_vits14_reg": "dinov2_vits14_reg4_pretrain.pth",
-    "dinov2_vitb14": "dinov2_vitb14_pretrain.pth", "dinov2_vitb14_reg": "dinov2_vitb14_reg4_pretrain.pth",
-    "dinov2_vitl14": "dinov2_vitl14_pretrain.pth", "dinov2_vitl14_reg": "dinov2_vitl14_reg4_pretrain.pth",
+_CKPT_NAMES = {   # the *_reg hub models only (ops.VIT_ARCHS: the non-reg entries interpolate the position embedding differently)
+    "dinov2_vits14_reg": "dinov2_vits14_reg4_pretrain.pth", "dinov2_vitb14_reg": "dinov2_vitb14_reg4_pretrain.pth",
+    "dinov2_vitl14_reg": "dinov2_vitl14_reg4_pretrain.pth",
 }
 
 

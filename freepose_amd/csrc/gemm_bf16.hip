@@ -21,7 +21,7 @@
 #include <stdlib.h>
 
 #ifndef FP_GEMM_DEFAULT_VARIANT
-#define FP_GEMM_DEFAULT_VARIANT 110
+#define FP_GEMM_DEFAULT_VARIANT 238   // 2|4|8|32|64|128 (profiles/r02_ab.md: +4..6 % over 110 on every ViT shape)
 #endif
 
 namespace {
@@ -298,7 +298,9 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
     // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads (8-wave kernels),
     // 4 = polynomial erf in the GELU epilogue, 8 = 16-wave big tile, 32 = persistent tile walk,
-    // 64 = streaming epilogue I/O: non-temporal output stores and residual loads (the last two with the 16-wave big tile).  FP_GEMM_VARIANT / fp_set_option override
+    // 64 = streaming epilogue I/O: non-temporal output stores and residual loads (the last two with the 16-wave big tile),
+    // 128 = split DMA issue (X pieces behind the first fragment reads, W pieces behind the first MFMA block) + MFMA priority
+    // (persistent 16-wave kernel).  FP_GEMM_VARIANT / fp_set_option override
     // the default (A/B probing only).
     static int env_var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
     const int var = fp_opt_get(FP_OPT_GEMM_VARIANT, env_var);

@@ -29,7 +29,8 @@ const char* fp_last_error(void);
 int fp_version(void);
 /* experiment toggles for A/B measurements; value < 0 restores the default.
  *   "gemm_variant": bit 2 pipelined fragment reads (8-wave kernels), 4 polynomial erf, 8 16-wave 256x256 tile,
- *                   32 persistent tile walk, 64 streaming epilogue I/O (default 110 = 2|4|8|32|64)
+ *                   32 persistent tile walk, 64 streaming epilogue I/O, 128 split DMA issue + MFMA priority
+ *                   (default 238 = 2|4|8|32|64|128)
  *   "attn_slots":   LDS ring depth of the attention kernel, 2 (default), 3 or 4
  *   "raster_tiled": unset = LDS-tiled rasteriser for meshes up to 32 768 triangles and images up to 704 px, global
  *                   visibility-buffer path otherwise; 1 / 0 force one of them (both bit-identical) */

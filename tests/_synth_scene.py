@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from PIL import Image
 
-MESH_IDS = ["ball_a", "cube_t"]
+MESH_IDS = ["balla", "cubet"]      # no underscores, like the shipped mesh list (the loader strips them from its index, template.py:41)
 
 
 def write_meshes(root: Path):
@@ -19,14 +19,14 @@ def write_meshes(root: Path):
     from tests._meshes import checker_gradient_texture, write_textured_obj
     mc = root / "data" / "mesh_cache"
     v, f, c = bench.synthetic_mesh(3, seed=41)
-    d = mc / "ball_a"
+    d = mc / "balla"
     d.mkdir(parents=True, exist_ok=True)
-    with open(d / "ball_a.obj", "w") as fh:
+    with open(d / "balla.obj", "w") as fh:
         for p, col in zip(v, c):
             fh.write(f"v {p[0]:.7f} {p[1]:.7f} {p[2]:.7f} {col[0] / 255:.6f} {col[1] / 255:.6f} {col[2] / 255:.6f}\n")
         for t in f:
             fh.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
-    write_textured_obj(mc / "cube_t", "cube_t", checker_gradient_texture(128))
+    write_textured_obj(mc / "cubet", "cubet", checker_gradient_texture(128))
     (root / "data" / "mesh_cache.txt").write_text("\n".join(MESH_IDS) + "\n")
     (root / "data" / "mesh_cache.csv").write_text("model_name\n" + "\n".join(MESH_IDS) + "\n")
 

@@ -64,7 +64,10 @@ def test_video_driver_one_rank_two_ranks_and_modes(workspace, monkeypatch):
     for i, row in df.iterrows():
         R, t = _pose(row)
         fr, o = int(row["im_id"]), i % 2
-        assert np.isfinite(R).all() and abs(np.linalg.det(R) - 1) < 1e-6 and 0 < float(row["score"]) <= 1.0
+        # scores are mean patch cosines, except on frame 0 where the reference scores against the UN-normalised query features
+        # (online_pose_estimator.py:40-41,76) — reproduced, so only positivity is universal
+        assert np.isfinite(R).all() and abs(np.linalg.det(R) - 1) < 1e-6 and np.isfinite(float(row["score"])) and float(row["score"]) > 0
+        assert fr == 0 or float(row["score"]) <= 1.0
         errs.append((sc.rotation_error_deg(R, gts[fr, o][:3, :3]), float(np.linalg.norm(t - gts[fr, o][:3, 3]))))
         x, y, w, h = [int(v) for v in row["bbox_visib"].split()]
         assert w > 20 and h > 20 and 0 <= x < 640 and 0 <= y < 480
@@ -132,15 +135,13 @@ def test_image_driver_and_bank_build(workspace, monkeypatch):
     extract_retrieval_features.main(["--filelist", "mesh_cache.csv", "--feature", "ffa", "--layer", "22", "--batch_size", "32",
                                      "--n_views", str(N_VIEWS), "--model", MODEL])
     fdir = root / "data" / "datasets" / "objaverse_shards_ffa_22"
-    per_mesh = {m: np.load(fdir / f"{m.replace('_', '')}.npy") for m in sc.MESH_IDS}
+    per_mesh = {m: np.load(fdir / f"{m}.npy") for m in sc.MESH_IDS}
     for m, d in per_mesh.items():
         assert d.dtype == np.float32 and d.shape == (N_VIEWS, 384) and np.isfinite(d).all()
-    # the reference's merge step looks files up by the ids of mesh_cache.txt; its loader strips underscores from names
-    (root / "data" / "mesh_cache_stripped.txt").write_text("\n".join(m.replace("_", "") for m in sc.MESH_IDS) + "\n")
-    merge_features.main(["--features_folder", "objaverse_shards_ffa_22", "--filelist", "mesh_cache_stripped.txt"])
+    merge_features.main(["--features_folder", "objaverse_shards_ffa_22", "--filelist", "mesh_cache.txt"])
     bank = np.load(root / "data" / "objaverse_shards_ffa_22.npy")
     assert bank.shape == (2, 384) and bank.dtype == np.float32
-    assert np.allclose(bank[0], per_mesh["ball_a"].mean(axis=0)) and np.allclose(bank[1], per_mesh["cube_t"].mean(axis=0))
+    assert np.allclose(bank[0], per_mesh["balla"].mean(axis=0)) and np.allclose(bank[1], per_mesh["cubet"].mean(axis=0))
     from freepose_amd.retrieval import TemplateBank
     tb = TemplateBank.from_files(root / "data" / "objaverse_shards_ffa_22.npy", root / "data" / "objaverse_shards_ffa_22.ids.txt")
     assert tb.N == 2 and tb.mesh_ids == ["balla", "cubet"]

@@ -193,7 +193,7 @@ def test_template_dataset_and_bank_build(tmp_path):
     sc, ix = bank.topk(ops.l2_normalize(q.to(torch.bfloat16)), 2)
     sc, ix = sc.cpu().numpy(), ix.cpu().numpy()
     for r in range(2):
-        assert sorted(ix[r].tolist()) == [0, 1] and sc[r][ix[r] == r][0] == sc[r].max() and sc[r].max() > 0.99
+        assert sorted(ix[r].tolist()) == [0, 1] and sc[r][ix[r] == r][0] >= sc[r].max() - 2 ** -7 and sc[r].max() > 0.99
     got, score, idx = bank.retrieve(ops.l2_normalize(q.to(torch.bfloat16)))
     assert got[0] == "meshA" and got[1] in names
     # crop=True path (what the inference drivers use)

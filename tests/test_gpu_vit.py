@@ -27,7 +27,7 @@ def _metrics(got, ref):
 
 
 @pytest.mark.parametrize("model,H,layer,B", [("dinov2_vits14_reg", 224, 22, 2), ("dinov2_vitl14_reg", 420, 22, 2),
-                                             ("dinov2_vitl14_reg", 518, 2, 1), ("dinov2_vits14", 224, 5, 3),
+                                             ("dinov2_vitl14_reg", 518, 2, 1), ("dinov2_vits14_reg", 224, 5, 3),
                                              ("dinov2_vitl14_reg", 518, 22, 1),      # the bench / north-star configuration
                                              ("dinov2_vitb14_reg", 518, 12, 1)])     # TrackingRefiner
 def test_vit_forward_vs_fp32_oracle(model, H, layer, B):

@@ -61,6 +61,14 @@ SIGNATURES = {
                              c_int, c_void_p, c_void_p, c_void_p]),
     "fp_depth_extents": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_void_p,
                                  c_void_p]),
+    "fp_comm_unique_id": (c_int, [c_void_p]),
+    "fp_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "fp_comm_destroy": (c_int, [c_void_p]),
+    "fp_comm_size": (c_int, [c_void_p]),
+    "fp_comm_rank": (c_int, [c_void_p]),
+    "fp_allgather_bytes": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fp_allgather_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fp_allgather_poses": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fp_op_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                            c_int, c_int, c_int, c_void_p]),
     "fp_op_gemm_vt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -72,8 +72,10 @@ extern "C" int fp_ctx_create(int device, fp_ctx** out) {
     *out = c;
     return FP_OK;
 }
+extern "C" int fp_comm_destroy(fp_ctx* ctx);
 extern "C" int fp_ctx_destroy(fp_ctx* ctx) {
     if (!ctx) return FP_OK;
+    (void)fp_comm_destroy(ctx);
     ctx->release();
     delete ctx;
     return FP_OK;

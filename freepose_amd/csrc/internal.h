@@ -14,6 +14,9 @@ struct fp_ctx {
     struct Buf { void* p = nullptr; size_t bytes = 0; };
     std::map<std::string, Buf> bufs;
     int get(const char* name, size_t bytes, void** out);
+    // optional RCCL communicator (comm.hip: fp_comm_init); null = single rank
+    void* comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
     size_t total() const;
     void release();
 };

@@ -10,6 +10,8 @@
 // this is the documented canonical rule).
 #include "internal.h"
 
+#include <stdlib.h>
+
 namespace {
 
 __device__ __forceinline__ uint32_t score_key16(float s_bf16_rounded) {
@@ -200,6 +202,245 @@ __global__ __launch_bounds__(SEL_T) void topk_select_kernel(const uint16_t* __re
         else if (key == T) { if (oe < need_eq) cand[ngt + oe] = ((unsigned long long)key << 32) | (unsigned)(0x7fffffff - i); ++oe; }
     }
     // pad to a power of two and bitonic-sort descending on (key, -index)
+    int n2 = 1;
+    while (n2 < k) n2 <<= 1;
+    for (int i = k + tid; i < n2; i += SEL_T) cand[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < n2; i += SEL_T) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = ((i & size) == 0);
+                    const unsigned long long a = cand[i], b = cand[j];
+                    if ((a < b) == desc) { cand[i] = b; cand[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k; i += SEL_T) {
+        const unsigned long long c = cand[i];
+        out_scores[(size_t)q * k + i] = key16_to_float((uint32_t)(c >> 32));
+        out_idx[(size_t)q * k + i] = idx_offset + (0x7fffffff - (int)(unsigned)(c & 0xffffffffu));
+    }
+}
+
+// ---- register-resident select (N <= 48 * SEL_T keys per query) ---------------------------------------------------------------
+// The two-level histogram above serialises on LDS atomics when the keys are skewed — and bf16 cosine scores are: with an
+// anisotropic bank nearly every key shares one high byte, so each ds_add hits one address 64 ways (43 us for 46 037 keys).
+// Here no atomics are used at all: a thread keeps its 2*MAXW consecutive keys packed in MAXW registers and the exact k-th
+// largest key T is found by COUNTING,
+//   1. per-thread maximum; L = the k-th largest of the SEL_T maxima (bit-wise binary search over 1024 values: one compare per
+//      thread and iteration).  At least k keys are >= L, so T >= L; G = the block maximum bounds T from above;
+//   2. binary search for T in [L, G] with exact block-wide counts of keys >= mid (packed 16-bit saturating subtract / min /
+//      add: 3 VALU per two keys); [L, G] spans a handful of bf16 values, so this takes ~4-6 iterations;
+//   3. ordered compaction (all keys > T, then the first k - #greater keys == T in index order) and the bitonic sort of the k
+//      survivors, as before.  Same total order (key desc, index asc) -> bit-identical results.
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+    v += __float_as_int(lane_xor<32>(__int_as_float(v)));
+    v += __float_as_int(lane_xor<16>(__int_as_float(v)));
+    v += __float_as_int(lane_xor<8>(__int_as_float(v)));
+    v += __float_as_int(lane_xor<4>(__int_as_float(v)));
+    v += __float_as_int(lane_xor<2>(__int_as_float(v)));
+    v += __float_as_int(lane_xor<1>(__int_as_float(v)));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    v = max(v, __float_as_int(lane_xor<32>(__int_as_float(v))));
+    v = max(v, __float_as_int(lane_xor<16>(__int_as_float(v))));
+    v = max(v, __float_as_int(lane_xor<8>(__int_as_float(v))));
+    v = max(v, __float_as_int(lane_xor<4>(__int_as_float(v))));
+    v = max(v, __float_as_int(lane_xor<2>(__int_as_float(v))));
+    v = max(v, __float_as_int(lane_xor<1>(__int_as_float(v))));
+    return v;
+}
+// packed 16-bit helpers (one VALU instruction each; hipcc scalarises the generic vector forms of sub_sat / min)
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+constexpr int SEL_W = 24;                 // packed words per thread: thread t owns keys [48 t, 48 t + 48)
+constexpr int SEL_CAP = SEL_T * 2 * SEL_W;   // 49 152 keys
+
+__global__ __launch_bounds__(SEL_T) void topk_select_reg_kernel(const uint16_t* __restrict__ keys, int ldk, int N, int k,
+                                                                int idx_offset, float* __restrict__ out_scores,
+                                                                int* __restrict__ out_idx) {
+    extern __shared__ uint16_t lkeys[];   // [SEL_CAP] staged key row, zero beyond N
+    __shared__ int slots[8][SEL_T / 64];  // per-iteration wave partials (one barrier per block-wide count)
+    __shared__ unsigned short smax[SEL_T];
+    __shared__ int sh[SEL_T / 64 + 2];
+    __shared__ unsigned long long cand[KMAX];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint16_t* kq = keys + (size_t)q * ldk;
+    {
+        // all six 16-byte loads of a thread are issued before the first is stored: a load -> store loop pays the full memory
+        // latency per iteration (the key row was just written by the scan kernel: it comes from HBM / MALL, not from this XCD's L2)
+        const uint4* src = (const uint4*)kq;
+        uint4* dst = (uint4*)lkeys;
+        const int n16 = N >> 3;                      // whole 16-byte groups inside the row
+        constexpr int NLD = SEL_CAP / 8 / SEL_T;     // 6
+        uint4 v[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * SEL_T;
+            v[j] = i < n16 ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) dst[tid + j * SEL_T] = v[j];
+        __syncthreads();
+        if (tid < 8) { const int i = (n16 << 3) + tid; if (i < N) lkeys[i] = kq[i]; }   // the ragged tail of the row
+    }
+    __syncthreads();
+    uint32_t w[SEL_W];
+    {
+        const uint4* lw = (const uint4*)lkeys + (size_t)tid * (SEL_W / 4);
+#pragma unroll
+        for (int j = 0; j < SEL_W / 4; ++j) {
+            const uint4 v = lw[j];
+            w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+        }
+    }
+    const int lo = tid * 2 * SEL_W, hi = min(lo + 2 * SEL_W, N);
+
+    // ---- 1. maxima: every wave finds L (k-th largest thread maximum) and G (largest) redundantly from the LDS copy ----------
+    uint32_t m2 = 0u;
+#pragma unroll
+    for (int j = 0; j < SEL_W; ++j) m2 = pk_max_u16(m2, w[j]);
+    smax[tid] = (unsigned short)max(m2 & 0xffffu, m2 >> 16);
+    __syncthreads();
+    uint32_t mw[SEL_T / 128];                          // this lane's 16 maxima, packed
+    {
+        const uint4* sm = (const uint4*)smax + lane * 2;
+        const uint4 a = sm[0], b = sm[1];
+        mw[0] = a.x; mw[1] = a.y; mw[2] = a.z; mw[3] = a.w; mw[4] = b.x; mw[5] = b.y; mw[6] = b.z; mw[7] = b.w;
+    }
+    const uint32_t ones = 0x00010001u;
+    auto pk_count_ge = [&](const uint32_t* v, int n, int c) -> int {   // halves of v[0..n) that are >= c (c >= 1)
+        const uint32_t cc = (uint32_t)(c - 1) * 0x00010001u;
+        uint32_t acc = 0u;
+#pragma unroll
+        for (int j = 0; j < n; ++j) acc = pk_add_u16(acc, pk_min_u16(pk_sub_sat_u16(v[j], cc), ones));
+        return (int)(acc & 0xffffu) + (int)(acc >> 16);
+    };
+    uint32_t g2 = 0u;
+#pragma unroll
+    for (int j = 0; j < SEL_T / 128; ++j) g2 = pk_max_u16(g2, mw[j]);
+    const int G = wave_max_i((int)max(g2 & 0xffffu, g2 >> 16));
+    int L = 0;
+    for (int bit = 15; bit >= 0; --bit) {
+        const int c = L | (1 << bit);
+        if (c > G) continue;
+        if (wave_sum_i(pk_count_ge(mw, SEL_T / 128, c)) >= k) L = c;
+    }
+    // ---- 1b. fast path: every key >= L is a candidate (at least k of them; typically k .. 2k).  If they fit the candidate buffer
+    // the answer is a rank sort of their (key, index) composites — distinct 64-bit values whose descending order IS the canonical
+    // (key desc, index asc) order — and no threshold search is needed.  Tie-heavy rows (more than KMAX keys >= L) take the
+    // counting search below.
+    {
+        unsigned long long gem = 0ull;               // bit b: this thread's key lo + b is >= max(L, 1) (pads are 0)
+        const uint32_t cc = (uint32_t)(max(L, 1) - 1) * 0x00010001u;
+#pragma unroll
+        for (int j = 0; j < SEL_W; ++j) {
+            const uint32_t d = pk_min_u16(pk_sub_sat_u16(w[j], cc), ones);
+            gem |= (unsigned long long)((d & 1u) | ((d >> 15) & 2u)) << (2 * j);
+        }
+        int M;
+        int off = block_excl_scan(__popcll(gem), sh, M);
+        if (M <= KMAX) {
+            while (gem) {
+                const int b = __ffsll((long long)gem) - 1;
+                gem &= gem - 1;
+                const int i = lo + b;
+                cand[off++] = ((unsigned long long)lkeys[i] << 32) | (unsigned)(0x7fffffff - i);
+            }
+            __syncthreads();
+            if (tid < M) {
+                const unsigned long long mine = cand[tid];
+                int rank = 0;
+                for (int j = 0; j < M; ++j) rank += cand[j] > mine;
+                if (rank < k) {
+                    out_scores[(size_t)q * k + rank] = key16_to_float((uint32_t)(mine >> 32));
+                    out_idx[(size_t)q * k + rank] = idx_offset + (0x7fffffff - (int)(unsigned)(mine & 0xffffffffu));
+                }
+            }
+            return;
+        }
+    }
+    // ---- 2. exact k-th largest key T in [L, G]: block-wide counts, one barrier each ----------------------------------------
+    int it = 0;
+    auto block_count_ge = [&](int c) -> int {
+        const int part = wave_sum_i(pk_count_ge(w, SEL_W, c));
+        int* sl = slots[it & 7];
+        ++it;
+        if (lane == 0) sl[wv] = part;
+        __syncthreads();
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < SEL_T / 64; ++i) t += sl[i];
+        return t;
+    };
+    int tlo = L, thi = G;                            // invariant: #keys >= tlo is >= k (L = 0 counts every real key: k <= N)
+    while (tlo < thi) {
+        const int mid = (tlo + thi + 1) >> 1;
+        if (block_count_ge(mid) >= k) tlo = mid; else thi = mid - 1;
+    }
+    const int T = tlo;
+    const int ngt = T >= 65535 ? 0 : block_count_ge(T + 1);
+    const int need_eq = k - ngt;
+    // ---- 3. ordered compaction (index order): first all > T, then the first need_eq == T -----------------------------------
+    int cg = 0, ce = 0;
+#pragma unroll
+    for (int j = 0; j < SEL_W; ++j) {
+        const int i0 = lo + 2 * j;
+        const int k0 = (int)(w[j] & 0xffffu), k1 = (int)(w[j] >> 16);
+        if (i0 < hi) { cg += k0 > T; ce += k0 == T; }
+        if (i0 + 1 < hi) { cg += k1 > T; ce += k1 == T; }
+    }
+    int tot;
+    const int both = block_excl_scan(cg | (ce << 16), sh, tot);   // both counts stay below 65 536: one scan carries the two
+    int og = both & 0xffff, oe = both >> 16;
+#pragma unroll
+    for (int j = 0; j < SEL_W; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = lo + 2 * j + h;
+            if (i >= hi) continue;
+            const int key = h ? (int)(w[j] >> 16) : (int)(w[j] & 0xffffu);
+            if (key > T) cand[og++] = ((unsigned long long)key << 32) | (unsigned)(0x7fffffff - i);
+            else if (key == T) { if (oe < need_eq) cand[ngt + oe] = ((unsigned long long)key << 32) | (unsigned)(0x7fffffff - i); ++oe; }
+        }
+    }
+    __syncthreads();
+    if (k <= 256) {
+        // rank sort: candidates are distinct 64-bit values; a candidate's rank is the number of larger ones (broadcast LDS reads)
+        if (tid < k) {
+            const unsigned long long mine = cand[tid];
+            int rank = 0;
+            for (int j = 0; j < k; ++j) rank += cand[j] > mine;
+            out_scores[(size_t)q * k + rank] = key16_to_float((uint32_t)(mine >> 32));
+            out_idx[(size_t)q * k + rank] = idx_offset + (0x7fffffff - (int)(unsigned)(mine & 0xffffffffu));
+        }
+        return;
+    }
     int n2 = 1;
     while (n2 < k) n2 <<= 1;
     for (int i = k + tid; i < n2; i += SEL_T) cand[i] = 0ull;
@@ -506,6 +747,18 @@ int fp_topk_select(const uint16_t* keys, int ldk, int N, int Q, int k, int idx_o
     FP_REQUIRE(k > 0 && k <= KMAX && k <= N, "topk: k=%d out of range (N=%d, max %d)", k, N, KMAX);
     FP_REQUIRE(ldk >= N && ldk % 8 == 0, "topk: key row stride %d must be >= N and a multiple of 8", ldk);
     const size_t key_bytes = (size_t)ldk * 2;
+    static int env_sel = [] { const char* e = getenv("FP_TOPK_SELECT"); return e ? atoi(e) : 1; }();   // 0: histogram kernels (A/B)
+    if (env_sel && N <= SEL_CAP) {   // counting select on register-resident keys (no LDS atomics)
+        const size_t lds = (size_t)SEL_CAP * 2;
+        static bool attr_set_r = false;
+        if (!attr_set_r) {
+            FP_HIP(hipFuncSetAttribute((const void*)topk_select_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set_r = true;
+        }
+        hipLaunchKernelGGL(topk_select_reg_kernel, dim3(Q), dim3(SEL_T), lds, s, keys, ldk, N, k, idx_offset, out_scores, out_idx);
+        FP_LAUNCH_CHECK();
+        return FP_OK;
+    }
     if (key_bytes <= 128 * 1024) {   // the key row fits beside the candidate buffer: all passes from LDS
         static bool attr_set = false;
         if (!attr_set) {

@@ -166,6 +166,25 @@ int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn,
 int fp_depth_extents(fp_ctx* ctx, const float* d_depth, int Hn, int Hh, int W, float fx, float fy, float cx,
                      float cy, double* d_out, void* stream);
 
+/* ---- e: multi-GPU.  One process per GPU; RCCL over xGMI.  The reference has no counterpart (SLURM array jobs +
+ * files: scripts/dino_inference.py:51-54, merge_results.py); Python hosts use torch.distributed (freepose_amd/parallel.py), these
+ * entry points serve hosts without it.  librccl is opened lazily on first use. ------------------------------------------- */
+/* rank 0 creates the 128-byte RCCL unique id (ncclGetUniqueId) and hands it to the other ranks through the host's own channel */
+int fp_comm_unique_id(void* out_id128);
+int fp_comm_init(fp_ctx* ctx, int nranks, int rank, const void* unique_id128);
+int fp_comm_destroy(fp_ctx* ctx);
+int fp_comm_size(const fp_ctx* ctx);
+int fp_comm_rank(const fp_ctx* ctx);
+/* all-gather `bytes` device bytes from every rank into d_recv [nranks * bytes] (rank order); a copy without a communicator */
+int fp_allgather_bytes(fp_ctx* ctx, const void* d_send, size_t bytes, void* d_recv, void* stream);
+/* bank-row sharding: every rank passes its local top-k [Q,k] with GLOBAL row indices; the candidates of all ranks
+ * are gathered and merged with the canonical (score desc, index asc) rule -> identical [Q,k_out] on every rank */
+int fp_allgather_topk(fp_ctx* ctx, const float* d_scores, const int32_t* d_idx, int Q, int k, int k_out, float* d_out_scores,
+                      int32_t* d_out_idx, void* stream);
+/* proposal / frame / object sharding: gather n_rows fixed-length f64 result rows per rank (every rank passes the same n_rows;
+ * pad with rows the caller can recognise) into d_out [nranks * n_rows, row_len] */
+int fp_allgather_poses(fp_ctx* ctx, const double* d_rows, int n_rows, int row_len, double* d_out, void* stream);
+
 /* ---- kernel-level entry points (unit parity tests, microbenchmarks; the ViT forward is built from these) */
 /* C[M,N] = epi(X[M,K] W[N,K]^T + bias): epi 0 = bias, 1 = bias+GELU(erf), 2 = resid + gamma*(.) ; bf16, ld* in
  * elements (multiples of 8), K % 64 == 0, N % 16 == 0. */

@@ -1,0 +1,61 @@
+"""Multi-GPU plumbing on real devices.  (1) the C-ABI communication entry points (fp_comm_*, RCCL opened lazily) with a
+single-rank communicator on the one GPU every box has; (2) when the box has >= 2 GPUs: the torch.distributed path over the
+`nccl` backend (= RCCL over xGMI) — sharded bank top-k, variable-row all-gather of float64 CUDA rows, the soft-vote reduction —
+and the C-ABI all-gathers across ranks.  (2) is skipped on single-GPU boxes; the same code runs there over gloo
+(tests/test_gpu_multirank.py, tests/test_distributed_cpu.py)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_c_abi_comm_single_rank():
+    from freepose_amd import _lib, ops
+    lib = _lib.load()
+    ctx = ops.context()
+    assert lib.fp_comm_size(ctx) == 1 and lib.fp_comm_rank(ctx) == 0
+    rng = np.random.default_rng(4)
+    s = torch.from_numpy(np.sort(rng.random((3, 16)).astype(np.float32), axis=1)[:, ::-1].copy()).cuda()
+    i = torch.from_numpy(rng.permutation(48).reshape(3, 16).astype(np.int32)).cuda()
+    os_, oi = torch.empty((3, 8), device="cuda"), torch.empty((3, 8), dtype=torch.int32, device="cuda")
+
+    def gather_topk():
+        _lib.check(lib.fp_allgather_topk(ctx, _lib.ptr(s), _lib.ptr(i), 3, 16, 8, _lib.ptr(os_), _lib.ptr(oi), _lib.current_stream()),
+                   "fp_allgather_topk")
+        torch.cuda.synchronize()
+        ms, mi = ops.topk_merge(s, i, 8)
+        assert torch.equal(os_, ms) and torch.equal(oi, mi)
+    gather_topk()                                   # no communicator: the gather is a copy
+    uid = (C.c_char * 128)()
+    _lib.check(lib.fp_comm_unique_id(uid), "fp_comm_unique_id")
+    _lib.check(lib.fp_comm_init(ctx, 1, 0, uid), "fp_comm_init")
+    try:
+        assert lib.fp_comm_size(ctx) == 1 and lib.fp_comm_rank(ctx) == 0
+        gather_topk()                               # through ncclAllGather on a 1-rank communicator
+        rows = torch.arange(38, dtype=torch.float64, device="cuda").reshape(2, 19)
+        out = torch.zeros_like(rows)
+        _lib.check(lib.fp_allgather_poses(ctx, _lib.ptr(rows), 2, 19, _lib.ptr(out), _lib.current_stream()), "fp_allgather_poses")
+        torch.cuda.synchronize()
+        assert torch.equal(out, rows)
+        assert lib.fp_comm_init(ctx, 1, 0, uid) != 0 and b"already" in lib.fp_last_error()
+    finally:
+        _lib.check(lib.fp_comm_destroy(ctx), "fp_comm_destroy")
+    assert lib.fp_comm_size(ctx) == 1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for the RCCL (nccl backend) path")
+def test_rccl_two_ranks_two_gpus(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FP_DIST_BACKEND="nccl", FP_COMM_DIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", str(ROOT / "tests" / "_multirank_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert "MULTIRANK_BANK_OK 2" in r.stdout and "MULTIRANK_CABI_OK 2" in r.stdout

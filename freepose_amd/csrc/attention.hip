@@ -21,6 +21,8 @@
 // xformers memory_efficient_attention in the reference environment (environment_cuda.yaml:33).
 #include "internal.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -62,7 +64,7 @@ __device__ __forceinline__ int key_perm4(int row) {  // rows laid out 16a + 4f +
     return (((rl >> 4) << 1) | ((rl & 3) >> 1)) & 7;
 }
 
-template <int NSLOT>  // LDS ring depth: NSLOT-1 K/V tiles in flight (16 KiB per slot)
+template <int NSLOT, int VAR = 0>  // LDS ring depth: NSLOT-1 K/V tiles in flight (16 KiB per slot); VAR bit 1: MFMA segments at raised priority
 __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {   // 3 waves/SIMD: <= 168 VGPRs
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) s[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int slot = (((kk << 2) | lg) ^ keyK) << 4;
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
                     s[fk][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[fq][kk], s[fk][fq], 0, 0, 0);
             }
         }
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
         if (kv0 + KVB > p.n_tok) {  // wave-uniform: only the last tile masks
 #pragma unroll
             for (int fk = 0; fk < 4; ++fk)
@@ -314,7 +318,9 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
         pv_half(1);
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- normalise and store: lane owns 16 consecutive d (= 16 lg + 4 fd + r) of query li ---------
@@ -353,7 +359,9 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     a.scale_log2e = 1.4426950408889634f / 8.0f;
     dim3 grid(cdiv(npad, QB) * H * B);
     const int nslot = fp_opt_get(FP_OPT_ATTN_SLOTS, 2);   // measured: 2 >= 3 > 4 (profiles/r01_ab.md)
-    if (nslot == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    static int env_var = [] { const char* e = getenv("FP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+    if (nslot == 2 && (env_var & 1)) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    else if (nslot == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     else if (nslot == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(NWAVE * 64), 4 * STAGE, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(NWAVE * 64), 3 * STAGE, stream, a);
     FP_LAUNCH_CHECK();

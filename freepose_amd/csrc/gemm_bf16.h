@@ -31,10 +31,10 @@ struct FpGemmArgs {
 // panels, so a strip's W slabs (<= 2 MB) stay in the XCD's 4 MB L2 for the whole sweep and each X panel is fetched once
 // per strip.  (rocprofv3, fc1 with N = 4096: the plain row-major order streamed the 8 MB weight matrix once per 2
 // row-panels — FETCH_SIZE 9x the algorithmic bytes.)
+template <int SW = 4>
 __device__ __forceinline__ void fp_gemm_tile(int block, int nblocks, int tiles_m, int tiles_n, int& tm, int& tn) {
     const int q = nblocks >> 3, r = nblocks & 7, xcd = block & 7, pos = block >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    constexpr int SW = 4;
     const int full = tiles_n / SW, tail = tiles_n - full * SW;
     const int in_full = full * tiles_m * SW;
     if (id < in_full) {

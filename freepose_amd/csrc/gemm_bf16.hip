@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     uint32_t offX[IX], offW[IW];
     auto set_tile = [&](int t, int& tm0, int& tn0) {
         int tile_m, tile_n;
-        fp_gemm_tile(t, ntiles, tiles_m, tiles_n, tile_m, tile_n);
+        fp_gemm_tile<(VAR & 512) ? 8 : 4>(t, ntiles, tiles_m, tiles_n, tile_m, tile_n);
         tm0 = tile_m * BM;
         tn0 = tile_n * BN;
 #pragma unroll
@@ -320,8 +320,10 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
             switch (var & (32 | 64)) {   // 32: persistent tile walk, 64: streaming (non-temporal) output stores
                 case 32: return launch_cfg<256, 256, 4, 4, EPI, 4 | 32>(a, stream);
                 case 64: return launch_cfg<256, 256, 4, 4, EPI, 4 | 64>(a, stream);
-                case 96: return (var & 128) ? launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128>(a, stream)
-                                            : launch_cfg<256, 256, 4, 4, EPI, 4 | 96>(a, stream);
+                case 96:
+                    if ((var & 128) && (var & 512)) return launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128 | 512>(a, stream);
+                    return (var & 128) ? launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128>(a, stream)
+                                       : launch_cfg<256, 256, 4, 4, EPI, 4 | 96>(a, stream);
                 default: return launch_cfg<256, 256, 4, 4, EPI, 4>(a, stream);
             }
         }

@@ -17,9 +17,10 @@ from freepose_amd.src.pipeline.retrieval.renderer import MeshRenderer
 from freepose_amd.src.pipeline.utils import z_from_extents
 
 
-class DinoOnlinePoseEstimator:
+class DinoOnlinePoseEstimator(torch.nn.Module):
     def __init__(self, n_coarse_poses=600, n_fine_poses=10000, cache_size=50, save_all=False, cache_dir="./data/cache",
                  feature_extractor=None):
+        super().__init__()
         self.coarse_estimator = DinoPoseEstimator(n_coarse_poses, cache_size, save_all, cache_dir, feature_extractor)
         self.feature_extractor = self.coarse_estimator.feature_extractor
         self.fine_mesh_poses = np.array(self.coarse_estimator.generate_poses(n_fine_poses))
@@ -27,15 +28,6 @@ class DinoOnlinePoseEstimator:
         self.renderer = MeshRenderer(0)
         self.renderer.mesh_poses = list(self.fine_mesh_poses)
         self.rendering_scale = 0.25
-
-    def to(self, *a, **k):
-        return self
-
-    def eval(self):
-        return self
-
-    def __call__(self, *a, **k):
-        return self.forward(*a, **k)
 
     @staticmethod
     def geodesic_distance(render_poses, query_pose, degrees=True):

@@ -28,8 +28,9 @@ def _intrinsics(K):
     return float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
 
 
-class DinoPoseEstimator:
+class DinoPoseEstimator(torch.nn.Module):
     def __init__(self, n_poses=600, cache_size=50, save_all=False, cache_dir="./data/cache", feature_extractor=None):
+        super().__init__()
         self.feature_extractor = feature_extractor if feature_extractor is not None else DINOv2FeatureExtractor()
         self.mesh_poses = self.generate_poses(n_poses)
         self.feature_cache = OrderedDict()   # model_name -> bf16 [T,P,D] on the device
@@ -37,16 +38,6 @@ class DinoPoseEstimator:
         self.save_all = save_all
         self.cache_dir = Path(cache_dir)
         self.cache_dir.mkdir(parents=True, exist_ok=True)
-
-    # nn.Module surface used by the drivers (scripts/dino_inference.py:46)
-    def to(self, *a, **k):
-        return self
-
-    def eval(self):
-        return self
-
-    def __call__(self, *a, **k):
-        return self.forward(*a, **k)
 
     def _extract_features(self, proposals, layer=22, batch_size=128):
         feats = [self.feature_extractor(proposals[i:i + batch_size], layer=layer, feature_type="patch")

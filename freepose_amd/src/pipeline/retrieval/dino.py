@@ -35,11 +35,14 @@ def _find_checkpoint(model_name: str):
     return None
 
 
-class DINOv2FeatureExtractor:
-    """Same surface as the reference nn.Module: construct, `.to(...)`, `.eval()`, call with
-    (images, layer=22, feature_type='cls'|'reg'|'patch')."""
+class DINOv2FeatureExtractor(torch.nn.Module):
+    """Same surface as the reference nn.Module (dino.py:7-32): construct, `.to(...)`, `.eval()`, call with
+    (images, layer=22, feature_type='cls'|'reg'|'patch').  The weights live in the HIP library's device tables (ops.ViT), not
+    in nn.Parameters, so `.to(device, dtype)` is a no-op by construction: the model is bf16 on the GPU, like the reference after
+    `.to('cuda', dtype=torch.bfloat16)` (pose_estimator.py:21)."""
 
     def __init__(self, model_name: str = "dinov2_vitl14_reg", state_dict: dict | None = None, seed: int = 0):
+        super().__init__()
         self.model_name = model_name
         if state_dict is None:
             ckpt = _find_checkpoint(model_name)
@@ -52,18 +55,6 @@ class DINOv2FeatureExtractor:
         self.model = ops.ViT(model_name, state_dict, seed=seed)
         self.num_register_tokens = self.model.n_reg
 
-    # nn.Module surface used by the reference call sites (pose_estimator.py:21, scripts/*.py)
-    def to(self, *args, **kwargs):
-        return self
-
-    def eval(self):
-        return self
-
-    def cuda(self):
-        return self
-
     def forward(self, images, layer=22, feature_type="cls"):
         with torch.inference_mode():
             return self.model.forward(images, layer=layer, feature_type=feature_type)
-
-    __call__ = forward

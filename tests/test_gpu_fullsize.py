@@ -93,3 +93,31 @@ def test_hot_path_full_size_planted_hypothesis():
     assert abs(z - z_formula) < 1e-9 and 1.03 < z < 1.08
     res2 = hp.run(hyp_crops[j:j + 1], masks, K, bbox, [hp.render_scale])
     assert np.array_equal(res[0].hyp_scores, res2[0].hyp_scores) and np.array_equal(res[0].topk_idx, res2[0].topk_idx)
+
+
+def test_bank_build_config_at_stated_size():
+    """BASELINE config 2 at its stated size: ViT-L/14-reg layer-22 FFA with batch 256 over the 42 template views of an object
+    (scripts.extract_retrieval_features.mesh_descriptors, reference :36-70).  The 256-crop call is padded out with repeats of
+    the views; every crop's features must be bit-identical to the same crop in a 2-crop call (batch invariance at B = 256 @
+    420^2), and the object descriptor must equal the mean of the per-view descriptors computed one view at a time."""
+    import warnings
+
+    from freepose_amd import ops
+    from freepose_amd.scripts.extract_retrieval_features import mesh_descriptors
+    from src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = DINOv2FeatureExtractor("dinov2_vitl14_reg", seed=1)
+    g = torch.Generator().manual_seed(10)
+    views = torch.rand(42, 3, 420, 420, generator=g).cuda()
+    yy, xx = torch.meshgrid(torch.arange(420), torch.arange(420), indexing="ij")
+    masks = torch.stack([(((yy - 210 + 3 * i) / (90.0 + i)) ** 2 + ((xx - 200 - 2 * i) / (150.0 - 2 * i)) ** 2) <= 1 for i in range(42)]).cuda()
+    big = torch.cat([views] * 7)[:256]                                    # B = 256
+    feats = model(big, layer=22, feature_type="patch")
+    assert feats.shape == (256, 900, 1024)
+    pair = model(views[:2], layer=22, feature_type="patch")
+    assert torch.equal(feats[:2], pair) and torch.equal(feats[42:44], pair) and torch.equal(feats[252:254], feats[0:2])
+    desc = mesh_descriptors(model, {"templates": views, "masks": masks}, "ffa", 22, 256)
+    assert desc.shape == (42, 1024) and desc.dtype == np.float32 and np.isfinite(desc).all()
+    one = np.concatenate([mesh_descriptors(model, {"templates": views[i:i + 1], "masks": masks[i:i + 1]}, "ffa", 22, 256) for i in (0, 17, 41)])
+    assert np.array_equal(desc[[0, 17, 41]], one)

@@ -181,6 +181,13 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
     for (int fq = 0; fq < 2; ++fq)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) asm volatile("" : "+v"(qf[fq][kk]));
+    if constexpr (VAR & 2) {
+        // de-phase the workgroups that share a CU: identical programs started together stay in lock-step (all in their MFMA
+        // segment, then all in their softmax segment), so a start delay spread over one tile period lets one wave's VALU work
+        // run beside another's MFMAs
+        const int d = (blockIdx.x * 5) % 12;
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(2);   // 2 x 64 cycles per step: 0 .. ~1400 cycles
+    }
     int slot = 0;
     for (int t = 0; t < ntile; ++t) {
         // tiles t+1 .. t+PF-1 may stay in flight (4 DMA instructions per tile per wave); near the end fewer are pending
@@ -360,7 +367,8 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     dim3 grid(cdiv(npad, QB) * H * B);
     const int nslot = fp_opt_get(FP_OPT_ATTN_SLOTS, 2);   // measured: 2 >= 3 > 4 (profiles/r01_ab.md)
     static int env_var = [] { const char* e = getenv("FP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-    if (nslot == 2 && (env_var & 1)) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    if (nslot == 2 && (env_var & 2)) hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    else if (nslot == 2 && (env_var & 1)) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     else if (nslot == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     else if (nslot == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(NWAVE * 64), 4 * STAGE, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(NWAVE * 64), 3 * STAGE, stream, a);

@@ -67,6 +67,7 @@ extern "C" int fp_ctx_create(int device, fp_ctx** out) {
                      prop.gcnArchName);
         return FP_ERR_STATE;
     }
+    if (int rc = fp_gemm_gelu_table(nullptr)) return rc;   // per-device constant table of the fc1 epilogue
     fp_ctx* c = new fp_ctx();
     c->device = device;
     *out = c;

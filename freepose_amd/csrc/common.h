@@ -46,6 +46,28 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// packed 16-bit helpers (one VALU instruction each; hipcc scalarises the generic vector forms of sub_sat / min)
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // ---- wave-level helpers ----------------------------------------------------------------------
 // Value held by lane (l ^ mask), mask = 32, 16, 8, 4, 2, 1, fetched on the VALU only (gfx950): v_permlane32/16_swap for
 // the wave halves / 16-lane rows, DPP inside a row (row_ror:8 is l^8 within 16 lanes; row_half_mirror then

@@ -24,6 +24,8 @@ struct FpGemmArgs {
     const bf16_t* pos; int P; int npad; int tok_off;
     // FP_EPI_VT: rows m = b*npad + t ; n = h*64 + d ; Vt is [B,H,64,npad]
     int heads;
+    // FP_EPI_BIAS_GELU: device table of fp_gemm_gelu_table() (filled in by fp_gemm_bf16; callers leave it null)
+    const uint16_t* gelu_tab;
 };
 
 // Tile order shared by the GEMM kernels.  blockIdx -> logical id (XCD-contiguous, bijective) -> (tile_m, tile_n) in
@@ -50,5 +52,7 @@ __device__ __forceinline__ void fp_gemm_tile(int block, int nblocks, int tiles_m
 
 // Launch on `stream`. Returns FP_OK / error code (fp_last_error() has the text).
 int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream);
+// builds (once per device) and returns the bf16 -> bf16 GELU table the fc1 epilogue gathers from
+int fp_gemm_gelu_table(const uint16_t** out);
 // name of the kernel variant used for (epi) — for profiles / bench bookkeeping
 const char* fp_gemm_kernel_name(int epi);

@@ -20,6 +20,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 #ifndef FP_GEMM_DEFAULT_VARIANT
 #define FP_GEMM_DEFAULT_VARIANT 238   // 2|4|8|32|64|128 (profiles/r02_ab.md: +4..6 % over 110 on every ViT shape)
 #endif
@@ -52,13 +54,31 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     constexpr int IW = BN / 8 / NW;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over waves");
 
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // dynamic LDS: [GELU table, 16 KiB, table-GELU kernels only][K-tile buffer 0][K-tile buffer 1][epilogue slabs, 2 KiB per wave].
+    // The 16-wave 256x256 kernel has no room for table + slabs (16 + 128 + 32 KiB): there the slabs live in the K-tile buffer the
+    // LAST K step consumed (free during the epilogue: the next tile's first stage is prefetched into the other one), behind one
+    // extra barrier per tile.
+    constexpr bool LUT = (EPI == FP_EPI_BIAS_GELU) && (VAR & 4) != 0;
+    constexpr bool RELOC = LUT && NW == 16;
+    constexpr int TAB = LUT ? fp_gemm::GELU_TAB_BYTES : 0;
+    extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+    char* const smem = smem_raw + TAB;                                     // K-tile buffers start here
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     char* epi_stage = smem + 2 * STAGE + wave * fp_gemm::EPI_STAGE_BYTES;   // row-coalescing slab of the epilogue
+    if constexpr (LUT) {
+        for (int o = tid * 16; o < fp_gemm::GELU_TAB_BYTES; o += NW * 64 * 16)
+            *(uint4*)(smem_raw + o) = *(const uint4*)((const char*)p.gelu_tab + o);
+        __syncthreads();   // (the pipelined loop's raw s_barrier does not wait for LDS writes)
+    }
+    // slab of this wave when the slabs share a K-tile buffer (RELOC): `buf` = the buffer the tile's last K step read
+    auto reloc_stage = [&](int buf) {
+        __syncthreads();                                                    // every wave is done reading that buffer
+        return smem + buf * STAGE + wave * fp_gemm::EPI_STAGE_BYTES;
+    };
 
     // ---- XCD-aware tile order (bijective for any grid size).  PERSIST: a resident grid walks the tiles t = block,
     // block + grid, ...; the grid is a multiple of 8, so a workgroup's tiles keep its XCD under the same remap.
@@ -209,7 +229,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
                     __builtin_amdgcn_s_setprio(0);
                 }
             }
-            fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage);
+            if constexpr (RELOC) epi_stage = reloc_stage((g - 1) & 1);
+            fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage, smem_raw);
             if (!has_next) return;
             tile += tstride;
             m0 = m0n;
@@ -269,13 +290,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         }
     }
 
-    fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage);
+    if constexpr (RELOC) epi_stage = reloc_stage((nkt - 1) & 1);
+    fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage, smem_raw);
+}
+
+// bf16(gelu_erf(x)) for the 8192 input patterns of the table window, evaluated with the device expression of the direct variant
+__global__ void gelu_table_kernel(uint16_t* tab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fp_gemm::GELU_TAB_ENTRIES) return;
+    const float x = __uint_as_float(fp_gemm::gelu_tab_pattern(i) << 16);
+    tab[i] = (uint16_t)(__float_as_uint(rbf(fp_gemm::gelu_erf(x))) >> 16);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr int SMEM = 2 * STAGE + WM * WN * fp_gemm::EPI_STAGE_BYTES;
+    constexpr bool LUT = (EPI == FP_EPI_BIAS_GELU) && (VAR & 4) != 0;
+    constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + 2 * STAGE + ((LUT && WM * WN == 16) ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -339,7 +371,32 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream) {
+// Per-device GELU table (16 KiB), built on first use; fp_ctx_create calls this so that no launch path ever allocates.
+int fp_gemm_gelu_table(const uint16_t** out) {
+    static std::mutex mu;
+    static uint16_t* tabs[64] = {};
+    int dev = 0;
+    FP_HIP(hipGetDevice(&dev));
+    FP_REQUIRE(dev >= 0 && dev < 64, "gemm: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!tabs[dev]) {
+        uint16_t* t = nullptr;
+        FP_HIP(hipMalloc((void**)&t, fp_gemm::GELU_TAB_BYTES));
+        hipLaunchKernelGGL(gelu_table_kernel, dim3(fp_gemm::GELU_TAB_ENTRIES / 256), dim3(256), 0, 0, t);
+        FP_LAUNCH_CHECK();
+        FP_HIP(hipDeviceSynchronize());
+        tabs[dev] = t;
+    }
+    if (out) *out = tabs[dev];
+    return FP_OK;
+}
+
+int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
+    FpGemmArgs a = a_in;
+    if (epi == FP_EPI_BIAS_GELU) {
+        const int rc = fp_gemm_gelu_table(&a.gelu_tab);
+        if (rc != FP_OK) return rc;
+    }
     FP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     FP_REQUIRE(a.K % BK == 0, "gemm: K=%d must be a multiple of %d", a.K, BK);
     FP_REQUIRE(a.N % 16 == 0, "gemm: N=%d must be a multiple of 16", a.N);

@@ -8,20 +8,79 @@ namespace fp_gemm {
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output ulp):
-// erf(z) = 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1/(1 + p z), z >= 0; odd extension.  ~14 VALU ops vs ~40 for erff.
-__device__ __forceinline__ float gelu_erf_poly(float x) {
-    // z = |x|/sqrt(2) never materialises: 1 + p z = fma(p/sqrt2, |x|, 1) and exp(-z^2) = exp2(x^2 * (-log2(e)/2))
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);
-    const float erfabs = fmaf(-poly * t, e, 1.0f);      // erf(|x|/sqrt2)
-    const float erfv = copysignf(erfabs, x);
-    const float hx = 0.5f * x;
-    return fmaf(hx, erfv, hx);                          // 0.5 x (1 + erf)
+// ---- table GELU -----------------------------------------------------------------------------------------------------------
+// The GELU input is the fc1 output ROUNDED TO BF16 (the reference's rounding point) and its output is rounded to bf16 again,
+// so the whole activation is a map bf16 -> bf16.  Outside |x| in [2^-15, 2^17) it is closed-form in bf16 (0.5 x below — exact,
+// a power-of-two scaling; x or -0 above), inside that window a 8192-entry table (2 signs x 32 exponents x 128 mantissas, 16 KiB
+// of LDS) holds bf16(gelu_erf(x)) for every input pattern, filled once per device by gelu_table_kernel with the SAME device
+// expression gelu_erf() the direct variant evaluates — the table variant is bit-identical to it by construction (tested over all
+// 65 536 input patterns) at ~5.5 VALU ops + one LDS gather per element instead of ~11 + v_rcp + v_exp.  On gfx950 the vector ALU
+// and the matrix pipe do not overlap, so the fc1 epilogue's ALU time is paid in full: ~7 us of a 34 us tile before.
+//
+// Index of pattern p (16 bit): (p & 0xfff) | ((p >> 3) & 0x1000): the low 5 exponent bits + mantissa are taken as they are (the
+// window 112 <= exp < 144 is a bijection onto exp & 31), the sign moves next to them.
+constexpr int GELU_TAB_ENTRIES = 8192;
+constexpr int GELU_TAB_BYTES = GELU_TAB_ENTRIES * 2;
+constexpr uint32_t GELU_WIN_LO = 112u << 7, GELU_WIN_HI = 144u << 7;      // abs-pattern window [LO, HI)
+
+__device__ __forceinline__ uint32_t gelu_tab_pattern(int i) {              // table index -> bf16 input pattern
+    const uint32_t s = (uint32_t)i >> 12, e5 = ((uint32_t)i >> 7) & 31u, m = (uint32_t)i & 127u;
+    const uint32_t ex = e5 >= 16u ? 96u + e5 : 128u + e5;
+    return (s << 15) | (ex << 7) | m;
+}
+// generic (any input) table GELU of one bf16 pattern; `tab` = LDS table
+__device__ __forceinline__ uint32_t gelu_tab_any(uint32_t p16, const uint16_t* tab) {
+    const uint32_t a = p16 & 0x7fffu;
+    if (a >= GELU_WIN_LO && a < GELU_WIN_HI) return tab[(p16 & 0xfffu) | ((p16 >> 3) & 0x1000u)];
+    const float x = __uint_as_float(p16 << 16);
+    if (a > 0x7f80u || p16 == 0xff80u) return p16 | 0x40u;                  // NaN stays NaN; -inf * (1 + erf(-inf)) = -inf * 0 = NaN
+    const float y = (a < GELU_WIN_LO) ? 0.5f * x : fmaxf(x, -0.0f);         // tiny: x/2 (exact); huge: x or -0
+    return __float_as_uint(rbf(y)) >> 16;
+}
+// 16 values of one lane (already + bias, fp32) -> 8 packed bf16 pairs of gelu(bf16(v))
+__device__ __forceinline__ void gelu_tab16(const float (&v)[16], uint32_t (&out)[8], const char* tab) {
+    uint32_t w[8];
+    uint32_t amin = 0x7fff7fffu, amax = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        w[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+        const uint32_t a2 = w[k] & 0x7fff7fffu;
+        amin = pk_min_u16(amin, a2);
+        amax = pk_max_u16(amax, a2);
+    }
+    const uint32_t lo = min(amin & 0xffffu, amin >> 16), hi = max(amax & 0xffffu, amax >> 16);
+    const bool inside = lo >= GELU_WIN_LO && hi < GELU_WIN_HI;
+    if (__builtin_amdgcn_ballot_w64(!inside) == 0ull) {
+        // every element of the wave's block is inside the window: two indices per VALU op
+        uint32_t alo[8], ahi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t u = (((w[k] >> 3) & 0x10001000u) | (w[k] & 0x0fff0fffu)) << 1;   // two byte offsets
+            alo[k] = u & 0xffffu;
+            ahi[k] = u >> 16;
+        }
+        // the gathers address the table at LDS byte 0 (the GEMM kernels put it first in their dynamic LDS, and have no static LDS)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // (the device runs with SRAM ECC: a d16 load clears the other half of its destination instead of keeping it, so the
+            // halves of a pair are gathered into two registers — low element zero-extended, high element by d16_hi — and OR-ed)
+            uint32_t r0, r1, r2, r3, q0, q1, q2, q3;
+            asm volatile(
+                "ds_read_u16 %0, %8\n\tds_read_u16 %1, %9\n\tds_read_u16 %2, %10\n\tds_read_u16 %3, %11\n\t"
+                "ds_read_u16_d16_hi %4, %12\n\tds_read_u16_d16_hi %5, %13\n\tds_read_u16_d16_hi %6, %14\n\tds_read_u16_d16_hi %7, %15\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                : "v"(alo[4 * h]), "v"(alo[4 * h + 1]), "v"(alo[4 * h + 2]), "v"(alo[4 * h + 3]),
+                  "v"(ahi[4 * h]), "v"(ahi[4 * h + 1]), "v"(ahi[4 * h + 2]), "v"(ahi[4 * h + 3])
+                : "memory");
+            r0 |= q0; r1 |= q1; r2 |= q2; r3 |= q3;
+            out[4 * h] = r0; out[4 * h + 1] = r1; out[4 * h + 2] = r2; out[4 * h + 3] = r3;
+        }
+    } else {
+        const uint16_t* t16 = (const uint16_t*)tab;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = gelu_tab_any(w[k] & 0xffffu, t16) | (gelu_tab_any(w[k] >> 16, t16) << 16);
+    }
 }
 
 // bytes of LDS each wave needs for the row-coalescing stage of the non-transposed epilogues (16 rows x 128 B)
@@ -43,7 +102,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 // streaming stores would be partial-line writes.
 template <int BM, int BN, int WM, int WN, int EPI, int VAR, int TC, int TR>
 __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC][TR], int m0, int n0, int wm, int wn,
-                                         int li, int lg, char* stg) {
+                                         int li, int lg, char* stg, const char* gelu_tab = nullptr) {
     constexpr bool TRANS = (EPI == FP_EPI_VT);
     constexpr int TM = BM / WM / 16;
     constexpr int TN = BN / WN / 16;
@@ -101,15 +160,22 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                         const uint32_t bw = biasw[2 * j + (r >> 1)];
                         v[4 * j + r] = acc[i][grp * 4 + j][r] + ((r & 1) ? hi_bf(bw) : lo_bf(bw));
                     }
-                if constexpr (EPI == FP_EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = (VAR & 4) ? gelu_erf_poly(rbf(v[e])) : gelu_erf(rbf(v[e]));
-                }
                 u32x4_t w0, w1;                                  // bf16 rounding point of the linear layer (/ GELU) output
-                w0.x = pack_bf2(v[0], v[1]);   w0.y = pack_bf2(v[2], v[3]);
-                w0.z = pack_bf2(v[4], v[5]);   w0.w = pack_bf2(v[6], v[7]);
-                w1.x = pack_bf2(v[8], v[9]);   w1.y = pack_bf2(v[10], v[11]);
-                w1.z = pack_bf2(v[12], v[13]); w1.w = pack_bf2(v[14], v[15]);
+                if constexpr (EPI == FP_EPI_BIAS_GELU && (VAR & 4) != 0) {
+                    uint32_t g[8];
+                    gelu_tab16(v, g, gelu_tab);
+                    w0 = u32x4_t{g[0], g[1], g[2], g[3]};
+                    w1 = u32x4_t{g[4], g[5], g[6], g[7]};
+                } else {
+                    if constexpr (EPI == FP_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = gelu_erf(rbf(v[e]));
+                    }
+                    w0.x = pack_bf2(v[0], v[1]);   w0.y = pack_bf2(v[2], v[3]);
+                    w0.z = pack_bf2(v[4], v[5]);   w0.w = pack_bf2(v[6], v[7]);
+                    w1.x = pack_bf2(v[8], v[9]);   w1.y = pack_bf2(v[10], v[11]);
+                    w1.z = pack_bf2(v[12], v[13]); w1.w = pack_bf2(v[14], v[15]);
+                }
                 *(bf16x8_t*)(wr + (((2 * lg) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w0);
                 *(bf16x8_t*)(wr + (((2 * lg + 1) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w1);
                 // ---- phase 2 (DS operations of one wave execute in issue order: no barrier) ---------------------------

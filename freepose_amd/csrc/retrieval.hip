@@ -256,28 +256,6 @@ __device__ __forceinline__ int wave_max_i(int v) {
     v = max(v, __float_as_int(lane_xor<1>(__int_as_float(v))));
     return v;
 }
-// packed 16-bit helpers (one VALU instruction each; hipcc scalarises the generic vector forms of sub_sat / min)
-__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {
-    uint32_t d;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
-    uint32_t d;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-    uint32_t d;
-    asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-    uint32_t d;
-    asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
 constexpr int SEL_W = 24;                 // packed words per thread: thread t owns keys [48 t, 48 t + 48)
 constexpr int SEL_CAP = SEL_T * 2 * SEL_W;   // 49 152 keys
 

@@ -42,6 +42,39 @@ def test_gemm_epilogues(M, N, K, epi):
     assert (diff <= tol).all(), f"max diff {diff.max().item()}"
 
 
+@pytest.mark.parametrize("M_rep,N", [(1, 64), (1, 256), (4, 256)])   # 128x128 kernel; 256x256 16-wave kernel (>= 192 big tiles), 1 and 4 tiles per CU
+def test_gelu_table_is_the_direct_formula_on_every_bf16_input(M_rep, N):
+    """fc1 epilogue: the table GELU (default) against the direct fp32 expression 0.5 x (1 + erf(x / sqrt 2)) (gemm_variant 0) on ALL 65 536 bf16 inputs — one-hot weights make the pre-activation equal the chosen pattern exactly (NaN/Inf and
+    both zeros included); bit-identical.  Against torch's CPU GELU of the same bf16 inputs: equal up to the last-place noise of
+    two erf implementations in the cancelling tail (x < -3.5, |gelu| < 1e-3)."""
+    from freepose_amd import ops
+    pats = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)          # every bf16 pattern
+    K = 64
+    x = torch.zeros((65536 * M_rep, K), dtype=torch.bfloat16)
+    x[:, 0] = pats.repeat(M_rep)
+    w = torch.zeros((N, K), dtype=torch.bfloat16)
+    w[:, 0] = 1.0
+    bias = torch.zeros((N,), dtype=torch.bfloat16)
+    try:
+        ops.set_option("gemm_variant", -1)
+        tab = ops.gemm(x, w, bias, 1).cpu()
+        ops.set_option("gemm_variant", 0)          # plain kernels: direct erff expression
+        direct = ops.gemm(x, w, bias, 1).cpu()
+    finally:
+        ops.set_option("gemm_variant", -1)
+    a, b = tab.view(torch.int16), direct.view(torch.int16)
+    finite = ~torch.isnan(pats.float()).repeat(M_rep)
+    assert torch.equal(a[finite], b[finite]), "table GELU differs from the direct formula"
+    assert torch.isnan(tab.float()[~finite]).all()
+    assert (a == a[:, :1]).all()                                                               # every column saw the same input
+    col = tab[:65536, 0].float()
+    ref = torch.nn.functional.gelu(pats.float()).to(torch.bfloat16).float()
+    ok = torch.isfinite(pats.float())
+    same = (col[ok] == ref[ok]).float().mean().item()
+    assert same > 0.995, same
+    assert ((col[ok] - ref[ok]).abs() <= 2e-6 + 2.0 ** -7 * ref[ok].abs()).all()
+
+
 @pytest.mark.parametrize("B,npad,H", [(1, 272, 6), (3, 912, 16), (2, 1376, 16), (52, 1376, 16)])   # last: persistent 256x256 path
 def test_gemm_vt(B, npad, H):
     from freepose_amd import ops

@@ -329,7 +329,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // big tile once the grid can fill the chip with it, else the 128x128 tile
     const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
     // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads (8-wave kernels),
-    // 4 = polynomial erf in the GELU epilogue, 8 = 16-wave big tile, 32 = persistent tile walk,
+    // 4 = table GELU in the fc1 epilogue (gemm_epilogue.h; 0 = direct erff expression), 8 = 16-wave big tile, 32 = persistent tile walk,
     // 64 = streaming epilogue I/O: non-temporal output stores and residual loads (the last two with the 16-wave big tile),
     // 128 = split DMA issue (X pieces behind the first fragment reads, W pieces behind the first MFMA block) + MFMA priority
     // (persistent 16-wave kernel).  FP_GEMM_VARIANT / fp_set_option override

@@ -147,10 +147,12 @@ __global__ __launch_bounds__(256) void crop_kernel(const void* __restrict__ imag
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void geodesic_flags_kernel(const double* __restrict__ grid, int G, const double* __restrict__ Rp,
+struct Rot9 { double v[9]; };   // the previous rotation travels as a kernel argument (no staging copy, no host sync)
+__global__ void geodesic_flags_kernel(const double* __restrict__ grid, int G, const Rot9 Rprev,
                                       double thresh_deg, int32_t* __restrict__ flags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G) return;
+    const double* Rp = Rprev.v;
     double R[9], D[9];
     for (int k = 0; k < 9; ++k) R[k] = grid[(size_t)i * 9 + k];
     // D = R_i * Rp^T
@@ -343,19 +345,16 @@ extern "C" int fp_geodesic_select(fp_ctx* ctx, const double* d_grid, int G, cons
     char* ws;
     int rc;
     if ((rc = ctx->get("geo.ws", (size_t)G * 4 + 256, (void**)&ws))) return rc;
-    double* Rp = (double*)ws;             // 9 doubles
     int* dn = (int*)(ws + 128);
     int32_t* flags = (int32_t*)(ws + 256);
-    double Rd[9];
-    for (int i = 0; i < 9; ++i) Rd[i] = h_R[i];
-    FP_HIP(hipMemcpyAsync(Rp, Rd, sizeof(Rd), hipMemcpyHostToDevice, s));
-    FP_HIP(hipStreamSynchronize(s));  // Rd is a stack buffer
-    hipLaunchKernelGGL(geodesic_flags_kernel, dim3(cdiv(G, 256)), dim3(256), 0, s, d_grid, G, Rp, thresh_deg, flags);
+    Rot9 Rd;
+    for (int i = 0; i < 9; ++i) Rd.v[i] = h_R[i];
+    hipLaunchKernelGGL(geodesic_flags_kernel, dim3(cdiv(G, 256)), dim3(256), 0, s, d_grid, G, Rd, thresh_deg, flags);
     FP_LAUNCH_CHECK();
     hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, s, flags, G, d_out_idx, dn);
     FP_LAUNCH_CHECK();
     FP_HIP(hipMemcpyAsync(h_n, dn, sizeof(int), hipMemcpyDeviceToHost, s));
-    FP_HIP(hipStreamSynchronize(s));
+    FP_HIP(hipStreamSynchronize(s));   // the one wait of the call: the caller sizes its render batch with *h_n
     return FP_OK;
 }
 

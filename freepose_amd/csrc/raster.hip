@@ -14,22 +14,36 @@
 //            exact ties; order independent, hence deterministic
 //   base colour of the visible fragment, q_i = b_i*iz_i:
 //            vertex colours : cv = fma(q2,c2, fma(q1,c1, q0*c0)) * depth                      (0..255 units)
-//            textured mesh  : per-corner UV, U = fma(q2,u2, fma(q1,u1, q0*u0)) * depth (same for V); bilinear filter of mip
-//                             level 0, REPEAT wrap, texel centres at integer + 0.5, v = 1 at the image's first row:
-//                             x = U*tw - 0.5, y = (1-V)*th - 0.5, (x0,y0) = floor, w = frac;
-//                             top = fma(wx, t01-t00, t00), bot = fma(wx, t11-t10, t10), val = fma(wy, bot-top, top); c = val*Kd
-//                             texel value = DEC[u8] (sRGB -> linear, 256-entry table: decode before filtering) when shade = 1,
-//                             float(u8)/255.f when shade = 0
+//            textured mesh  : per-corner UV, U = fma(q2,u2, fma(q1,u1, q0*u0)) * depth (same for V).  The texture is filtered
+//                             as stored (u8 values 0..255, the image's gamma space — a GL_RGBA8 texture):
+//              level k      : max(1, tw>>k) x max(1, th>>k); level k+1 = 2x2 box of level k, (a+b+c+d+2)>>2 per channel (built on
+//                             the host at upload; second row / column clamped when the source size is 1)
+//              bilinear(k)  : x = U*wk - 0.5, y = (1-V)*hk - 0.5 (v = 1 at the image's first row), (x0,y0) = floor, REPEAT wrap,
+//                             top = fma(wx, t01-t00, t00), bot = fma(wx, t11-t10, t10), val = fma(wy, bot-top, top)
+//              level of detail (filter 1, default: GL_LINEAR_MIPMAP_LINEAR with ANALYTIC derivatives — what pyrender's sampler
+//                             asks GL for): g?_i = d(b_i)/d(px|py) * iz_i are constants of the triangle;
+//                             dU/dx = fma(gx2,u2-U, fma(gx1,u1-U, gx0*(u0-U))) * depth (same for V, y);
+//                             rho2 = max((dU/dx*tw)^2 + (dV/dx*th)^2, (dU/dy*tw)^2 + (dV/dy*th)^2);
+//                             rho2 <= 1 (magnification) or a single level: bilinear(0); else e = exponent(rho2), m = mantissa,
+//                             lg = LOG2P(m-1) (degree-5 polynomial in fmaf steps, |err| < 2e-5), l0 = e>>1,
+//                             fr = 0.5*((e&1) + lg); l0 >= last: bilinear(last); else val = fma(fr, bilinear(l0+1)-bilinear(l0), bilinear(l0))
+//                             filter 0: bilinear(0) always
+//              shade 1      : lin = sRGB->linear of val/255 by linear interpolation in DEC[256] (i = min(int(val),254),
+//                             lin = fma(val-i, DEC[i+1]-DEC[i], DEC[i])): sample, THEN decode (a shader's srgb_to_linear(texture()));
+//                             c = lin*Kd.      shade 0: c255 = val*Kd
 //   output : shade 1 (default, "gamma"): u8 = #{k in 1..255 : THR[k] <= a*c}, THR[k] = ((k-.5)/255)^2.2, i.e.
 //            round(255 (a c)^(1/2.2)) found by table search so that host oracle and device agree bit for bit (vertex: c = cv/255)
-//            shade 0 ("linear", the round-1 rule): (u8) min(255, a*cv + 0.5)                  (textured: cv = c*255)
+//            shade 0 ("linear", the round-1 rule): (u8) min(255, a*cv + 0.5)                  (textured: cv = c255)
 //            a = ambient light factor: 2 by default (renderer.py:53-55), 5 in tracking_refiner.py:33.
 //   pyrender's fragment shader is third-party and absent from /root/reference: the shading rule is STATED here, not pinned
-//   (DESIGN.md §5).  GL would minify through trilinear mip-maps; level 0 only is a documented deviation.
+//   (DESIGN.md §5).  A GPU derives the level of detail from 2x2-quad finite differences with a few fractional bits; the analytic
+//   derivative used here is the quantity those approximate.
 // Launch shape: vertex kernel (Hn x V threads), triangle kernel (Hn x F threads; small triangles are
 // rasterised by their thread, large ones by a whole wave via a queue), resolve kernel (Hn x pixels).
 #include "../../include/freepose_hip.h"
 #include "internal.h"
+
+#include <algorithm>
 
 struct fp_mesh {
     fp_ctx* ctx = nullptr;
@@ -37,7 +51,10 @@ struct fp_mesh {
     int32_t* faces = nullptr;  // [F,3]
     uint8_t* colors = nullptr; // [V,4] rgba (a unused)
     float* uv = nullptr;       // [F,3,2] per-corner texture coordinates (textured meshes)
-    uint8_t* tex = nullptr;    // [th,tw,4] rgba diffuse texture
+    uint8_t* tex = nullptr;    // rgba diffuse texture, all mip levels back to back (level k at texel offset lev_off[k])
+    int nlev = 0;
+    uint32_t lev_off[16] = {};
+    int filter = 1;            // 1 = trilinear mip-maps, 0 = bilinear level 0
     float* tables = nullptr;   // DEC[256] sRGB->linear, THR[256] gamma-encode thresholds
     int th = 0, tw = 0;
     float kd[3] = {1.f, 1.f, 1.f};   // material diffuse factor (MTL Kd / glTF baseColorFactor)
@@ -160,11 +177,13 @@ __device__ __forceinline__ void tri_pixel(const TriSetup& t, int f, int px, int 
 struct ShadeArgs {
     const uint8_t* colors;   // [V,4] or null
     const float* uv;         // [F,3,2] or null
-    const uint8_t* tex;      // [th,tw,4] or null
+    const uint8_t* tex;      // rgba mip chain or null
     int th, tw;
     float kd0, kd1, kd2;
     float ambient;
     int shade;
+    int nlev, filter;
+    uint32_t lev_off[16];
 };
 
 // largest k in [0,255] with thr[k] <= x (thr[0] = 0); the pow() estimate only decides how many table steps are taken
@@ -178,6 +197,36 @@ __device__ __forceinline__ uint8_t encode_gamma(float x, const float* thr) {
 }
 __device__ __forceinline__ int wrapi(int a, int n) { const int m = a % n; return m < 0 ? m + n : m; }
 
+// bilinear sample of one mip level (values in 0..255 units)
+__device__ __forceinline__ void bilinear_level(const uint8_t* __restrict__ lev, int w, int h, float U, float Vv, float (&out)[3]) {
+    float x = fmaf(U, (float)w, -0.5f), y = fmaf(1.0f - Vv, (float)h, -0.5f);
+    x = fminf(fmaxf(x, -1.0e6f), 1.0e6f); y = fminf(fmaxf(y, -1.0e6f), 1.0e6f);
+    if (!(x == x)) x = 0.f;
+    if (!(y == y)) y = 0.f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float wx = x - xf, wy = y - yf;
+    const int x0 = wrapi((int)xf, w), x1 = wrapi((int)xf + 1, w);
+    const int y0 = wrapi((int)yf, h), y1 = wrapi((int)yf + 1, h);
+    const uint32_t e00 = *(const uint32_t*)(lev + ((size_t)y0 * w + x0) * 4), e01 = *(const uint32_t*)(lev + ((size_t)y0 * w + x1) * 4);
+    const uint32_t e10 = *(const uint32_t*)(lev + ((size_t)y1 * w + x0) * 4), e11 = *(const uint32_t*)(lev + ((size_t)y1 * w + x1) * 4);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float t00 = (float)((e00 >> (8 * c)) & 255), t01 = (float)((e01 >> (8 * c)) & 255);
+        const float t10 = (float)((e10 >> (8 * c)) & 255), t11 = (float)((e11 >> (8 * c)) & 255);
+        const float top = fmaf(wx, t01 - t00, t00), bot = fmaf(wx, t11 - t10, t10);
+        out[c] = fmaf(wy, bot - top, top);
+    }
+}
+// LOG2P(t) ~ log2(1 + t) on [0,1)
+__device__ __forceinline__ float log2p(float t) {
+    float a = 0.045148879289627075f;
+    a = fmaf(a, t, -0.19357527792453766f);
+    a = fmaf(a, t, 0.41560569405555725f);
+    a = fmaf(a, t, -0.7090963125228882f);
+    a = fmaf(a, t, 1.441917061805725f);
+    return a * t;
+}
+
 // tab: DEC[256] then THR[256] (LDS copy)
 __device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetup& t, int f, float q0, float q1, float q2,
                                                float dd, const float* tab, uint8_t (&out)[3]) {
@@ -186,28 +235,53 @@ __device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetu
     if (s.uv) {
         const float* tc = s.uv + (size_t)f * 6;
         const int k1 = t.swapped ? 2 : 1, k2 = t.swapped ? 1 : 2;
-        const float U = fmaf(q2, tc[2 * k2], fmaf(q1, tc[2 * k1], q0 * tc[0])) * dd;
-        const float Vv = fmaf(q2, tc[2 * k2 + 1], fmaf(q1, tc[2 * k1 + 1], q0 * tc[1])) * dd;
-        float x = fmaf(U, (float)s.tw, -0.5f), y = fmaf(1.0f - Vv, (float)s.th, -0.5f);
-        x = fminf(fmaxf(x, -1.0e6f), 1.0e6f); y = fminf(fmaxf(y, -1.0e6f), 1.0e6f);
-        if (!(x == x)) x = 0.f;
-        if (!(y == y)) y = 0.f;
-        const float xf = floorf(x), yf = floorf(y);
-        const float wx = x - xf, wy = y - yf;
-        const int x0 = wrapi((int)xf, s.tw), x1 = wrapi((int)xf + 1, s.tw);
-        const int y0 = wrapi((int)yf, s.th), y1 = wrapi((int)yf + 1, s.th);
-        const uint32_t e00 = *(const uint32_t*)(s.tex + ((size_t)y0 * s.tw + x0) * 4), e01 = *(const uint32_t*)(s.tex + ((size_t)y0 * s.tw + x1) * 4);
-        const uint32_t e10 = *(const uint32_t*)(s.tex + ((size_t)y1 * s.tw + x0) * 4), e11 = *(const uint32_t*)(s.tex + ((size_t)y1 * s.tw + x1) * 4);
+        const float u0 = tc[0], u1 = tc[2 * k1], u2 = tc[2 * k2];
+        const float v0 = tc[1], v1 = tc[2 * k1 + 1], v2 = tc[2 * k2 + 1];
+        const float U = fmaf(q2, u2, fmaf(q1, u1, q0 * u0)) * dd;
+        const float Vv = fmaf(q2, v2, fmaf(q1, v1, q0 * v0)) * dd;
+        int l0 = 0;
+        bool two = false;
+        float fr = 0.f;
+        if (s.filter && s.nlev > 1) {
+            const float fa = (float)t.area2;
+            // d(w_i)/d(px) = -256 (y_b - y_a), d(w_i)/d(py) = 256 (x_b - x_a) of the edge opposite corner i
+            const float gx0 = (float)(-(long long)(t.y2 - t.y1) * 256) / fa * t.iz0, gy0 = (float)((long long)(t.x2 - t.x1) * 256) / fa * t.iz0;
+            const float gx1 = (float)(-(long long)(t.y0 - t.y2) * 256) / fa * t.iz1, gy1 = (float)((long long)(t.x0 - t.x2) * 256) / fa * t.iz1;
+            const float gx2 = (float)(-(long long)(t.y1 - t.y0) * 256) / fa * t.iz2, gy2 = (float)((long long)(t.x1 - t.x0) * 256) / fa * t.iz2;
+            const float dux = fmaf(gx2, u2 - U, fmaf(gx1, u1 - U, gx0 * (u0 - U))) * dd * (float)s.tw;
+            const float dvx = fmaf(gx2, v2 - Vv, fmaf(gx1, v1 - Vv, gx0 * (v0 - Vv))) * dd * (float)s.th;
+            const float duy = fmaf(gy2, u2 - U, fmaf(gy1, u1 - U, gy0 * (u0 - U))) * dd * (float)s.tw;
+            const float dvy = fmaf(gy2, v2 - Vv, fmaf(gy1, v1 - Vv, gy0 * (v0 - Vv))) * dd * (float)s.th;
+            float r2 = fmaxf(fmaf(dux, dux, dvx * dvx), fmaf(duy, duy, dvy * dvy));
+            if (!(r2 == r2)) r2 = 0.f;
+            if (r2 > 1.0f) {
+                const uint32_t rb = __float_as_uint(r2);
+                const int e = (int)(rb >> 23) - 127;
+                const float m = __uint_as_float((rb & 0x7fffffu) | 0x3f800000u);
+                const float lg = log2p(m - 1.0f);
+                l0 = e >> 1;
+                fr = 0.5f * ((float)(e & 1) + lg);
+                if (l0 >= s.nlev - 1) { l0 = s.nlev - 1; fr = 0.f; } else two = true;
+            }
+        }
+        float val[3];
+        bilinear_level(s.tex + (size_t)s.lev_off[l0] * 4, max(1, s.tw >> l0), max(1, s.th >> l0), U, Vv, val);
+        if (two) {
+            float hi[3];
+            bilinear_level(s.tex + (size_t)s.lev_off[l0 + 1] * 4, max(1, s.tw >> (l0 + 1)), max(1, s.th >> (l0 + 1)), U, Vv, hi);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) val[c] = fmaf(fr, hi[c] - val[c], val[c]);
+        }
         const float kd[3] = {s.kd0, s.kd1, s.kd2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const int b00 = (e00 >> (8 * c)) & 255, b01 = (e01 >> (8 * c)) & 255, b10 = (e10 >> (8 * c)) & 255, b11 = (e11 >> (8 * c)) & 255;
-            const float t00 = s.shade ? dec[b00] : (float)b00 / 255.f, t01 = s.shade ? dec[b01] : (float)b01 / 255.f;
-            const float t10 = s.shade ? dec[b10] : (float)b10 / 255.f, t11 = s.shade ? dec[b11] : (float)b11 / 255.f;
-            const float top = fmaf(wx, t01 - t00, t00), bot = fmaf(wx, t11 - t10, t10);
-            const float cl = fmaf(wy, bot - top, top) * kd[c];
-            if (s.shade) out[c] = encode_gamma(s.ambient * cl, thr);
-            else out[c] = (uint8_t)fmaxf(fminf(s.ambient * (cl * 255.f) + 0.5f, 255.0f), 0.f);
+            if (s.shade) {
+                const int ii = min(max((int)val[c], 0), 254);
+                const float lin = fmaf(val[c] - (float)ii, dec[ii + 1] - dec[ii], dec[ii]);
+                out[c] = encode_gamma(s.ambient * (lin * kd[c]), thr);
+            } else {
+                out[c] = (uint8_t)fmaxf(fminf(s.ambient * (val[c] * kd[c]) + 0.5f, 255.0f), 0.f);
+            }
         }
     } else {
 #pragma unroll
@@ -481,8 +555,28 @@ extern "C" int fp_mesh_upload_textured(fp_ctx* ctx, const float* h_verts, int V,
     fp_mesh* m = nullptr;
     int rc = mesh_geometry(ctx, h_verts, V, h_faces, F, &m);
     if (rc) return rc;
-    std::vector<uint8_t> rgba((size_t)th * tw * 4, 255);
+    // level 0 + the box-filtered chain down to 1 x 1 (contract in the header), rgba, back to back
+    int lw[16], lh[16], n = 0;
+    size_t total = 0;
+    for (int w = tw, h = th;; w = w > 1 ? w >> 1 : 1, h = h > 1 ? h >> 1 : 1) {
+        lw[n] = w; lh[n] = h; m->lev_off[n] = (uint32_t)total; total += (size_t)w * h; ++n;
+        if ((w == 1 && h == 1) || n == 16) break;
+    }
+    m->nlev = n;
+    std::vector<uint8_t> rgba(total * 4, 255);
     for (size_t i = 0; i < (size_t)th * tw; ++i) { rgba[4 * i] = h_texture[3 * i]; rgba[4 * i + 1] = h_texture[3 * i + 1]; rgba[4 * i + 2] = h_texture[3 * i + 2]; }
+    for (int k = 1; k < n; ++k) {
+        const uint8_t* src = rgba.data() + (size_t)m->lev_off[k - 1] * 4;
+        uint8_t* dst = rgba.data() + (size_t)m->lev_off[k] * 4;
+        const int sw = lw[k - 1], sh = lh[k - 1];
+        for (int y = 0; y < lh[k]; ++y)
+            for (int x = 0; x < lw[k]; ++x) {
+                const int x0 = std::min(2 * x, sw - 1), x1 = std::min(2 * x + 1, sw - 1), y0 = std::min(2 * y, sh - 1), y1 = std::min(2 * y + 1, sh - 1);
+                for (int c = 0; c < 3; ++c)
+                    dst[((size_t)y * lw[k] + x) * 4 + c] = (uint8_t)((src[((size_t)y0 * sw + x0) * 4 + c] + src[((size_t)y0 * sw + x1) * 4 + c] +
+                                                                     src[((size_t)y1 * sw + x0) * 4 + c] + src[((size_t)y1 * sw + x1) * 4 + c] + 2) >> 2);
+            }
+    }
     FP_HIP(hipMalloc((void**)&m->tex, rgba.size()));
     FP_HIP(hipMemcpy(m->tex, rgba.data(), rgba.size(), hipMemcpyHostToDevice));
     FP_HIP(hipMalloc((void**)&m->uv, (size_t)F * 24));
@@ -509,6 +603,8 @@ static ShadeArgs shade_args(const fp_mesh* m) {
     a.colors = m->colors; a.uv = m->uv; a.tex = m->tex; a.th = m->th; a.tw = m->tw;
     a.kd0 = m->kd[0]; a.kd1 = m->kd[1]; a.kd2 = m->kd[2];
     a.ambient = m->ambient; a.shade = m->shade;
+    a.nlev = m->nlev; a.filter = m->filter;
+    for (int k = 0; k < 16; ++k) a.lev_off[k] = m->lev_off[k];
     return a;
 }
 
@@ -596,6 +692,11 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
 extern "C" int fp_mesh_set_ambient(fp_mesh* mesh, float ambient) {
     FP_REQUIRE(mesh && ambient >= 0.f, "mesh_set_ambient: bad argument");
     mesh->ambient = ambient;
+    return FP_OK;
+}
+extern "C" int fp_mesh_set_filter(fp_mesh* mesh, int mode) {
+    FP_REQUIRE(mesh && (mode == 0 || mode == 1), "mesh_set_filter: mode must be 0 (bilinear level 0) or 1 (trilinear mip-maps)");
+    mesh->filter = mode;
     return FP_OK;
 }
 extern "C" int fp_mesh_set_shading(fp_mesh* mesh, int mode) {

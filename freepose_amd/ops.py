@@ -343,6 +343,11 @@ class Mesh:
             check(self.lib.fp_mesh_upload(context(), ptr(v), v.shape[0], ptr(f), f.shape[0], ptr(c), C.byref(h)), "fp_mesh_upload")
         self.handle, self.V, self.F = h, v.shape[0], f.shape[0]
 
+    def set_filter(self, mode: int):
+        """texture minification: 1 = trilinear mip-maps (default), 0 = bilinear level 0 (csrc/raster.hip header)"""
+        check(self.lib.fp_mesh_set_filter(self.handle, int(mode)), "fp_mesh_set_filter")
+        return self
+
     def set_shading(self, mode: int):
         """1 = gamma output rule (default), 0 = linear (csrc/raster.hip header)"""
         check(self.lib.fp_mesh_set_shading(self.handle, int(mode)), "fp_mesh_set_shading")

@@ -138,7 +138,8 @@ int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_fa
 /* textured mesh, as pyrender.Mesh.from_trimesh(mesh) receives it from trimesh.load(obj, force='mesh') (renderer.py:43-45,70-72;
  * scripts/dino_inference_video.py:93-101, scripts/render_templates.py:58-66): per-corner texture coordinates uv f32 [F,3,2]
  * (OBJ `vt` convention: v up), diffuse texture u8 [th,tw,3] (image rows top to bottom), material diffuse factor kd f32 [3] or
- * NULL (= 1,1,1).  Fragments are shaded with a perspective-correct bilinear texture fetch (REPEAT wrap, mip level 0); the
+ * NULL (= 1,1,1).  Fragments are shaded with a perspective-correct texture fetch (REPEAT wrap, trilinear over a box-filtered
+ * mip chain built at upload — the sampler pyrender gives a trimesh texture; fp_mesh_set_filter(.., 0) = bilinear level 0); the
  * exact arithmetic is the contract at the top of csrc/raster.hip.  All host pointers. */
 int fp_mesh_upload_textured(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F, const float* h_uv,
                             const uint8_t* h_texture, int th, int tw, const float* h_kd3, fp_mesh** out);
@@ -150,6 +151,9 @@ int fp_mesh_set_ambient(fp_mesh* mesh, float ambient);
  * term reaches the frame buffer); 0 = linear rule, u8 = min(255, 255 ambient c + .5).  pyrender's shader is third-party and
  * not in the reference tree, so neither is pinned; both are bit-exact against the oracle. */
 int fp_mesh_set_shading(fp_mesh* mesh, int mode);
+/* texture minification: 1 (default) = trilinear mip-maps, level of detail from the analytic UV derivatives of the fragment;
+ * 0 = bilinear fetch of level 0 only.  Replaces the sampler state of pyrender's texture objects (renderer.py:43-47,70-74). */
+int fp_mesh_set_filter(fp_mesh* mesh, int mode);
 /* vertex stage of the rasteriser alone: window coordinates in 24.8 fixed point d_xy i32 [Hn,V,2] (x right, y down, pixel
  * centres at +0.5; 0,0 for vertices at or behind the near plane) and camera-frame depth d_zc f32 [Hn,V].  Conventions pinned
  * against the reference's K -> OpenGL projection (bop_toolkit_lib/renderer_py.py:186-231, renderer.py:37-41). */

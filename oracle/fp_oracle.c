@@ -381,15 +381,26 @@ typedef struct { int xi, yi; float iz, zc; } svert_t;
 static int topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
 
 /* Shading contract (shared with raster.hip; pyrender's shader is not in /root/reference, so this is a stated rule, not a pin):
- *   base colour of a fragment, in [0,1]:
- *     textured mesh : perspective-correct per-corner UV (U = fma(q2,u2, fma(q1,u1, q0*u0)) * depth, q_i = b_i*iz_i), bilinear
- *                     filter of mip level 0 with REPEAT wrap, texel centres at integer+0.5, v = 1 is the image's first row:
- *                     x = U*tw - 0.5, y = (1-V)*th - 0.5 ; (x0,y0) = floor ; weights (x-x0, y-y0) ;
- *                     top = fma(wx, t01-t00, t00), bot = fma(wx, t11-t10, t10), val = fma(wy, bot-top, top) ; c = val*Kd
- *                     texel value: shade 1 -> DEC[u8] (sRGB -> linear through a 256-entry table, i.e. decode BEFORE filtering, GL's
- *                     SRGB8 behaviour), shade 0 -> float(u8)/255.f
- *     vertex colours: cv = fma(q2,c2, fma(q1,c1, q0*c0)) * depth  (0..255 units, as before)
- *   output: shade 0 (linear, the round-1 rule): u8(min(255, ambient*cv + 0.5))            [textured: cv = c*255.f]
+ *   base colour of a fragment:
+ *     textured mesh : perspective-correct per-corner UV (U = fma(q2,u2, fma(q1,u1, q0*u0)) * depth, q_i = b_i*iz_i).  The texture
+ *                     is filtered as stored (u8 values 0..255, i.e. in the image's gamma space — what a GL_RGBA8 texture does):
+ *       level k       : size max(1, tw>>k) x max(1, th>>k); level k+1 = 2x2 box of level k, (a+b+c+d+2)>>2 per channel (the
+ *                       second row / column is clamped when the source size is 1)
+ *       bilinear(k)   : x = U*wk - 0.5, y = (1-V)*hk - 0.5 (v = 1 is the image's first row) ; (x0,y0) = floor ; REPEAT wrap ;
+ *                       top = fma(wx, t01-t00, t00), bot = fma(wx, t11-t10, t10), val = fma(wy, bot-top, top)
+ *       level of detail (filter 1, default = GL_LINEAR_MIPMAP_LINEAR with analytic derivatives): with g?_i = d(b_i)/d(px|py) * iz_i
+ *                       (constants of the triangle), dU/dx = fma(gx2,u2-U, fma(gx1,u1-U, gx0*(u0-U))) * depth (same for V, y);
+ *                       rho2 = max((dU/dx*tw)^2 + (dV/dx*th)^2, (dU/dy*tw)^2 + (dV/dy*th)^2).  rho2 <= 1 (magnification) or one
+ *                       level only: bilinear(0).  Otherwise e = exponent(rho2), m = mantissa in [1,2), lg = LOG2P(m-1) (degree-5
+ *                       polynomial, |err| < 2e-5), l0 = e>>1, fr = 0.5*((e&1) + lg) [= 0.5*log2(rho2) - l0]; l0 >= last level:
+ *                       bilinear(last); else val = fma(fr, bilinear(l0+1) - bilinear(l0), bilinear(l0)).
+ *                       filter 0: bilinear(0) always (the rule before mip-maps).
+ *       shade 1       : lin = sRGB->linear of val/255 by linear interpolation in the 256-entry table DEC (i = min(int(val), 254),
+ *                       lin = fma(val-i, DEC[i+1]-DEC[i], DEC[i])): sample first, decode after — the order of a shader that calls
+ *                       srgb_to_linear(texture(...)) ; c = lin*Kd
+ *       shade 0       : c255 = val*Kd
+ *     vertex colours: cv = fma(q2,c2, fma(q1,c1, q0*c0)) * depth  (0..255 units)
+ *   output: shade 0 (linear, the round-1 rule): u8(min(255, ambient*cv + 0.5))            [textured: cv = c255]
  *           shade 1 (gamma, default): u8 = #{ k in 1..255 : THR[k] <= ambient*c }, THR[k] = ((k-0.5)/255)^2.2 — i.e.
  *           round(255 * x^(1/2.2)) evaluated by table search so host and device agree bit for bit      [vertex: c = cv*(1/255.f)] */
 static float g_dec[256], g_thr[256];
@@ -412,14 +423,66 @@ static uint8_t encode_gamma(float x) {
 }
 static int wrapi(int a, int n) { int m = a % n; return m < 0 ? m + n : m; }
 
+/* mip chain of an RGB u8 texture (see the contract): returns malloc'd texels of all levels, level k at offset off[k] (texels) */
+#define FPO_MAX_LEV 16
+static uint8_t* build_mips(const uint8_t* tex, int th, int tw, int* nlev, size_t* off, int* lw, int* lh) {
+    int n = 0; size_t total = 0;
+    for (int w = tw, h = th;; w = w > 1 ? w >> 1 : 1, h = h > 1 ? h >> 1 : 1) {
+        lw[n] = w; lh[n] = h; off[n] = total; total += (size_t)w * h; ++n;
+        if ((w == 1 && h == 1) || n == FPO_MAX_LEV) break;
+    }
+    uint8_t* m = (uint8_t*)malloc(total * 3);
+    memcpy(m, tex, (size_t)tw * th * 3);
+    for (int k = 1; k < n; ++k) {
+        const uint8_t* src = m + off[k - 1] * 3; uint8_t* dst = m + off[k] * 3;
+        const int sw = lw[k - 1], sh = lh[k - 1];
+        for (int y = 0; y < lh[k]; ++y)
+            for (int x = 0; x < lw[k]; ++x) {
+                const int x0 = 2 * x < sw ? 2 * x : sw - 1, x1 = 2 * x + 1 < sw ? 2 * x + 1 : sw - 1;
+                const int y0 = 2 * y < sh ? 2 * y : sh - 1, y1 = 2 * y + 1 < sh ? 2 * y + 1 : sh - 1;
+                for (int ch = 0; ch < 3; ++ch)
+                    dst[((size_t)y * lw[k] + x) * 3 + ch] = (uint8_t)((src[((size_t)y0 * sw + x0) * 3 + ch] + src[((size_t)y0 * sw + x1) * 3 + ch] +
+                                                                     src[((size_t)y1 * sw + x0) * 3 + ch] + src[((size_t)y1 * sw + x1) * 3 + ch] + 2) >> 2);
+            }
+    }
+    *nlev = n;
+    return m;
+}
+/* bilinear sample of one level, values in 0..255 units */
+static void bilinear_level(const uint8_t* lev, int w, int h, float U, float Vv, float out[3]) {
+    float x = fmaf(U, (float)w, -0.5f), y = fmaf(1.0f - Vv, (float)h, -0.5f);
+    x = fminf(fmaxf(x, -1.0e6f), 1.0e6f); y = fminf(fmaxf(y, -1.0e6f), 1.0e6f);
+    if (!(x == x)) x = 0.f;
+    if (!(y == y)) y = 0.f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float wx = x - xf, wy = y - yf;
+    const int x0 = wrapi((int)xf, w), x1 = wrapi((int)xf + 1, w);
+    const int y0 = wrapi((int)yf, h), y1 = wrapi((int)yf + 1, h);
+    for (int ch = 0; ch < 3; ++ch) {
+        const float t00 = (float)lev[((size_t)y0 * w + x0) * 3 + ch], t01 = (float)lev[((size_t)y0 * w + x1) * 3 + ch];
+        const float t10 = (float)lev[((size_t)y1 * w + x0) * 3 + ch], t11 = (float)lev[((size_t)y1 * w + x1) * 3 + ch];
+        const float top = fmaf(wx, t01 - t00, t00), bot = fmaf(wx, t11 - t10, t10);
+        out[ch] = fmaf(wy, bot - top, top);
+    }
+}
+/* LOG2P(t) ~ log2(1 + t) on [0,1): t * Horner(c1..c5), every step an fmaf */
+static float log2p(float t) {
+    float a = 0.045148879289627075f;
+    a = fmaf(a, t, -0.19357527792453766f);
+    a = fmaf(a, t, 0.41560569405555725f);
+    a = fmaf(a, t, -0.7090963125228882f);
+    a = fmaf(a, t, 1.441917061805725f);
+    return a * t;
+}
+
 void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
                        const float* uv /* [F,3,2] or NULL */, const uint8_t* tex /* [th,tw,3] or NULL */, int th, int tw,
                        const float* kd3 /* or NULL = 1,1,1 */, const float* poses, int Hn, float scale, float fx, float fy,
-                       float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade);
+                       float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade, int filter);
 void fpo_rasterize_amb(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
                        const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
                        uint8_t* rgb, float* depth, float ambient) {
-    fpo_rasterize_tex(verts, V, faces, F, colors, NULL, NULL, 0, 0, NULL, poses, Hn, scale, fx, fy, cx, cy, W, Hh, rgb, depth, ambient, 0);
+    fpo_rasterize_tex(verts, V, faces, F, colors, NULL, NULL, 0, 0, NULL, poses, Hn, scale, fx, fy, cx, cy, W, Hh, rgb, depth, ambient, 0, 0);
 }
 
 /* vertex stage alone: fixed-point 24.8 window coordinates (image convention: x right, y down, pixel centres at +0.5) and the
@@ -450,9 +513,12 @@ void fpo_project_vertices(const float* verts, int V, const float* poses, int Hn,
 
 void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors, const float* uv,
                        const uint8_t* tex, int th, int tw, const float* kd3, const float* poses, int Hn, float scale, float fx,
-                       float fy, float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade) {
+                       float fy, float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade, int filter) {
     const float ZNEAR = 0.05f;
     const int textured = uv && tex && th > 0 && tw > 0;
+    int nlev = 0, lw[FPO_MAX_LEV], lh[FPO_MAX_LEV];
+    size_t loff[FPO_MAX_LEV];
+    uint8_t* mips = textured ? build_mips(tex, th, tw, &nlev, loff, lw, lh) : NULL;
     const float kd[3] = {kd3 ? kd3[0] : 1.f, kd3 ? kd3[1] : 1.f, kd3 ? kd3[2] : 1.f};
     shade_tables();
     svert_t* sv = (svert_t*)malloc((size_t)V * sizeof(svert_t));
@@ -530,25 +596,46 @@ void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, c
                     const float q0 = b0 * a.iz, q1 = b1 * b.iz, q2 = b2 * c.iz;
                     if (textured) {
                         const float* t = uv + (size_t)f * 6;
-                        float U = fmaf(q2, t[2 * k2], fmaf(q1, t[2 * k1], q0 * t[2 * k0])) * dd;
-                        float Vv = fmaf(q2, t[2 * k2 + 1], fmaf(q1, t[2 * k1 + 1], q0 * t[2 * k0 + 1])) * dd;
-                        float x = fmaf(U, (float)tw, -0.5f), y = fmaf(1.0f - Vv, (float)th, -0.5f);
-                        x = fminf(fmaxf(x, -1.0e6f), 1.0e6f); y = fminf(fmaxf(y, -1.0e6f), 1.0e6f);
-                        if (!(x == x)) x = 0.f;
-                        if (!(y == y)) y = 0.f;
-                        const float xf = floorf(x), yf = floorf(y);
-                        const float wx = x - xf, wy = y - yf;
-                        const int x0 = wrapi((int)xf, tw), x1 = wrapi((int)xf + 1, tw);
-                        const int y0 = wrapi((int)yf, th), y1 = wrapi((int)yf + 1, th);
+                        const float u0 = t[2 * k0], u1 = t[2 * k1], u2 = t[2 * k2];
+                        const float v0 = t[2 * k0 + 1], v1 = t[2 * k1 + 1], v2 = t[2 * k2 + 1];
+                        const float U = fmaf(q2, u2, fmaf(q1, u1, q0 * u0)) * dd;
+                        const float Vv = fmaf(q2, v2, fmaf(q1, v1, q0 * v0)) * dd;
+                        float val[3];
+                        int l0 = 0, two = 0; float fr = 0.f;
+                        if (filter && nlev > 1) {
+                            /* d(w_i)/d(px) = -256 (y_b - y_a), d(w_i)/d(py) = 256 (x_b - x_a) of the edge opposite corner i */
+                            const float gx0 = (float)(-(int64_t)(c.yi - b.yi) * 256) / fa * a.iz, gy0 = (float)((int64_t)(c.xi - b.xi) * 256) / fa * a.iz;
+                            const float gx1 = (float)(-(int64_t)(a.yi - c.yi) * 256) / fa * b.iz, gy1 = (float)((int64_t)(a.xi - c.xi) * 256) / fa * b.iz;
+                            const float gx2 = (float)(-(int64_t)(b.yi - a.yi) * 256) / fa * c.iz, gy2 = (float)((int64_t)(b.xi - a.xi) * 256) / fa * c.iz;
+                            const float dux = fmaf(gx2, u2 - U, fmaf(gx1, u1 - U, gx0 * (u0 - U))) * dd * (float)tw;
+                            const float dvx = fmaf(gx2, v2 - Vv, fmaf(gx1, v1 - Vv, gx0 * (v0 - Vv))) * dd * (float)th;
+                            const float duy = fmaf(gy2, u2 - U, fmaf(gy1, u1 - U, gy0 * (u0 - U))) * dd * (float)tw;
+                            const float dvy = fmaf(gy2, v2 - Vv, fmaf(gy1, v1 - Vv, gy0 * (v0 - Vv))) * dd * (float)th;
+                            float r2 = fmaxf(fmaf(dux, dux, dvx * dvx), fmaf(duy, duy, dvy * dvy));
+                            if (!(r2 == r2)) r2 = 0.f;
+                            if (r2 > 1.0f) {
+                                uint32_t rb; memcpy(&rb, &r2, 4);
+                                const int e = (int)(rb >> 23) - 127;
+                                uint32_t mb = (rb & 0x7fffffu) | 0x3f800000u; float m; memcpy(&m, &mb, 4);
+                                const float lg = log2p(m - 1.0f);
+                                l0 = e >> 1; fr = 0.5f * ((float)(e & 1) + lg);
+                                if (l0 >= nlev - 1) { l0 = nlev - 1; fr = 0.f; } else two = 1;
+                            }
+                        }
+                        bilinear_level(mips + loff[l0] * 3, lw[l0], lh[l0], U, Vv, val);
+                        if (two) {
+                            float v1l[3];
+                            bilinear_level(mips + loff[l0 + 1] * 3, lw[l0 + 1], lh[l0 + 1], U, Vv, v1l);
+                            for (int ch = 0; ch < 3; ++ch) val[ch] = fmaf(fr, v1l[ch] - val[ch], val[ch]);
+                        }
                         for (int ch = 0; ch < 3; ++ch) {
-                            const uint8_t e00 = tex[((size_t)y0 * tw + x0) * 3 + ch], e01 = tex[((size_t)y0 * tw + x1) * 3 + ch];
-                            const uint8_t e10 = tex[((size_t)y1 * tw + x0) * 3 + ch], e11 = tex[((size_t)y1 * tw + x1) * 3 + ch];
-                            const float t00 = shade ? g_dec[e00] : (float)e00 / 255.f, t01 = shade ? g_dec[e01] : (float)e01 / 255.f;
-                            const float t10 = shade ? g_dec[e10] : (float)e10 / 255.f, t11 = shade ? g_dec[e11] : (float)e11 / 255.f;
-                            const float top = fmaf(wx, t01 - t00, t00), bot = fmaf(wx, t11 - t10, t10);
-                            const float cl = fmaf(wy, bot - top, top) * kd[ch];
-                            if (shade) col[ch] = encode_gamma(ambient * cl);
-                            else { float amb = fminf(ambient * (cl * 255.f) + 0.5f, 255.0f); if (amb < 0.f) amb = 0.f; col[ch] = (uint8_t)amb; }
+                            if (shade) {
+                                int ii = (int)val[ch]; if (ii > 254) ii = 254; if (ii < 0) ii = 0;
+                                const float lin = fmaf(val[ch] - (float)ii, g_dec[ii + 1] - g_dec[ii], g_dec[ii]);
+                                col[ch] = encode_gamma(ambient * (lin * kd[ch]));
+                            } else {
+                                float amb = fminf(ambient * (val[ch] * kd[ch]) + 0.5f, 255.0f); if (amb < 0.f) amb = 0.f; col[ch] = (uint8_t)amb;
+                            }
                         }
                     } else {
                         for (int ch = 0; ch < 3; ++ch) {
@@ -565,7 +652,7 @@ void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, c
                 o[0] = col[0]; o[1] = col[1]; o[2] = col[2];
             }
     }
-    free(sv); free(zb);
+    free(sv); free(zb); free(mips);
 }
 
 

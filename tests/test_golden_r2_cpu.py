@@ -107,6 +107,46 @@ def test_texel_pattern_survives_linear_shading():
     assert np.abs(mid - (0.6 * a + 0.4 * b)).max() <= 1.0
 
 
+def test_mip_levels_and_level_of_detail_known_answers():
+    """Trilinear minification of the textured path (oracle; the device kernels are bit-compared with it in the gpu tests).
+    1-texel checker of 0 / 255: every level >= 1 is the constant 128 ((0+255+0+255+2)>>2).  A fronto-parallel quad that maps n
+    texels onto n/2 pixels has rho = 2, level of detail exactly 1 -> every pixel is 128; mapped onto 4n pixels it is magnified ->
+    level 0, identical to the unfiltered lookup; at rho = sqrt(2) the result is the half-way blend of level 0 and 128."""
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    tex = np.where(((xx + yy) % 2)[..., None] == 0, np.uint8(255), np.uint8(0)).repeat(3, axis=2).astype(np.uint8)
+    v, f, P = _quad(1.0)
+    uv_corner = {0: (0.0, 1.0), 1: (1.0, 1.0), 2: (1.0, 0.0), 3: (0.0, 0.0)}
+    uv = np.array([[uv_corner[i] for i in tri] for tri in f], np.float32)
+
+    def render(px, filt):      # the quad spans px x px pixels of a (px + 8)^2 image
+        W = px + 8
+        return fo.rasterize(v, f, None, P[None], 0.1, px / 0.2, px / 0.2, W / 2, W / 2, W, W, ambient=1.0, shade=0, uv=uv, texture=tex,
+                            filter=filt)
+
+    rgb, d = render(n // 2, 1)
+    cov = d[0] > 0
+    assert cov.sum() == (n // 2) ** 2 and (rgb[0][cov] == 128).all()
+    big1, dm = render(4 * n, 1)
+    big0, _ = render(4 * n, 0)
+    assert np.array_equal(big1, big0) and (dm[0] > 0).sum() == (4 * n) ** 2
+    # rho = sqrt(2): 64 texels on 45.25 px is not integral; use 2 : sqrt(2) via anisotropy-free scaling of the image instead:
+    # 64 texels onto 45 px -> rho = 1.4222, log2 = 0.5082 -> weight of level 1 = 0.5082 (+- the 2e-5 polynomial)
+    rgbh, dh = render(45, 1)
+    lvl0, _ = render(45, 0)
+    covh = dh[0] > 0
+    w = np.log2(64 / 45.0)
+    want = (1 - w) * lvl0[0][covh].astype(np.float64) + w * 128.0
+    assert np.abs(rgbh[0][covh].astype(np.float64) - want).max() <= 1.0
+    # white noise at rho = 4: level 2 averages 16 texels per sample; the level-0 bilinear lookup (pixel centres on texel corners) only 4
+    rng = np.random.Generator(np.random.PCG64(4))
+    tex = rng.integers(0, 256, size=(n, n, 3), dtype=np.uint8)
+    a1, da = render(n // 4, 1)
+    a0, _ = render(n // 4, 0)
+    c = da[0] > 0
+    assert a1[0][c].astype(np.float64).std() < 0.6 * a0[0][c].astype(np.float64).std()      # 16 vs 4 texels per sample
+
+
 def test_gamma_shading_rule_and_material_factor():
     dec, thr = fo.shade_tables()
     assert dec[0] == 0 and abs(dec[255] - 1) < 1e-6 and abs(dec[128] - 0.21586) < 1e-4 and (np.diff(dec) > 0).all()

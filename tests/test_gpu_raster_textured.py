@@ -56,6 +56,38 @@ def test_textured_cube_bit_exact_both_strategies(W, H, shade, ambient, kd):
     assert len(np.unique(rgb_o[cov].reshape(-1, 3), axis=0)) > 500
 
 
+@pytest.mark.parametrize("filt", [1, 0])
+def test_minified_texture_mip_chain_bit_exact(filt):
+    """1024^2 noise-on-checker texture on the cube seen from 0.45 m to 6 m: levels 0 .. 5 of the mip chain are in play (and the
+    far views are a handful of pixels); both visibility strategies against the oracle, trilinear and level-0-only filtering"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    v, f, uv = textured_cube()
+    rng = np.random.Generator(np.random.PCG64(21))
+    tex = (checker_gradient_texture(1024, cells=64, seed=5).astype(np.int32) // 2 + rng.integers(0, 128, size=(1024, 1024, 3))).astype(np.uint8)
+    poses = _poses(6)
+    for i, z in enumerate([0.45, 1.1, 2.0, 3.5, 6.0, 0.8]):
+        poses[i, :3, 3] = [0.02 * i, -0.01 * i, z]
+    rgb_o, d_o = fo.rasterize(v, f, None, poses, 0.25, 600, 600, 210, 210, 420, 420, uv=uv, texture=tex, filter=filt)
+    mesh = ops.Mesh(v, f, uv=uv, texture=tex).set_filter(filt)
+    try:
+        for mode in (1, 0):
+            ops.set_option("raster_tiled", mode)
+            rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(poses), 0.25, 600, 600, 210, 210, 420, 420)
+            assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
+            diff = rgb_g.cpu().numpy() != rgb_o
+            assert not diff.any(), f"rgb differs at {int(diff.sum())} values (tiled={mode}, filter={filt})"
+    finally:
+        ops.set_option("raster_tiled", -1)
+    if filt == 1:   # minification really smooths: the far view's colours vary far less than the unfiltered lookup's
+        rgb_n, _ = fo.rasterize(v, f, None, poses[3:4], 0.25, 600, 600, 210, 210, 420, 420, uv=uv, texture=tex, filter=0)
+        c = d_o[3] > 0
+        assert c.sum() > 500
+        gx1 = np.abs(np.diff(rgb_o[3].astype(np.int32), axis=1))[c[:, 1:] & c[:, :-1]].mean()
+        gx0 = np.abs(np.diff(rgb_n[0].astype(np.int32), axis=1))[c[:, 1:] & c[:, :-1]].mean()
+        assert gx1 < 0.6 * gx0, (gx1, gx0)
+
+
 def test_textured_dense_mesh_and_repeat_wrap_bit_exact():
     """displaced icosphere (20 480 triangles) with spherical uv scaled x3 (REPEAT wrap in play, seam triangles span a period)"""
     from freepose_amd import ops

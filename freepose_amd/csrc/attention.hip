@@ -23,6 +23,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -48,13 +50,25 @@ struct AttnArgs {
 // combine a value with the lane whose id differs in bit 4 (16-lane rows) / bit 5 (32-lane halves): gfx950
 // v_permlane16_swap / v_permlane32_swap are plain VALU instructions (a ds_bpermute round trip costs ~100 cycles of
 // latency on the softmax critical path).  swap(a=v, b=v) leaves {own, partner} in the two results on every lane.
+// raw v_max_f32 / v_max3_f32: fmaxf() makes hipcc canonicalise each operand first (v_max x, x, x — 12 extra VALU instructions
+// per K/V tile in the softmax, and the vector ALU is this kernel's co-bound); logits are never signalling NaNs
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ float xlane_max16(float v) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float xlane_max32(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ int key_plain(int row) { return (row >> 1) & 7; }
 // K tile rows are read in the order 32 (fk>>1) + 8 a + 4 (fk&1) + b (a = li>>2, b = li&3): key follows (a, b>>1)
@@ -111,23 +125,25 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         slotV[it] = (lane & 7) ^ key_perm4(row);
         offV[it] = (uint32_t)row * (uint32_t)p.npad * 2u;
     }
-    // running per-lane source pointers (advanced by one tile per call); only a tile that can reach past the crop's npad
-    // rows takes the clamped path (keys >= n_tok are masked anyway, the clamp just keeps the reads inside the buffers)
-    const char* kp[2];
-    const char* vp[2];
+    // Unclamped tiles go through buffer descriptors: per-lane byte offset fixed for the whole kernel (VGPR), the tile's offset in
+    // the scalar operand — the loop spends no vector ALU instruction on DMA addresses (this kernel is co-bound by VALU issue).
+    // Only a tile that can reach past the crop's npad rows takes the clamped path (keys >= n_tok are masked anyway, the clamp
+    // just keeps the reads inside the buffers).
+    const char* gKb = gQK + rowbase * (size_t)p.ldqk * 2;          // this crop's rows (uniform)
+    uint32_t lofK[2], lofV[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        kp[it] = gQK + (rowbase + rowK[it]) * (size_t)p.ldqk * 2 + offK[it];
-        vp[it] = gVt + offV[it] + (size_t)(slotV[it] * 8) * 2;
+        lofK[it] = (uint32_t)rowK[it] * (uint32_t)p.ldqk * 2u + offK[it];
+        lofV[it] = offV[it] + (uint32_t)(slotV[it] * 16);
     }
-    const size_t kstep = (size_t)KVB * p.ldqk * 2;
+    const uint32_t kstep = (uint32_t)p.ldqk * 2u;                   // bytes per key row
     auto stage = [&](int buf, int kv0) {
         char* sb = smem + buf * STAGE;
         if (kv0 + KVB <= p.npad) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) glds16(kp[it], sb + (it * NWAVE + wave) * 1024);
+            for (int it = 0; it < 2; ++it) glds16_buf(gKb, lofK[it], (uint32_t)kv0 * kstep, sb + (it * NWAVE + wave) * 1024);
 #pragma unroll
-            for (int it = 0; it < 2; ++it) glds16(vp[it], sb + TILE + (it * NWAVE + wave) * 1024);
+            for (int it = 0; it < 2; ++it) glds16_buf(gVt, lofV[it], (uint32_t)kv0 * 2u, sb + TILE + (it * NWAVE + wave) * 1024);
         } else {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -140,8 +156,6 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
                 glds16(gVt + offV[it] + (size_t)k8 * 2, sb + TILE + (it * NWAVE + wave) * 1024);
             }
         }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) { kp[it] += kstep; vp[it] += KVB * 2; }
     };
 
     // ---- fragment read offsets -----------------------------------------------------------------
@@ -188,8 +202,10 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         const int d = (blockIdx.x * 5) % 12;
         for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(2);   // 2 x 64 cycles per step: 0 .. ~1400 cycles
     }
-    int slot = 0;
-    for (int t = 0; t < ntile; ++t) {
+    // one K/V tile; `slot` = its ring slot — a compile-time constant in the 2-slot kernel (the loop below is unrolled by the
+    // ring), so every fragment read address is a loop-invariant lane base plus an immediate
+    auto tile_body = [&](int t, auto slot_c) {
+        const int slot = slot_c;
         // tiles t+1 .. t+PF-1 may stay in flight (4 DMA instructions per tile per wave); near the end fewer are pending
         const int ahead = min(PF - 1, ntile - 1 - t);
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -199,7 +215,6 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         asm volatile("" ::: "memory");
         if (t + PF < ntile) stage(slot >= 1 ? slot - 1 : NSLOT - 1, (t + PF) * KVB);   // slot of tile t-1 = (slot+PF) % NSLOT
         const char* sb = smem + slot * STAGE;
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
         const int kv0 = t * KVB;
 
         // ---- S^T = K Q^T -------------------------------------------------------------------------
@@ -254,16 +269,19 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         //    four lanes' keys at once) in lacc, replacing 16 packed adds and the cross-lane reduction at the end.
         bf16x8_t pf[2][2];  // [fq][ks]  B-operand fragments of P^T
         auto softmax_max = [&](int fq) {
-            float mx = s[0][fq][0];
-#pragma unroll
-            for (int fk = 0; fk < 4; ++fk)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[fk][fq][r]);
+            float mx = vmax3(s[0][fq][0], s[0][fq][1], s[0][fq][2]);
+            mx = vmax3(mx, s[0][fq][3], s[1][fq][0]);
+            mx = vmax3(mx, s[1][fq][1], s[1][fq][2]);
+            mx = vmax3(mx, s[1][fq][3], s[2][fq][0]);
+            mx = vmax3(mx, s[2][fq][1], s[2][fq][2]);
+            mx = vmax3(mx, s[2][fq][3], s[3][fq][0]);
+            mx = vmax3(mx, s[3][fq][1], s[3][fq][2]);
+            mx = vmax2(mx, s[3][fq][3]);
             // the 4 lanes sharing a query differ in lane bits 4 and 5: VALU row/half swaps, not ds_bpermute
             mx = xlane_max16(mx);
             mx = xlane_max32(mx);
             if (__builtin_amdgcn_ballot_w64(mx > mrow[fq] + LAZY_THR) != 0) {   // wave-uniform
-                const float mnew = fmaxf(mrow[fq], mx);
+                const float mnew = vmax2(mrow[fq], mx);
                 // raw v_exp_f32 (results below 2^-126 flush to 0, which is what a masked / negligible weight should be)
                 const float alpha = __builtin_amdgcn_exp2f((mrow[fq] - mnew) * p.scale_log2e);
                 mrow[fq] = mnew;
@@ -328,6 +346,18 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
         pv_half(1);
         if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
+    };
+    if constexpr (NSLOT == 2) {
+        for (int t = 0; t < ntile; t += 2) {
+            tile_body(t, std::integral_constant<int, 0>{});
+            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        int slot = 0;
+        for (int t = 0; t < ntile; ++t) {
+            tile_body(t, slot);
+            slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        }
     }
 
     // ---- normalise and store: lane owns 16 consecutive d (= 16 lg + 4 fd + r) of query li ---------

@@ -136,6 +136,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// the same copy through a buffer descriptor: wave-uniform base, per-lane 32-bit byte offset (VGPR), wave-uniform byte offset
+// (SGPR): a loop that only advances the uniform offset spends no vector ALU work on addresses.  The descriptor type exists only
+// in the device pass, hence the guard (the host pass needs just the declaration to emit the kernel stubs).
+__device__ __forceinline__ void glds16_buf(const void* base, unsigned lane_off, unsigned wave_off, void* lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, lane_off, wave_off, 0, 0);
+#else
+    (void)base; (void)lane_off; (void)wave_off; (void)lds_wave_base;
+#endif
+}
+
 // ---- host-side error plumbing (C-ABI: int status + fp_last_error()) --------------------------
 #ifdef __cplusplus
 extern "C" const char* fp_last_error(void);

@@ -50,16 +50,11 @@ struct AttnArgs {
 // combine a value with the lane whose id differs in bit 4 (16-lane rows) / bit 5 (32-lane halves): gfx950
 // v_permlane16_swap / v_permlane32_swap are plain VALU instructions (a ds_bpermute round trip costs ~100 cycles of
 // latency on the softmax critical path).  swap(a=v, b=v) leaves {own, partner} in the two results on every lane.
-// raw v_max_f32 / v_max3_f32: fmaxf() makes hipcc canonicalise each operand first (v_max x, x, x — 12 extra VALU instructions
+// raw v_max_f32 (and v_max3_f32 in softmax_max): fmaxf() makes hipcc canonicalise each operand first (v_max x, x, x — 12 extra VALU instructions
 // per K/V tile in the softmax, and the vector ALU is this kernel's co-bound); logits are never signalling NaNs
 __device__ __forceinline__ float vmax2(float a, float b) {
     float d;
     asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
 __device__ __forceinline__ float xlane_max16(float v) {
@@ -269,14 +264,13 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         //    four lanes' keys at once) in lacc, replacing 16 packed adds and the cross-lane reduction at the end.
         bf16x8_t pf[2][2];  // [fq][ks]  B-operand fragments of P^T
         auto softmax_max = [&](int fq) {
-            float mx = vmax3(s[0][fq][0], s[0][fq][1], s[0][fq][2]);
-            mx = vmax3(mx, s[0][fq][3], s[1][fq][0]);
-            mx = vmax3(mx, s[1][fq][1], s[1][fq][2]);
-            mx = vmax3(mx, s[1][fq][3], s[2][fq][0]);
-            mx = vmax3(mx, s[2][fq][1], s[2][fq][2]);
-            mx = vmax3(mx, s[2][fq][3], s[3][fq][0]);
-            mx = vmax3(mx, s[3][fq][1], s[3][fq][2]);
-            mx = vmax2(mx, s[3][fq][3]);
+            float mx;   // one statement: between separate asm statements hipcc pads every dependent pair with an s_nop
+            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\t"
+                "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
+                : "=&v"(mx)
+                : "v"(s[0][fq][0]), "v"(s[0][fq][1]), "v"(s[0][fq][2]), "v"(s[0][fq][3]), "v"(s[1][fq][0]), "v"(s[1][fq][1]),
+                  "v"(s[1][fq][2]), "v"(s[1][fq][3]), "v"(s[2][fq][0]), "v"(s[2][fq][1]), "v"(s[2][fq][2]), "v"(s[2][fq][3]),
+                  "v"(s[3][fq][0]), "v"(s[3][fq][1]), "v"(s[3][fq][2]), "v"(s[3][fq][3]));
             // the 4 lanes sharing a query differ in lane bits 4 and 5: VALU row/half swaps, not ds_bpermute
             mx = xlane_max16(mx);
             mx = xlane_max32(mx);

@@ -168,6 +168,8 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
 #pragma unroll
         for (int j = 0; j < 2; ++j) o[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float mrow[2] = {-1e30f, -1e30f};
+    float mthr[2] = {-1e30f, -1e30f};   // mrow + LAZY_THR and -mrow * scale, kept beside mrow (they change only on a rescale)
+    float nmb[2] = {0.f, 0.f};
     f32x4_t lacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};   // [0]: running sum of P per query
     bf16x8_t ones;
 #pragma unroll
@@ -271,14 +273,18 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
                 : "v"(s[0][fq][0]), "v"(s[0][fq][1]), "v"(s[0][fq][2]), "v"(s[0][fq][3]), "v"(s[1][fq][0]), "v"(s[1][fq][1]),
                   "v"(s[1][fq][2]), "v"(s[1][fq][3]), "v"(s[2][fq][0]), "v"(s[2][fq][1]), "v"(s[2][fq][2]), "v"(s[2][fq][3]),
                   "v"(s[3][fq][0]), "v"(s[3][fq][1]), "v"(s[3][fq][2]), "v"(s[3][fq][3]));
-            // the 4 lanes sharing a query differ in lane bits 4 and 5: VALU row/half swaps, not ds_bpermute
-            mx = xlane_max16(mx);
-            mx = xlane_max32(mx);
-            if (__builtin_amdgcn_ballot_w64(mx > mrow[fq] + LAZY_THR) != 0) {   // wave-uniform
+            // The lazy test needs no cross-lane work: "some query's row maximum exceeds its reference + LAZY_THR" is the same
+            // predicate as "some LANE's local maximum does" (a row maximum is the maximum of its 4 lanes).  Only the rare
+            // rescale reduces over the 4 lanes sharing a query (lane bits 4 and 5: VALU row/half swaps, not ds_bpermute).
+            if (__builtin_amdgcn_ballot_w64(mx > mthr[fq]) != 0) {   // wave-uniform
+                mx = xlane_max16(mx);
+                mx = xlane_max32(mx);
                 const float mnew = vmax2(mrow[fq], mx);
                 // raw v_exp_f32 (results below 2^-126 flush to 0, which is what a masked / negligible weight should be)
                 const float alpha = __builtin_amdgcn_exp2f((mrow[fq] - mnew) * p.scale_log2e);
                 mrow[fq] = mnew;
+                mthr[fq] = mnew + LAZY_THR;
+                nmb[fq] = -(mnew * p.scale_log2e);
                 lacc[fq][0] *= alpha;
 #pragma unroll
                 for (int fd = 0; fd < 4; ++fd)
@@ -288,8 +294,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         };
         auto softmax_exp = [&](int fq) {
             const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e};
-            const float nmb = -(mrow[fq] * p.scale_log2e);
-            const f32x2_t mb2 = {nmb, nmb};
+            const f32x2_t mb2 = {nmb[fq], nmb[fq]};
             float pv[4][4];
 #pragma unroll
             for (int fk = 0; fk < 4; ++fk)

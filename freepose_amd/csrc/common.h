@@ -177,6 +177,19 @@ void fp_set_error(const char* fmt, ...);
         }                           \
     } while (0)
 
+// Raise a kernel's dynamic-LDS limit once per DEVICE (function attributes are per device; a host may hold one context per GPU in
+// one process).  `seen` is a per-call-site bit mask of the devices already done.
+#define FP_DYN_LDS_ONCE(fn, bytes)                                                                              \
+    do {                                                                                                        \
+        static unsigned long long seen__ = 0ull;                                                                \
+        int dev__ = 0;                                                                                          \
+        FP_HIP(hipGetDevice(&dev__));                                                                           \
+        if (dev__ >= 64 || !((seen__ >> dev__) & 1ull)) {                                                       \
+            FP_HIP(hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+            if (dev__ < 64) seen__ |= 1ull << dev__;                                                            \
+        }                                                                                                       \
+    } while (0)
+
 #define FP_LAUNCH_CHECK()                                                          \
     do {                                                                           \
         hipError_t e__ = hipGetLastError();                                        \

@@ -309,11 +309,7 @@ int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + 2 * STAGE + ((LUT && WM * WN == 16) ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        FP_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-        attr_set = true;
-    }
+    FP_DYN_LDS_ONCE(kern, SMEM);
     int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
     if constexpr ((VAR & 32) != 0) {   // one resident workgroup per CU (128 KiB of LDS each)
         static int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n & ~7; }();

@@ -658,11 +658,7 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
         hipLaunchKernelGGL(raster_bin_kernel, dim3(nchunk, Hn), dim3(BIN_CHUNK), 0, s, sv, mesh->faces, V, F, W, Hh, T, tbox, cmask);
         FP_LAUNCH_CHECK();
         const size_t lds = (size_t)T * T * 8 + 2048;   // visibility keys + DEC/THR tables
-        static bool attr_set = false;
-        if (!attr_set) {
-            FP_HIP(hipFuncSetAttribute((const void*)raster_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 88 * 88 * 8 + 2048));
-            attr_set = true;
-        }
+        FP_DYN_LDS_ONCE(raster_tile_kernel, 88 * 88 * 8 + 2048);
         hipLaunchKernelGGL(raster_tile_kernel, dim3(ntx * nty, Hn), dim3(256), lds, s, sv, mesh->faces, shade_args(mesh), mesh->tables,
                            V, F, W, Hh, T, ntx, tbox, cmask, nchunk, d_rgb, d_depth);
         FP_LAUNCH_CHECK();

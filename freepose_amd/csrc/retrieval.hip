@@ -728,21 +728,13 @@ int fp_topk_select(const uint16_t* keys, int ldk, int N, int Q, int k, int idx_o
     static int env_sel = [] { const char* e = getenv("FP_TOPK_SELECT"); return e ? atoi(e) : 1; }();   // 0: histogram kernels (A/B)
     if (env_sel && N <= SEL_CAP) {   // counting select on register-resident keys (no LDS atomics)
         const size_t lds = (size_t)SEL_CAP * 2;
-        static bool attr_set_r = false;
-        if (!attr_set_r) {
-            FP_HIP(hipFuncSetAttribute((const void*)topk_select_reg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set_r = true;
-        }
+        FP_DYN_LDS_ONCE(topk_select_reg_kernel, 128 * 1024);
         hipLaunchKernelGGL(topk_select_reg_kernel, dim3(Q), dim3(SEL_T), lds, s, keys, ldk, N, k, idx_offset, out_scores, out_idx);
         FP_LAUNCH_CHECK();
         return FP_OK;
     }
     if (key_bytes <= 128 * 1024) {   // the key row fits beside the candidate buffer: all passes from LDS
-        static bool attr_set = false;
-        if (!attr_set) {
-            FP_HIP(hipFuncSetAttribute((const void*)topk_select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set = true;
-        }
+        FP_DYN_LDS_ONCE(topk_select_kernel<true>, 128 * 1024);
         hipLaunchKernelGGL(topk_select_kernel<true>, dim3(Q), dim3(SEL_T), key_bytes, s, keys, ldk, N, k, idx_offset, out_scores, out_idx);
     } else {
         hipLaunchKernelGGL(topk_select_kernel<false>, dim3(Q), dim3(SEL_T), 0, s, keys, ldk, N, k, idx_offset, out_scores, out_idx);

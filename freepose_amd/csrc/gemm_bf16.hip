@@ -55,11 +55,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over waves");
 
     // dynamic LDS: [GELU table, 16 KiB, table-GELU kernels only][K-tile buffer 0][K-tile buffer 1][epilogue slabs, 2 KiB per wave].
-    // The 16-wave 256x256 kernel has no room for table + slabs (16 + 128 + 32 KiB): there the slabs live in the K-tile buffer the
-    // LAST K step consumed (free during the epilogue: the next tile's first stage is prefetched into the other one), behind one
-    // extra barrier per tile.
+    // The table-GELU kernels keep no slab region: the 16-wave 256x256 kernel has no room for table + slabs (16 + 128 + 32 KiB),
+    // and the 4-wave 128x128 kernel would drop from two resident workgroups per CU to one (88 KiB instead of 80).  Their slabs
+    // live in the K-tile buffer the LAST K step consumed (free during the epilogue: the next tile's first stage is prefetched
+    // into the other one), behind one extra barrier per tile.
     constexpr bool LUT = (EPI == FP_EPI_BIAS_GELU) && (VAR & 4) != 0;
-    constexpr bool RELOC = LUT && NW == 16;
+    constexpr bool RELOC = LUT;
     constexpr int TAB = LUT ? fp_gemm::GELU_TAB_BYTES : 0;
     extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
     char* const smem = smem_raw + TAB;                                     // K-tile buffers start here
@@ -306,7 +307,7 @@ template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr bool LUT = (EPI == FP_EPI_BIAS_GELU) && (VAR & 4) != 0;
-    constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + 2 * STAGE + ((LUT && WM * WN == 16) ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
+    constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + 2 * STAGE + (LUT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
     FP_DYN_LDS_ONCE(kern, SMEM);

@@ -91,7 +91,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 // `stg`: this wave's private EPI_STAGE_BYTES slab of LDS (unused by the transposed epilogue).
 //
 // Non-transposed epilogues run in two phases per 16-token x 64-feature block of the wave tile:
-//   phase 1 (accumulator layout: lane = token row li, 16 consecutive features): + bias [, GELU], round to bf16, write the
+//   phase 1 (accumulator layout: lane = token row li, 16 consecutive features; bias already accumulated): [GELU,] round to bf16, write the
 //            lane's 32 B into the slab (row li; 16-B slots XOR-swizzled with (row>>1)&7 like the operand tiles);
 //   phase 2 (row layout: 8 lanes x 16 B = one full 128-B output row, 8 rows per instruction): read back, apply
 //            LayerScale+residual / position embedding with equally coalesced loads, store.
@@ -119,16 +119,11 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
             const int nbw = n0 + wn * (16 * TN) + grp * 64;     // the wave's 64-feature group
             const int nb1 = nbw + lg * 16;                      // phase-1 features of this lane
             const int nb2 = nbw + pslot * 8;                    // phase-2 features of this lane
-            // bias / LayerScale stay packed (bf16 pairs) and are unpacked at use: the 16-wave kernels run at 128 VGPRs
-            uint32_t biasw[8], gamw[4];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) biasw[e] = 0u;
-            if (nb1 < p.N) {
-                const uint4* bp = (const uint4*)(p.bias + nb1);
-                const uint4 b0 = bp[0], b1 = bp[1];
-                biasw[0] = b0.x; biasw[1] = b0.y; biasw[2] = b0.z; biasw[3] = b0.w;
-                biasw[4] = b1.x; biasw[5] = b1.y; biasw[6] = b1.z; biasw[7] = b1.w;
-            }
+            // (the bias is already in the accumulators: the GEMM kernels start them at it, gemm_bf16.hip init_acc; the transposed
+            //  V store below still adds it here)
+            // LayerScale stays packed (bf16 pairs) and is unpacked at use: the 16-wave kernels run at 128 VGPRs
+            uint32_t gamw[4];
+            (void)nb1;
             // LayerScale+residual: the residual rows of block i+1 are requested (row layout, 16 B per lane) before block i
             // is processed, so their HBM latency overlaps a whole block instead of sitting between an LDS read and its store
             uint4 res[2][2];
@@ -156,10 +151,7 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint32_t bw = biasw[2 * j + (r >> 1)];
-                        v[4 * j + r] = acc[i][grp * 4 + j][r] + ((r & 1) ? hi_bf(bw) : lo_bf(bw));
-                    }
+                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][grp * 4 + j][r];
                 u32x4_t w0, w1;                                  // bf16 rounding point of the linear layer (/ GELU) output
                 if constexpr (EPI == FP_EPI_BIAS_GELU && (VAR & 4) != 0) {
                     uint32_t g[8];

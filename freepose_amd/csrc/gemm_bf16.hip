@@ -368,9 +368,14 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     const long rounds_big = (tiles_big + ncu - 1) / ncu;
     const bool filled = tiles_big * 4 >= rounds_big * ncu * 3;          // >= 75 % of the big-tile rounds are real work
     const bool big = tiles_big >= 192 && filled && !(var & 256);        // bit 256 (A/B only): force the 128x128 kernel
+    // A launch that cannot even give every CU one 128x128 tile (a single 518^2 crop: 88 tiles for N = 1024) runs one-wave
+    // 64x64 tiles instead — 4x the workgroups, all CUs busy (bit 2048, A/B only: keep the 128x128 kernel).
+    const long tiles_mid = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    const bool tiny = !big && tiles_mid < ncu && !(var & 2048);
 #define FP_GEMM_CASE(V)                                                          \
     case V: return big ? launch_cfg<256, 256, 2, 4, EPI, V>(a, stream)          \
-                       : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);
+               : tiny ? launch_cfg<64, 64, 1, 1, EPI, V>(a, stream)             \
+                      : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);
     if (big && (var & 8)) {   // experimental: 16-wave workgroup (4 waves/SIMD), 64x64 per wave, non-pipelined reads
         {
             switch (var & (32 | 64)) {   // 32: persistent tile walk, 64: streaming (non-temporal) output stores

@@ -259,10 +259,12 @@ def main():
     from freepose_amd.retrieval import TemplateBank
     import torch.distributed as dist
 
+    # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) and exit with their status
+    parallel.self_launch(args.gpus, [str(Path(__file__).resolve())], sys.argv[1:])
     # FP_DIST_BACKEND=gloo lets several ranks share one GPU (flow test on a single-GPU box); the default is RCCL ("nccl")
     rank, world, local = parallel.init_from_env(os.environ.get("FP_DIST_BACKEND", "nccl"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local % torch.cuda.device_count())
 
     vit = ops.ViT("dinov2_vitl14_reg", seed=0)                         # random-init weights of the real architecture

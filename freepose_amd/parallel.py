@@ -37,6 +37,29 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def self_launch(n_ranks: int, target: Sequence[str], argv: Sequence[str]) -> None:
+    """`python bench.py --gpus N` / `python -m scripts.dino_inference --gpus N` started WITHOUT a launcher: re-exec the same
+    command as N ranks under torch.distributed.run on 127.0.0.1 (one process per GPU, RCCL) and exit with its status.  Returns
+    immediately when n_ranks <= 1 or when this process already is a rank (WORLD_SIZE set by a launcher).  `target` is
+    ["bench.py"] or ["-m", "scripts.dino_inference"].  With fewer visible GPUs than ranks (single-GPU test boxes) the ranks
+    share devices, which RCCL refuses — FP_DIST_BACKEND falls back to gloo unless the caller set it."""
+    if n_ranks <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "FP_DIST_BACKEND" not in env and torch.cuda.is_available() and torch.cuda.device_count() < n_ranks:
+        env["FP_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), *target, *argv]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

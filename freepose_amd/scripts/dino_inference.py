@@ -71,8 +71,12 @@ def run(argv=None):
     ap.add_argument("--save_all_cache", action="store_true")
     ap.add_argument("--n_views", type=int, default=600)                      # not in the reference: views per mesh (600 there)
     ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")        # not in the reference: backbone
+    ap.add_argument("--allow_random_weights", action="store_true")           # not in the reference: run without the checkpoint
+    ap.add_argument("--gpus", type=int, default=1)                           # not in the reference: self-launch N ranks, one per GPU
     args = ap.parse_args(argv)
 
+    import sys
+    parallel.self_launch(args.gpus, ["-m", "scripts.dino_inference"], sys.argv[1:] if argv is None else list(argv))
     rank, world, _ = parallel.init_from_env()
     task = int(os.getenv("SLURM_ARRAY_TASK_ID", 0))
     res_dir = Path("./data/results").resolve() / args.dataset
@@ -84,7 +88,7 @@ def run(argv=None):
     dataset = BOPDataset(f"data/datasets/{args.dataset}/", args.split)
     templates = WebTemplateDataset("data/datasets/objaverse_shards", "data/mesh_cache.csv", bbox_extend=args.bbox_extend,
                                    n_views=args.n_views)
-    extractor = None if args.model == "dinov2_vitl14_reg" else DINOv2FeatureExtractor(args.model)
+    extractor = DINOv2FeatureExtractor(args.model, allow_random_weights=args.allow_random_weights or None)
     model = DinoPoseEstimator(n_poses=args.n_views, cache_size=args.cache_size, save_all=args.save_all_cache,
                               cache_dir=f"./data/cache_{task}_{args.dataset}_r{rank}", feature_extractor=extractor)
     props = json.loads((res_dir / args.proposals).read_text())

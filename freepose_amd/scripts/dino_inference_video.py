@@ -81,7 +81,7 @@ def main(args):
                                    n_views=args.n_views)
     templates.get_template_by_name = functools.lru_cache(maxsize=args.template_cache_size)(templates.get_template_by_name)
     cache_dir = Path("data") / f"cache_{os.environ.get('SLURM_JOB_ID', 0)}_{args.video}_r{rank}"
-    extractor = None if args.model == "dinov2_vitl14_reg" else DINOv2FeatureExtractor(args.model)
+    extractor = DINOv2FeatureExtractor(args.model, allow_random_weights=args.allow_random_weights or None)
     if args.no_rescore:
         model = DinoPoseEstimator(n_poses=args.n_views, cache_size=args.cache_size, save_all=args.save_all_cache,
                                   cache_dir=cache_dir, feature_extractor=extractor)
@@ -157,11 +157,16 @@ def build_parser():
     ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")
     ap.add_argument("--n_fine_poses", type=int, default=20000)
     ap.add_argument("--frame_chunks", action="store_true")
+    ap.add_argument("--allow_random_weights", action="store_true")           # run without the DINOv2 checkpoint (tests, benches)
+    ap.add_argument("--gpus", type=int, default=1)                           # self-launch N ranks, one per GPU (RCCL)
     return ap
 
 
 def run(argv=None):
-    return main(build_parser().parse_args(argv))
+    import sys
+    args = build_parser().parse_args(argv)
+    parallel.self_launch(args.gpus, ["-m", "scripts.dino_inference_video"], sys.argv[1:] if argv is None else list(argv))
+    return main(args)
 
 
 if __name__ == "__main__":

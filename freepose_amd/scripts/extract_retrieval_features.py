@@ -43,7 +43,11 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=128)
     ap.add_argument("--n_views", type=int, default=600)                      # not in the reference: views per mesh (600 there)
     ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")        # not in the reference: backbone
+    ap.add_argument("--allow_random_weights", action="store_true")           # not in the reference: run without the checkpoint
+    ap.add_argument("--gpus", type=int, default=1)                           # not in the reference: self-launch N ranks, one per GPU
     args = ap.parse_args(argv)
+    import sys
+    parallel.self_launch(args.gpus, ["-m", "scripts.extract_retrieval_features"], sys.argv[1:] if argv is None else list(argv))
 
     shards_path = Path("data/datasets").resolve() / args.shards_folder
     features_path = Path("data/datasets").resolve() / f"{args.shards_folder}_{args.feature}_{args.layer}"
@@ -51,7 +55,7 @@ def main(argv=None):
     filelist_path = Path("data").resolve() / args.filelist
 
     rank, world, _ = parallel.init_from_env()
-    model = DINOv2FeatureExtractor(args.model)
+    model = DINOv2FeatureExtractor(args.model, allow_random_weights=args.allow_random_weights or None)
     dataset = WebTemplateDataset(shards_path.as_posix(), filelist_path.as_posix(), crop=False, n_views=args.n_views)
 
     if "SLURM_ARRAY_TASK_ID" in os.environ:

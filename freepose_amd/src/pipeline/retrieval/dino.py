@@ -2,8 +2,8 @@
 
 The reference pulls `facebookresearch/dinov2` through torch.hub (dino.py:10) and runs it with cuBLAS/xformers; here the
 same forward (normalise -> tokens -> first `layer` blocks -> final norm -> cls/reg/patch slice) is one call into
-libfreepose_hip.so (fp_vit_forward): hand-written gfx950 MFMA GEMMs with fused epilogues, LDS-tiled attention, fused
-LayerNorm.  Weights use the official hub state-dict layout, so `dinov2_vitl14_reg4_pretrain.pth` loads unchanged.
+libfreepose_hip.so (fp_vit_forward): hand-written gfx950 MFMA GEMMs with fused epilogues (bias, GELU, LayerScale + residual; LayerNorm folded into the
+consuming GEMM algebraically where the library says so) and LDS-tiled attention.  Weights use the official hub state-dict layout, so `dinov2_vitl14_reg4_pretrain.pth` loads unchanged.
 """
 from __future__ import annotations
 
@@ -41,18 +41,35 @@ class DINOv2FeatureExtractor(torch.nn.Module):
     in nn.Parameters, so `.to(device, dtype)` is a no-op by construction: the model is bf16 on the GPU, like the reference after
     `.to('cuda', dtype=torch.bfloat16)` (pose_estimator.py:21)."""
 
-    def __init__(self, model_name: str = "dinov2_vitl14_reg", state_dict: dict | None = None, seed: int = 0):
+    def __init__(self, model_name: str = "dinov2_vitl14_reg", state_dict: dict | None = None, seed: int | None = None,
+                 allow_random_weights: bool | None = None):
+        """Weights: `state_dict` if given, else the hub checkpoint (FREEPOSE_DINOV2_WEIGHTS file/dir, then torch.hub's
+        checkpoint cache — what dino.py:10's torch.hub.load would have downloaded).  A missing checkpoint is an ERROR
+        (fail closed) unless random weights were asked for: an explicit `seed`, `allow_random_weights=True`
+        (the CLIs' --allow_random_weights) or FREEPOSE_ALLOW_RANDOM_WEIGHTS=1 — benchmarks and tests only."""
         super().__init__()
         self.model_name = model_name
+        self.checkpoint = None
         if state_dict is None:
             ckpt = _find_checkpoint(model_name)
             if ckpt is not None:
                 state_dict = torch.load(ckpt, map_location="cpu")
+                if isinstance(state_dict, dict) and "model" in state_dict and "pos_embed" not in state_dict:
+                    state_dict = state_dict["model"]
+                self.checkpoint = ckpt
             else:
+                if allow_random_weights is None:
+                    allow_random_weights = seed is not None or os.environ.get("FREEPOSE_ALLOW_RANDOM_WEIGHTS", "0") == "1"
+                if not allow_random_weights:
+                    raise FileNotFoundError(
+                        f"DINOv2 checkpoint {_CKPT_NAMES[model_name]} not found: set FREEPOSE_DINOV2_WEIGHTS to the file or its "
+                        f"directory (looked in {os.environ.get('FREEPOSE_DINOV2_WEIGHTS') or '<unset>'} and "
+                        f"{Path(torch.hub.get_dir()) / 'checkpoints'}).  Pass --allow_random_weights / allow_random_weights=True "
+                        "to run on seeded random-init weights of the same architecture (benchmarks and tests only).")
                 warnings.warn(
                     f"no {_CKPT_NAMES[model_name]} found (set FREEPOSE_DINOV2_WEIGHTS); using seeded random-init weights "
                     "with the DINOv2 shapes — features are NOT meaningful for real images", RuntimeWarning)
-        self.model = ops.ViT(model_name, state_dict, seed=seed)
+        self.model = ops.ViT(model_name, state_dict, seed=0 if seed is None else seed)
         self.num_register_tokens = self.model.n_reg
 
     def forward(self, images, layer=22, feature_type="cls"):

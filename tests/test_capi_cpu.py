@@ -93,3 +93,38 @@ def test_cli_flags_match_reference():
     for flag in ("--shards_folder", "--filelist", "--feature", "--layer", "--mesh_per_job", "--batch_size"):
         assert flag in src
     assert d.CSV_COLUMNS == ["scene_id", "im_id", "obj_id", "score", "R", "t", "bbox_visib", "scale", "time"]
+
+
+def test_missing_checkpoint_fails_closed_and_self_launch_command(tmp_path, monkeypatch):
+    """no checkpoint and no explicit request for random weights -> FileNotFoundError before anything touches the GPU
+    (reference: torch.hub.load would have raised, src/pipeline/retrieval/dino.py:10); `--gpus N` without a launcher re-execs
+    under torch.distributed.run on 127.0.0.1."""
+    import subprocess
+    import torch
+    from freepose_amd import parallel
+    from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+    monkeypatch.setenv("FREEPOSE_DINOV2_WEIGHTS", str(tmp_path / "nowhere.pth"))
+    monkeypatch.delenv("FREEPOSE_ALLOW_RANDOM_WEIGHTS", raising=False)
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="allow_random_weights"):
+        DINOv2FeatureExtractor("dinov2_vitl14_reg")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    parallel.self_launch(1, ["bench.py"], ["--gpus", "1"])                     # one rank: no launcher, returns
+    assert not seen
+    with pytest.raises(SystemExit) as e:
+        parallel.self_launch(4, ["bench.py"], ["--gpus", "4", "--steps", "2"])
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["bench.py", "--gpus", "4", "--steps", "2"]
+    monkeypatch.setenv("WORLD_SIZE", "4")                                       # already a rank: never re-launch
+    seen.clear()
+    parallel.self_launch(4, ["bench.py"], [])
+    assert not seen

@@ -51,11 +51,19 @@ def test_c_abi_comm_single_rank():
     assert lib.fp_comm_size(ctx) == 1
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs for the RCCL (nccl backend) path")
-def test_rccl_two_ranks_two_gpus(tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FP_DIST_BACKEND="nccl", FP_COMM_DIR=str(tmp_path))
+def test_rccl_two_ranks(tmp_path):
+    """2 ranks over the `nccl` backend (RCCL) + the C-ABI communicator.  With >= 2 GPUs each rank has its own device; on a
+    single-GPU box both ranks are pointed at GPU 0 — RCCL normally refuses that ("Duplicate GPU detected"), in which case the
+    test is skipped with RCCL's own message; any other failure is a failure."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FP_DIST_BACKEND="nccl", FP_COMM_DIR=str(tmp_path), NCCL_DEBUG="WARN")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29581", str(ROOT / "tests" / "_multirank_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0 and torch.cuda.device_count() < 2:
+        blob = r.stdout + r.stderr
+        refused = [ln.strip() for ln in blob.splitlines() if "Duplicate GPU" in ln or "invalid usage" in ln or "ncclInvalidUsage" in ln]
+        if refused:
+            print("RCCL refused 2 ranks on one device:", refused[0])
+            pytest.skip(f"single-GPU box and RCCL refuses two ranks on one device: {refused[0][:200]}")
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert "MULTIRANK_BANK_OK 2" in r.stdout and "MULTIRANK_CABI_OK 2" in r.stdout

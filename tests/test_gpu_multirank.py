@@ -37,3 +37,17 @@ def test_sharded_bank_topk_two_ranks_on_one_gpu():
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert "MULTIRANK_BANK_OK 2" in r.stdout
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with NO launcher (how the round driver may start it): bench.py re-execs itself as 2 ranks under
+    torch.distributed.run (RCCL when the box has >= 2 GPUs, gloo on a shared device otherwise), rank 0 prints the one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FP_DIST_BACKEND")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--hyp", "24", "--bank", "2000",
+           "--mesh-sub", "3", "--vit-batch", "8", "--video-frames", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["steps"] == 1

@@ -68,3 +68,32 @@ def test_vit_batch_invariance_and_layer_semantics():
     # layer > depth runs every block (dino.py:18-21) == layer == depth
     assert torch.equal(vit(img[:1], layer=12, feature_type="cls"), vit(img[:1], layer=99, feature_type="cls"))
     assert not torch.equal(vit(img[:1], layer=11, feature_type="cls"), vit(img[:1], layer=12, feature_type="cls"))
+
+
+def test_checkpoint_path_hub_layout_fp32_pth(tmp_path, monkeypatch):
+    """dino.py:8-12 loads `dinov2_vitl14_reg4_pretrain.pth` through torch.hub; here the same file is found through
+    FREEPOSE_DINOV2_WEIGHTS (file or directory).  A hub-layout fp32 checkpoint (incl. `mask_token`, which the forward never
+    uses) must give exactly the features of the in-memory load of the same weights; a missing file must fail closed."""
+    from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor, _CKPT_NAMES
+    name = "dinov2_vits14_reg"
+    sd = ops.random_state_dict(name, seed=11)
+    hub = {k: v.float().clone() for k, v in sd.items()}            # the hub files are fp32
+    hub["mask_token"] = torch.zeros(1, 384)
+    ck = tmp_path / _CKPT_NAMES[name]
+    torch.save(hub, ck)
+    x = torch.rand(3, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).cuda()
+    ref = DINOv2FeatureExtractor(name, state_dict=sd)(x, layer=12, feature_type="patch")
+    for env in (str(ck), str(tmp_path)):                            # file and directory forms
+        monkeypatch.setenv("FREEPOSE_DINOV2_WEIGHTS", env)
+        fe = DINOv2FeatureExtractor(name)
+        assert fe.checkpoint == ck
+        got = fe(x, layer=12, feature_type="patch")
+        assert torch.equal(got, ref)
+        assert torch.equal(fe(x, layer=12, feature_type="cls"), DINOv2FeatureExtractor(name, state_dict=sd)(x, layer=12, feature_type="cls"))
+    monkeypatch.setenv("FREEPOSE_DINOV2_WEIGHTS", str(tmp_path / "nowhere"))
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path / "empty_hub"))
+    monkeypatch.delenv("FREEPOSE_ALLOW_RANDOM_WEIGHTS", raising=False)
+    with pytest.raises(FileNotFoundError, match="FREEPOSE_DINOV2_WEIGHTS"):
+        DINOv2FeatureExtractor(name)
+    with pytest.warns(RuntimeWarning):
+        DINOv2FeatureExtractor(name, allow_random_weights=True)

@@ -24,7 +24,7 @@ REPO = ROOT.parent
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+    "--offload-arch=gfx950:sramecc+", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     # gfx950 has one unified VGPR/AGPR file: keep MFMA accumulators in VGPRs so VALU epilogue / softmax-rescale work on
     # them needs no v_accvgpr_read/write round trips (attention: -128 moves per KV tile, occupancy 2 -> 3 waves/SIMD)
     "-mllvm", "-amdgpu-mfma-vgpr-form=1",
@@ -64,7 +64,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> Path:
             list(ex.map(cc, jobs))
     objs = [OBJDIR / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        cmd = [HIPCC, "--offload-arch=gfx950:sramecc+", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

@@ -111,8 +111,9 @@ extern "C" int fp_comm_size(const fp_ctx* ctx) { return ctx && ctx->comm ? ctx->
 extern "C" int fp_comm_rank(const fp_ctx* ctx) { return ctx && ctx->comm ? ctx->comm_rank : 0; }
 
 extern "C" int fp_allgather_bytes(fp_ctx* ctx, const void* d_send, size_t bytes, void* d_recv, void* stream) {
-    FP_REQUIRE(ctx && d_send && d_recv, "allgather_bytes: null argument");
-    if (bytes == 0) return FP_OK;
+    FP_REQUIRE(ctx, "allgather_bytes: null context");
+    if (bytes == 0) return FP_OK;                     // nothing to exchange (every rank passes the same size): pointers may be null
+    FP_REQUIRE(d_send && d_recv, "allgather_bytes: null buffer");
     hipStream_t s = (hipStream_t)stream;
     if (!ctx->comm) {   // single rank: the gather is a copy
         FP_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s));

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     char* epi_stage = smem + 2 * STAGE + wave * fp_gemm::EPI_STAGE_BYTES;   // row-coalescing slab of the epilogue
     if constexpr (LUT) {
+        // gelu_tab16's inline-asm gathers use table-relative byte offsets as absolute LDS addresses
+        if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem_raw != 0u) __builtin_trap();
         for (int o = tid * 16; o < fp_gemm::GELU_TAB_BYTES; o += NW * 64 * 16)
             *(uint4*)(smem_raw + o) = *(const uint4*)((const char*)p.gelu_tab + o);
         __syncthreads();   // (the pipelined loop's raw s_barrier does not wait for LDS writes)

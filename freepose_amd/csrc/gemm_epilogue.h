@@ -52,6 +52,9 @@ __device__ __forceinline__ void gelu_tab16(const float (&v)[16], uint32_t (&out)
     const bool inside = lo >= GELU_WIN_LO && hi < GELU_WIN_HI;
     if (__builtin_amdgcn_ballot_w64(!inside) == 0ull) {
         // every element of the wave's block is inside the window: two indices per VALU op
+        // the gathers address the table at LDS byte 0: the GEMM kernels put it first in their dynamic LDS, have no static LDS,
+        // and TRAP at entry if the table's LDS address is not 0 (gemm_bf16.hip) — adding the base here would cost a VALU add per
+        // address in a loop whose VALU time is paid in full
         uint32_t alo[8], ahi[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -59,11 +62,11 @@ __device__ __forceinline__ void gelu_tab16(const float (&v)[16], uint32_t (&out)
             alo[k] = u & 0xffffu;
             ahi[k] = u >> 16;
         }
-        // the gathers address the table at LDS byte 0 (the GEMM kernels put it first in their dynamic LDS, and have no static LDS)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            // (the device runs with SRAM ECC: a d16 load clears the other half of its destination instead of keeping it, so the
-            // halves of a pair are gathered into two registers — low element zero-extended, high element by d16_hi — and OR-ed)
+            // (with SRAM ECC a d16 load clears the other half of its destination instead of keeping it, so the halves of a pair
+            // are gathered into two registers — low element zero-extended, high element by d16_hi — and OR-ed.  The library is
+            // built for gfx950:sramecc+ only (build.py), so the code object does not load on a device in the other mode.)
             uint32_t r0, r1, r2, r3, q0, q1, q2, q3;
             asm volatile(
                 "ds_read_u16 %0, %8\n\tds_read_u16 %1, %9\n\tds_read_u16 %2, %10\n\tds_read_u16 %3, %11\n\t"

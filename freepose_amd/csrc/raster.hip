@@ -518,10 +518,21 @@ static int mesh_tables(fp_mesh* m) {
     return FP_OK;
 }
 
+extern "C" int fp_mesh_destroy(fp_mesh* m);
+namespace {
+// frees a half-built mesh when an upload step fails (FP_HIP / FP_REQUIRE return early); release() on success
+struct MeshGuard {
+    fp_mesh* m;
+    ~MeshGuard() { if (m) (void)fp_mesh_destroy(m); }
+    fp_mesh* release() { fp_mesh* r = m; m = nullptr; return r; }
+};
+}  // namespace
+
 static int mesh_geometry(fp_ctx* ctx, const float* h_verts, int V, const int32_t* h_faces, int F, fp_mesh** out) {
     FP_REQUIRE(ctx && h_verts && h_faces && out && V > 0 && F > 0, "mesh_upload: bad argument");
     for (int i = 0; i < 3 * F; ++i) FP_REQUIRE(h_faces[i] >= 0 && h_faces[i] < V, "mesh_upload: face index out of range");
     fp_mesh* m = new fp_mesh();
+    MeshGuard guard{m};
     m->ctx = ctx; m->V = V; m->F = F;
     FP_HIP(hipMalloc((void**)&m->verts, (size_t)V * 12));
     FP_HIP(hipMalloc((void**)&m->faces, (size_t)F * 12));
@@ -529,7 +540,7 @@ static int mesh_geometry(fp_ctx* ctx, const float* h_verts, int V, const int32_t
     FP_HIP(hipMemcpy(m->faces, h_faces, (size_t)F * 12, hipMemcpyHostToDevice));
     int rc = mesh_tables(m);
     if (rc) return rc;
-    *out = m;
+    *out = guard.release();
     return FP_OK;
 }
 
@@ -538,13 +549,14 @@ extern "C" int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const in
     fp_mesh* m = nullptr;
     int rc = mesh_geometry(ctx, h_verts, V, h_faces, F, &m);
     if (rc) return rc;
+    MeshGuard guard{m};
     if (h_colors) {
         std::vector<uint8_t> rgba((size_t)V * 4, 255);
         for (int i = 0; i < V; ++i) { rgba[4 * i] = h_colors[3 * i]; rgba[4 * i + 1] = h_colors[3 * i + 1]; rgba[4 * i + 2] = h_colors[3 * i + 2]; }
         FP_HIP(hipMalloc((void**)&m->colors, (size_t)V * 4));
         FP_HIP(hipMemcpy(m->colors, rgba.data(), (size_t)V * 4, hipMemcpyHostToDevice));
     }
-    *out = m;
+    *out = guard.release();
     return FP_OK;
 }
 
@@ -555,6 +567,7 @@ extern "C" int fp_mesh_upload_textured(fp_ctx* ctx, const float* h_verts, int V,
     fp_mesh* m = nullptr;
     int rc = mesh_geometry(ctx, h_verts, V, h_faces, F, &m);
     if (rc) return rc;
+    MeshGuard guard{m};
     // level 0 + the box-filtered chain down to 1 x 1 (contract in the header), rgba, back to back
     int lw[16], lh[16], n = 0;
     size_t total = 0;
@@ -583,7 +596,7 @@ extern "C" int fp_mesh_upload_textured(fp_ctx* ctx, const float* h_verts, int V,
     FP_HIP(hipMemcpy(m->uv, h_uv, (size_t)F * 24, hipMemcpyHostToDevice));
     m->th = th; m->tw = tw;
     if (h_kd3) { m->kd[0] = h_kd3[0]; m->kd[1] = h_kd3[1]; m->kd[2] = h_kd3[2]; }
-    *out = m;
+    *out = guard.release();
     return FP_OK;
 }
 extern "C" int fp_mesh_destroy(fp_mesh* m) {

@@ -120,25 +120,27 @@ constexpr int KMAX = 1024;
 
 __device__ __forceinline__ int block_excl_scan(int v, int* sh, int& total) {
     // sh: SEL_T ints.  simple Hillis-Steele over waves: wave scan + wave totals
+    // all sums are carried in unsigned arithmetic: callers pack two 16-bit counts into one word, and the upper one reaches
+    // 2^15 and beyond on degenerate rows (46 037 equal keys), which would overflow a signed add
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int x = v;
+    unsigned x = (unsigned)v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(x, off, 64);
+        const unsigned y = (unsigned)__shfl_up((int)x, off, 64);
         if (lane >= off) x += y;
     }
     __syncthreads();
-    if (lane == 63) sh[w] = x;
+    if (lane == 63) sh[w] = (int)x;
     __syncthreads();
-    int base = 0, tot = 0;
+    unsigned base = 0, tot = 0;
     for (int i = 0; i < SEL_T / 64; ++i) {
-        const int t = sh[i];
+        const unsigned t = (unsigned)sh[i];
         if (i < w) base += t;
         tot += t;
     }
-    total = tot;
+    total = (int)tot;
     __syncthreads();
-    return base + x - v;
+    return (int)(base + x - (unsigned)v);
 }
 
 // LDSKEYS: the query's whole key row (N x 2 B; 92 KB for the 46 037-row bank) is staged into LDS once with coalesced loads
@@ -394,8 +396,9 @@ __global__ __launch_bounds__(SEL_T) void topk_select_reg_kernel(const uint16_t* 
         if (i0 + 1 < hi) { cg += k1 > T; ce += k1 == T; }
     }
     int tot;
-    const int both = block_excl_scan(cg | (ce << 16), sh, tot);   // both counts stay below 65 536: one scan carries the two
-    int og = both & 0xffff, oe = both >> 16;
+    // both counts stay below 65 536 (a row holds <= 49 152 keys): one unsigned scan carries the two
+    const unsigned both = (unsigned)block_excl_scan((int)((unsigned)cg | ((unsigned)ce << 16)), sh, tot);
+    int og = (int)(both & 0xffffu), oe = (int)(both >> 16);
 #pragma unroll
     for (int j = 0; j < SEL_W; ++j) {
 #pragma unroll

@@ -80,15 +80,25 @@ class TemplateBank:
             s = ops.rerank_views(self.views, self.view_offsets, i, queries, topk)
         return s, i
 
-    def soft_vote(self, per_frame_queries: List[torch.Tensor], k: int = 100, topk: int = 0, frame_ids: Optional[Sequence[int]] = None):
+    def soft_vote(self, per_frame_queries: List[torch.Tensor], k: int = 100, topk: int = 0, frame_ids: Optional[Sequence[int]] = None,
+                  n_obj: int = 0):
         """video soft-vote (ground_video.py:154-159,186-190): dense [N] score vectors with only each frame's top-k filled,
         mean over frames, per-object arg-max.  per_frame_queries[f] is bf16 [n_obj, D].  With `frame_ids` (the global numbers
         of the frames THIS rank holds) the vote is a collective: sparse lists are all-gathered and every rank reduces them in
         frame order (parallel.soft_vote_reduce) — identical result on all ranks and to a single-rank run.
         Returns (best row per object, its mean score)."""
+        if self.sharded and frame_ids is not None:
+            raise ValueError("soft_vote: a row-sharded bank makes topk() itself a collective over ALL ranks with the SAME queries; "
+                             "it cannot be combined with frame sharding (different queries per rank) — replicate the bank")
         votes = [self.frame_votes(q, k, topk) for q in per_frame_queries]
-        s = torch.stack([v[0] for v in votes])
-        i = torch.stack([v[1] for v in votes])
+        if votes:
+            s = torch.stack([v[0] for v in votes])
+            i = torch.stack([v[1] for v in votes])
+        else:                   # a rank that holds no frame (fewer frames than ranks) still joins the collective, with 0 rows
+            if not n_obj:
+                raise ValueError("soft_vote: a rank without frames must pass n_obj (objects per frame)")
+            s = torch.zeros((0, n_obj, k), dtype=torch.float32, device="cuda")
+            i = torch.zeros((0, n_obj, k), dtype=torch.int32, device="cuda")
         fid = torch.arange(len(votes), dtype=torch.int64) if frame_ids is None else torch.as_tensor(list(frame_ids), dtype=torch.int64)
         if frame_ids is None and parallel.world()[1] > 1:
             raise ValueError("soft_vote under torch.distributed needs frame_ids (which frames this rank holds)")

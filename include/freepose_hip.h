@@ -28,8 +28,11 @@ typedef struct fp_mesh fp_mesh; /* device copy of a triangle mesh for the raster
 const char* fp_last_error(void);
 int fp_version(void);
 /* experiment toggles for A/B measurements; value < 0 restores the default.
- *   "gemm_variant": bit 2 pipelined fragment reads (8-wave kernels), 4 polynomial erf, 8 16-wave 256x256 tile,
- *                   32 persistent tile walk, 64 streaming epilogue I/O, 128 split DMA issue + MFMA priority
+ *   "gemm_variant": bit 1 s_setprio around MFMA blocks (8-wave kernels), 2 pipelined fragment reads (8-wave kernels),
+ *                   4 GELU by LDS table (16 KiB at LDS byte 0; the epilogue slabs move into the last K-tile buffer),
+ *                   8 16-wave 256x256 tile, 32 persistent tile walk, 64 streaming epilogue I/O,
+ *                   128 split DMA issue + MFMA priority, 512 8-tile column strips (A/B only),
+ *                   2048 keep the 128x128 kernel for grids smaller than the CU count (A/B only)
  *                   (default 238 = 2|4|8|32|64|128)
  *   "attn_slots":   LDS ring depth of the attention kernel, 2 (default), 3 or 4
  *   "raster_tiled": unset = LDS-tiled rasteriser for meshes up to 32 768 triangles and images up to 704 px, global

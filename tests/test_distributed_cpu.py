@@ -74,6 +74,17 @@ def _worker(rank, world, port, tmp):
     assert np.array_equal(mean.numpy(), acc)
     assert np.array_equal(best_row.numpy(), acc.argmax(axis=1)) and np.array_equal(best.numpy(), acc.max(axis=1))
 
+    # a clip with fewer frames than ranks: the rank without a frame joins the collective with zero rows (it used to raise in
+    # torch.stack([]) while the other ranks waited in the all-gather)
+    one = [0] if rank == 0 else []
+    br1, b1, m1 = parallel.soft_vote_reduce(torch.from_numpy(np.stack([lists[f][0] for f in one]).reshape(len(one), n_obj, kk)),
+                                            torch.from_numpy(np.stack([lists[f][1] for f in one]).reshape(len(one), n_obj, kk))
+                                            if one else torch.zeros((0, n_obj, kk), dtype=torch.int32),
+                                            torch.tensor(one, dtype=torch.int64), N) if one else \
+        parallel.soft_vote_reduce(torch.zeros((0, n_obj, kk)), torch.zeros((0, n_obj, kk), dtype=torch.int32),
+                                  torch.zeros((0,), dtype=torch.int64), N)
+    assert np.array_equal(m1.numpy(), dense[0]) and np.array_equal(br1.numpy(), dense[0].argmax(axis=1))
+
     # ---- proposal / object sharding: round-robin items, variable rows per rank ---------------------------
     items = parallel.shard_items(7, rank, world)
     assert items == ([0, 2, 4, 6], [1, 3, 5])[rank]

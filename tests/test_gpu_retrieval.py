@@ -51,6 +51,28 @@ def test_topk_tie_heavy_and_offsets():
         assert np.array_equal(s_g.cpu().numpy(), s_o)
 
 
+def test_topk_degenerate_full_bank_of_equal_keys():
+    """46 037 identical rows (and an all-zero query: every score 0, and a NaN query): every key equals the threshold, so the
+    "== T" count of the ordered compaction reaches 46 037 >= 2^15 — the packed (count>, count==) scan must not go negative
+    (round-2 advisor finding).  Canonical order then is index ascending."""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    N, D = 46037, 1024
+    row = _bank(1, D, 61)
+    bank_o = fo.bank_prepare(np.repeat(row, N, axis=0))
+    bank_g = fo.bits_to_torch(bank_o).cuda()
+    qs = fo.l2norm_rows(fo.to_bf16_bits(_bank(2, D, 62)))
+    zero = np.zeros((1, D), dtype=np.uint16)
+    nan = np.full((1, D), 0x7fc0, dtype=np.uint16)
+    q = np.concatenate([qs, zero, nan], axis=0)
+    for k in (1, 100, 1024):
+        s_o, i_o = fo.bank_topk(bank_o, q, k)
+        s_g, i_g = ops.bank_topk(bank_g, fo.bits_to_torch(q), k)
+        assert np.array_equal(i_g.cpu().numpy(), i_o)
+        assert np.array_equal(s_g.cpu().numpy().view(np.uint32), s_o.view(np.uint32))
+        assert np.array_equal(i_o[0], np.arange(k))
+
+
 def test_topk_merge_matches_unsharded():
     """bank-row sharding: per-shard top-k + merge == global top-k"""
     from freepose_amd import ops

@@ -74,6 +74,7 @@ def test_checkpoint_path_hub_layout_fp32_pth(tmp_path, monkeypatch):
     """dino.py:8-12 loads `dinov2_vitl14_reg4_pretrain.pth` through torch.hub; here the same file is found through
     FREEPOSE_DINOV2_WEIGHTS (file or directory).  A hub-layout fp32 checkpoint (incl. `mask_token`, which the forward never
     uses) must give exactly the features of the in-memory load of the same weights; a missing file must fail closed."""
+    from freepose_amd import ops
     from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor, _CKPT_NAMES
     name = "dinov2_vits14_reg"
     sd = ops.random_state_dict(name, seed=11)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "fp_rerank_views": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fp_l2_normalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fp_template_score": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fp_template_score_normed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fp_crop_resize_pad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                    c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "fp_roi_align": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float,

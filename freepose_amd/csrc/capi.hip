@@ -452,7 +452,18 @@ extern "C" int fp_template_score(fp_ctx* ctx, const void* d_tmpl, const void* d_
     float* dots;
     int rc;
     if ((rc = ctx->get("tmpl.dots", (size_t)T * P * 4, (void**)&dots))) return rc;
-    return fp_template_score_launch((const bf16_t*)d_tmpl, (const bf16_t*)d_query, d_weights, dots, d_scores, T, P, D,
+    return fp_template_score_launch((const bf16_t*)d_tmpl, (const bf16_t*)d_query, d_weights, dots, d_scores, T, P, D, 0,
+                                    (hipStream_t)stream);
+}
+
+extern "C" int fp_template_score_normed(fp_ctx* ctx, const void* d_tmpl_normed, const void* d_query, const float* d_weights,
+                                        int T, int P, int D, float* d_scores, void* stream) {
+    FP_REQUIRE(ctx && d_tmpl_normed && d_query && d_scores, "template_score_normed: null argument");
+    if (T == 0) return FP_OK;
+    float* dots;
+    int rc;
+    if ((rc = ctx->get("tmpl.dots", (size_t)T * P * 4, (void**)&dots))) return rc;
+    return fp_template_score_launch((const bf16_t*)d_tmpl_normed, (const bf16_t*)d_query, d_weights, dots, d_scores, T, P, D, 1,
                                     (hipStream_t)stream);
 }
 

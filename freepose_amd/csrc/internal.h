@@ -44,4 +44,4 @@ int fp_topk_merge_launch(const float* cs, const int* ci, int Q, int C, int k, fl
 int fp_rerank_views_launch(const bf16_t* views, const int* offsets, const int* cand, const bf16_t* queries, float* out,
                            int Q, int C, int D, int k, hipStream_t s);
 int fp_template_score_launch(const bf16_t* tmpl, const bf16_t* qn, const float* weights, float* dots, float* scores,
-                             int T, int P, int D, hipStream_t s);
+                             int T, int P, int D, int templates_normalised, hipStream_t s);

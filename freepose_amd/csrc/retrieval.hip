@@ -561,6 +561,72 @@ __global__ __launch_bounds__(256) void template_dots_kernel(const bf16_t* __rest
     }
 }
 
+// Pre-normalised template store: the reference normalises the cached [T,P,D] tensor on every call
+// (pose_estimator.py:85-88); F.normalize of a bf16 tensor IS a bf16 tensor, so storing tn once (fp_l2_normalize when the
+// features enter the cache) is bit-identical to the reference's intermediate, and the scorer becomes a streaming dot:
+//   d[t,p] = bf16( tn[t,p,:] . qn[p,:] )   in the canonical dot64 order (same chain as template_dots_kernel).
+// A wave owns ONE patch index p and walks templates t = t0, t0 + TS, ...: its query row stays unpacked in registers (no
+// second load stream), template rows (2 KB, full lines) are requested two ahead of the one being reduced.
+template <int NCH>
+__global__ __launch_bounds__(256) void template_dots_normed_kernel(const bf16_t* __restrict__ tn, const bf16_t* __restrict__ qn,
+                                                                   float* __restrict__ dots, int T, int P, int D, int TS) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int pidx = wave / TS, t0 = wave % TS;
+    if (pidx >= P) return;
+    float qq[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int base = (c * 64 + lane) * 8;
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (base < D) b = *(const uint4*)(qn + (size_t)pidx * D + base);
+        const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qq[c][2 * e] = lo_bf(bw[e]); qq[c][2 * e + 1] = hi_bf(bw[e]); }
+    }
+    const size_t tstride = (size_t)P * D;
+    const bf16_t* row = tn + (size_t)pidx * D;
+    auto fetch = [&](int t, uint4 (&dst)[NCH]) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int base = (c * 64 + lane) * 8;
+            dst[c] = make_uint4(0, 0, 0, 0);
+            if (base < D && t < T) {
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+                const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)(row + (size_t)t * tstride + base));
+                dst[c] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+    };
+    auto reduce = [&](const uint4 (&src)[NCH], int t) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t aw[4] = {src[c].x, src[c].y, src[c].z, src[c].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = __fmaf_rn(lo_bf(aw[e]), qq[c][2 * e], acc);
+                acc = __fmaf_rn(hi_bf(aw[e]), qq[c][2 * e + 1], acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) dots[(size_t)t * P + pidx] = rbf(acc);
+    };
+    uint4 a0[NCH], a1[NCH], a2[NCH];
+    fetch(t0, a0);
+    fetch(t0 + TS, a1);
+    for (int t = t0; t < T; t += 3 * TS) {          // three register buffers in rotation: two rows always in flight
+        fetch(t + 2 * TS, a2);
+        reduce(a0, t);
+        if (t + TS >= T) break;
+        fetch(t + 3 * TS, a0);
+        reduce(a1, t + TS);
+        if (t + 2 * TS >= T) break;
+        fetch(t + 4 * TS, a1);
+        reduce(a2, t + 2 * TS);
+    }
+}
+
 __global__ __launch_bounds__(64) void template_mean_kernel(const float* __restrict__ dots,
                                                            const float* __restrict__ weights,
                                                            float* __restrict__ scores, int T, int P) {
@@ -759,9 +825,22 @@ int fp_topk_merge_launch(const float* cs, const int* ci, int Q, int C, int k, fl
 
 // dots: workspace [T*P] f32
 int fp_template_score_launch(const bf16_t* tmpl, const bf16_t* qn, const float* weights, float* dots, float* scores, int T,
-                      int P, int D, hipStream_t s) {
+                      int P, int D, int templates_normalised, hipStream_t s) {
     FP_REQUIRE(T > 0 && P > 0 && D % 8 == 0 && D <= 1536, "template_score: bad shape");
     const long rows = (long)T * P;
+    if (templates_normalised) {
+        // ~16 waves per CU in flight: TS template slices per patch index
+        const int TS = std::max(1, std::min(T, cdiv(256 * 16, P)));
+        const int nblk = cdiv(P * TS, 4);
+        const int nchn = cdiv(D, 512);
+        if (nchn == 1) hipLaunchKernelGGL(template_dots_normed_kernel<1>, dim3(nblk), dim3(256), 0, s, tmpl, qn, dots, T, P, D, TS);
+        else if (nchn == 2) hipLaunchKernelGGL(template_dots_normed_kernel<2>, dim3(nblk), dim3(256), 0, s, tmpl, qn, dots, T, P, D, TS);
+        else hipLaunchKernelGGL(template_dots_normed_kernel<3>, dim3(nblk), dim3(256), 0, s, tmpl, qn, dots, T, P, D, TS);
+        FP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(template_mean_kernel, dim3(T), dim3(64), 0, s, dots, weights, scores, T, P);
+        FP_LAUNCH_CHECK();
+        return FP_OK;
+    }
     const int blocks = (int)std::min<long>((rows + 3) / 4, 256 * 16);
     const int nch = cdiv(D, 512);
     if (nch == 1) hipLaunchKernelGGL(template_dots_kernel<1>, dim3(blocks), dim3(256), 0, s, tmpl, qn, dots, T, P, D);

@@ -177,12 +177,13 @@ def ffa(feats: torch.Tensor, masks: torch.Tensor, cell: int = 14, normalize: boo
     return of if out_f32 else ob
 
 
-def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+def l2_normalize(x: torch.Tensor, inplace: bool = False) -> torch.Tensor:
+    """F.normalize(x, dim=-1) with the reference's bf16 rounding points; `inplace` overwrites a contiguous bf16 device tensor"""
     lib = _lib.load()
     xb = _dev(x, torch.bfloat16)
     D = xb.shape[-1]
     rows = xb.numel() // D
-    y = torch.empty_like(xb)
+    y = xb if inplace else torch.empty_like(xb)
     if rows:
         check(lib.fp_l2_normalize(context(), ptr(xb), rows, D, ptr(y), current_stream()), "fp_l2_normalize")
     return y
@@ -240,8 +241,10 @@ def rerank_views(views_bf16: torch.Tensor, offsets: torch.Tensor, cand_idx: torc
     return out
 
 
-def template_score(tmpl: torch.Tensor, query: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """tmpl bf16 [T,P,D] raw, query bf16 [P,D] used as given -> scores f32 [T] (bf16-valued unless weighted)."""
+def template_score(tmpl: torch.Tensor, query: torch.Tensor, weights: Optional[torch.Tensor] = None,
+                   normalized: bool = False) -> torch.Tensor:
+    """tmpl bf16 [T,P,D] raw — or, with normalized=True, already l2_normalize()d rows (the pre-normalised feature store; same
+    bits out, one streaming pass) —, query bf16 [P,D] used as given -> scores f32 [T] (bf16-valued unless weighted)."""
     lib = _lib.load()
     t = _dev(tmpl, torch.bfloat16)
     q = _dev(query, torch.bfloat16).reshape(-1, t.shape[-1])
@@ -250,8 +253,8 @@ def template_score(tmpl: torch.Tensor, query: torch.Tensor, weights: Optional[to
     w = _dev(weights, torch.float32) if weights is not None else None
     out = torch.empty((T,), dtype=torch.float32, device=t.device)
     if T:
-        check(lib.fp_template_score(context(), ptr(t), ptr(q), ptr(w), T, Pn, D, ptr(out), current_stream()),
-              "fp_template_score")
+        fn = lib.fp_template_score_normed if normalized else lib.fp_template_score
+        check(fn(context(), ptr(t), ptr(q), ptr(w), T, Pn, D, ptr(out), current_stream()), "fp_template_score")
     return out
 
 

@@ -33,7 +33,9 @@ class DinoPoseEstimator(torch.nn.Module):
         super().__init__()
         self.feature_extractor = feature_extractor if feature_extractor is not None else DINOv2FeatureExtractor()
         self.mesh_poses = self.generate_poses(n_poses)
-        self.feature_cache = OrderedDict()   # model_name -> bf16 [T,P,D] on the device
+        # model_name -> bf16 [T,P,D] on the device, rows already F.normalize()d (the reference re-normalises the cached tensor on
+        # every call, :85; the normalised bf16 tensor is the same bits every time, so it is stored once — SURVEY §8 f-1)
+        self.feature_cache = OrderedDict()
         self.cache_size = cache_size
         self.save_all = save_all
         self.cache_dir = Path(cache_dir)
@@ -45,16 +47,20 @@ class DinoPoseEstimator(torch.nn.Module):
         return torch.cat(feats, dim=0)
 
     def _cache_features(self, key, features):
-        self.feature_cache[key] = features
-        self.feature_cache.move_to_end(key)
+        """`features`: RAW bf16 [T,P,D] (what the reference caches and writes to <key>.pth).  The on-disk file keeps the reference's
+        raw format; the device store holds the rows normalised in place (no second 1.1 GB tensor)."""
         if self.save_all:
             path = self.cache_dir / f"{key}.pth"
             if not path.exists():
                 torch.save(features.cpu(), path)
+        features = ops.l2_normalize(features, inplace=True)
+        self.feature_cache[key] = features
+        self.feature_cache.move_to_end(key)
         while len(self.feature_cache) > self.cache_size:
             self.feature_cache.popitem(last=False)
 
     def _get_template_features(self, template_dict, layer=22, batch_size=128):
+        """pre-normalised features of the mesh's templates (device store -> <name>.pth -> ViT)"""
         name = template_dict["model_name"]
         if name in self.feature_cache:
             self.feature_cache.move_to_end(name)
@@ -65,7 +71,7 @@ class DinoPoseEstimator(torch.nn.Module):
         else:
             feats = self._extract_features(template_dict["templates"], layer=layer, batch_size=batch_size)
         self._cache_features(name, feats)
-        return feats
+        return self.feature_cache[name] if name in self.feature_cache else ops.l2_normalize(feats)
 
     def __del__(self):
         try:
@@ -74,12 +80,13 @@ class DinoPoseEstimator(torch.nn.Module):
         except Exception:
             pass
 
-    def score_templates(self, feats_template, query_feat, normalize_query=True):
-        """[T] fp32 (bf16-valued) mean patch cosine of every template against the query."""
+    def score_templates(self, feats_template, query_feat, normalize_query=True, templates_normalized=False):
+        """[T] fp32 (bf16-valued) mean patch cosine of every template against the query.  `templates_normalized`: the rows of
+        feats_template are already F.normalize()d (the device store) -> streaming dot, same bits."""
         q = query_feat.reshape(-1, query_feat.shape[-1])
         if normalize_query:
             q = ops.l2_normalize(q)
-        return ops.template_score(feats_template, q)
+        return ops.template_score(feats_template, q, normalized=templates_normalized)
 
     def forward(self, proposal, template_dict, K, bbox, est_scale, layer=22, batch_size=128, return_query_feat=False,
                 query_feat=None):
@@ -91,7 +98,7 @@ class DinoPoseEstimator(torch.nn.Module):
             feats_template = self._extract_features(template_dict["templates"], layer=layer, batch_size=batch_size)
         if query_feat is None:
             query_feat = self.feature_extractor(proposal[None], layer=layer, feature_type="patch")
-        scores = self.score_templates(feats_template, query_feat)
+        scores = self.score_templates(feats_template, query_feat, templates_normalized=self.cache_size > 0)
         T = scores.shape[0]
         idx_all = torch.arange(T, dtype=torch.int32, device=scores.device)
         top_scores, top_indices = ops.topk_merge(scores[None], idx_all[None], min(3, T))

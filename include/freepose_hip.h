@@ -105,6 +105,12 @@ int fp_l2_normalize(fp_ctx* ctx, const void* d_x_bf16, int rows, int D, void* d_
  * NULL (mask_scores variant).  d_scores f32 [T]. */
 int fp_template_score(fp_ctx* ctx, const void* d_tmpl, const void* d_query, const float* d_weights, int T, int P,
                       int D, float* d_scores, void* stream);
+/* The same score for a PRE-NORMALISED template store: d_tmpl_normed = fp_l2_normalize of the raw [T*P, D]
+ * features, done once when they enter the cache.  F.normalize of a bf16 tensor is a bf16 tensor, so this is the reference's
+ * own intermediate (pose_estimator.py:85) and the scores are bit-identical to fp_template_score on the raw features; the
+ * kernel is a streaming dot (one pass over T*P*D*2 bytes). */
+int fp_template_score_normed(fp_ctx* ctx, const void* d_tmpl_normed, const void* d_query, const float* d_weights, int T,
+                             int P, int D, float* d_scores, void* stream);
 
 /* ---- a5: CropResizePad (src/utils/bbox_utils.py:20-56) as used by Proposals (src/pipeline/utils.py:32-52)
  * and MeshRenderer.generate_proposals (renderer.py:109-130) -------------------------------------------- */

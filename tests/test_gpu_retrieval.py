@@ -153,6 +153,14 @@ def test_template_score_bit_exact(T, P, D):
     sw_g = ops.template_score(fo.bits_to_torch(tm[:T_o]), fo.bits_to_torch(q), torch.from_numpy(w)).cpu().numpy()
     sw_o = fo.template_score(tm[:T_o], q, w)
     assert np.array_equal(sw_g.view(np.uint32), sw_o.view(np.uint32))
+    # pre-normalised store: normalise the rows ONCE (in place), then the streaming-dot scorer — the same bits
+    # as the on-the-fly scorer on ALL T templates, and as the oracle (which normalises per call like pose_estimator.py:85)
+    tn = ops.l2_normalize(fo.bits_to_torch(tm).cuda().clone(), inplace=True)
+    assert np.array_equal(fo.torch_to_bits(tn[:T_o].cpu()).reshape(-1, D), fo.l2norm_rows(tm[:T_o].reshape(-1, D)))
+    s_n = ops.template_score(tn, fo.bits_to_torch(q), normalized=True).cpu().numpy()
+    assert np.array_equal(s_n.view(np.uint32), s_g.view(np.uint32))
+    sw_n = ops.template_score(tn[:T_o], fo.bits_to_torch(q), torch.from_numpy(w), normalized=True).cpu().numpy()
+    assert np.array_equal(sw_n.view(np.uint32), sw_o.view(np.uint32))
 
 
 def test_crop_resize_pad_bit_exact():

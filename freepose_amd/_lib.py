@@ -75,6 +75,10 @@ SIGNATURES = {
                            c_int, c_int, c_int, c_void_p]),
     "fp_op_gemm_vt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                               c_void_p]),
+    "fp_op_ln_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_int,
+                                c_int, c_void_p, c_void_p]),
+    "fp_op_gemm_stats": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_float, c_void_p, c_void_p]),
     "fp_op_attention": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fp_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "fp_timer_create": (c_int, [P(c_void_p)]),

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <cmath>
 
@@ -26,6 +27,7 @@ extern "C" int fp_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_variant")) g_opts[FP_OPT_GEMM_VARIANT] = value;
     else if (!strcmp(name, "attn_slots")) g_opts[FP_OPT_ATTN_SLOTS] = value;
     else if (!strcmp(name, "raster_tiled")) g_opts[FP_OPT_RASTER_TILED] = value;
+    else if (!strcmp(name, "ln_fused")) g_opts[FP_OPT_LN_FUSED] = value;
     else { fp_set_error("set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
     return FP_OK;
 }
@@ -98,6 +100,11 @@ struct fp_vit {
     bf16_t* pe_w = nullptr;  // [dim, KP] private padded copy
     bf16_t* ones = nullptr;  // LayerScale gamma = 1 for checkpoints without ls*
     std::vector<VitBlockW> blk;
+    // LayerNorm folded into the consuming GEMMs (gemm_bf16.h FP_EPI_LN_*): per block W' = W diag(gamma_ln) for qkv / fc1 and the
+    // (colsum(W'), b') pairs, built on the device the first time a forward runs after the weights changed
+    struct VitFold { bf16_t *qkvw = nullptr, *fc1w = nullptr; float2 *qkv_cb = nullptr, *fc1_cb = nullptr; };
+    std::vector<VitFold> fold;
+    bool folded = false;
     // pos-embed cache per (gh,gw)
     std::map<std::pair<int, int>, bf16_t*> pos_cache;
     // profiling
@@ -119,6 +126,7 @@ extern "C" int fp_vit_create(fp_ctx* ctx, const fp_vit_arch* arch, fp_vit** out)
     v->ctx = ctx;
     v->a = *arch;
     v->blk.resize(arch->depth);
+    v->fold.resize(arch->depth);
     v->KP = cdiv(3 * arch->patch * arch->patch, 64) * 64;
     if (hipMalloc((void**)&v->pe_w, (size_t)arch->dim * v->KP * 2) != hipSuccess ||
         hipMalloc((void**)&v->ones, (size_t)arch->dim * 2) != hipSuccess) {
@@ -137,6 +145,12 @@ extern "C" int fp_vit_destroy(fp_vit* v) {
     if (v->pe_w) (void)hipFree(v->pe_w);
     if (v->ones) (void)hipFree(v->ones);
     for (auto& kv : v->pos_cache) (void)hipFree(kv.second);
+    for (auto& f : v->fold) {
+        if (f.qkvw) (void)hipFree(f.qkvw);
+        if (f.fc1w) (void)hipFree(f.fc1w);
+        if (f.qkv_cb) (void)hipFree(f.qkv_cb);
+        if (f.fc1_cb) (void)hipFree(f.fc1_cb);
+    }
     for (auto& p : v->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete v;
     return FP_OK;
@@ -147,6 +161,7 @@ extern "C" int fp_vit_set_weight(fp_vit* v, const char* name, const void* d, siz
     const fp_vit_arch& a = v->a;
     const bf16_t* p = (const bf16_t*)d;
     const size_t D = a.dim;
+    v->folded = false;   // any new tensor invalidates the folded LayerNorm weights
     auto need = [&](size_t n) -> bool {
         if (numel != n) { fp_set_error("vit_set_weight: %s has %zu elements, expected %zu", name, numel, n); return false; }
         return true;
@@ -208,6 +223,24 @@ static int vit_pos(fp_vit* v, int gh, int gw, hipStream_t s, const bf16_t** out)
     return FP_OK;
 }
 
+// W' = W diag(gamma_ln), (colsum, b') for the qkv and fc1 layers of the first L blocks (device kernels on `s`, once per weight load)
+static int vit_fold(fp_vit* v, int L, hipStream_t s) {
+    const fp_vit_arch& a = v->a;
+    const size_t D = a.dim, Mm = a.mlp_dim;
+    for (int i = 0; i < L; ++i) {
+        const VitBlockW& w = v->blk[i];
+        fp_vit::VitFold& f = v->fold[i];
+        if (!f.qkvw) FP_HIP(hipMalloc((void**)&f.qkvw, 3 * D * D * 2));
+        if (!f.qkv_cb) FP_HIP(hipMalloc((void**)&f.qkv_cb, 3 * D * sizeof(float2)));
+        if (!f.fc1w) FP_HIP(hipMalloc((void**)&f.fc1w, Mm * D * 2));
+        if (!f.fc1_cb) FP_HIP(hipMalloc((void**)&f.fc1_cb, Mm * sizeof(float2)));
+        int rc;
+        if ((rc = fp_ln_fold(w.qkvw, w.n1w, w.n1b, w.qkvb, f.qkvw, f.qkv_cb, (int)(3 * D), (int)D, s))) return rc;
+        if ((rc = fp_ln_fold(w.fc1w, w.n2w, w.n2b, w.fc1b, f.fc1w, f.fc1_cb, (int)Mm, (int)D, s))) return rc;
+    }
+    return FP_OK;
+}
+
 extern "C" double fp_vit_flops(const fp_vit* v, int B, int H, int W, int layer) {
     const fp_vit_arch& a = v->a;
     const double P = (double)(H / a.patch) * (W / a.patch), N = P + 1 + a.n_reg, D = a.dim;
@@ -265,6 +298,20 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
 
     bf16_t *A0, *X, *Y, *QK, *Vt, *AO, *H1;
     int rc;
+    // LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs (default; fp_set_option("ln_fused", 0) runs the separate kernel for A/B)
+    static const int ln_env = [] { const char* e = getenv("FP_LN_FUSED"); return e ? atoi(e) : 1; }();
+    const bool lnf = fp_opt_get(FP_OPT_LN_FUSED, ln_env) != 0 && D % 64 == 0;
+    float2 *stat = nullptr, *part = nullptr;
+    float* rstd = nullptr;
+    if (lnf) {
+        if (!v->folded) {
+            if ((rc = vit_fold(v, a.depth, s))) return rc;
+            v->folded = true;
+        }
+        if ((rc = v->ctx->get("vit.ln_stat", M * sizeof(float2), (void**)&stat))) return rc;
+        if ((rc = v->ctx->get("vit.ln_rstd", M * sizeof(float), (void**)&rstd))) return rc;
+        if ((rc = v->ctx->get("vit.ln_part", M * (size_t)(D / 64) * sizeof(float2), (void**)&part))) return rc;
+    }
     if ((rc = v->ctx->get("vit.im2col", (size_t)B * P * v->KP * 2, (void**)&A0))) return rc;
     if ((rc = v->ctx->get("vit.x", M * D * 2, (void**)&X))) return rc;
     if ((rc = v->ctx->get("vit.y", M * D * 2, (void**)&Y))) return rc;
@@ -294,20 +341,25 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
     const double Malg = (double)B * n_tok;  // algorithmic rows (pad rows are overhead, not counted as work)
     for (int i = 0; i < L; ++i) {
         const VitBlockW& w = v->blk[i];
+        const fp_vit::VitFold& f = v->fold[i];
+        const bool stats_out = lnf;               // proj feeds LN2 of this block; fc2 feeds LN1 of the next one (not after the last)
         {
             ProfScope ps(v, s, &v->ms_other);
-            if ((rc = fp_layernorm(X, Y, w.n1w, w.n1b, Mi, D, a.ln_eps, 0, 0, 0, s))) return rc;
+            if (!lnf) { if ((rc = fp_layernorm(X, Y, w.n1w, w.n1b, Mi, D, a.ln_eps, 0, 0, 0, s))) return rc; }
+            else if (i == 0) { if ((rc = fp_row_stats(X, stat, rstd, Mi, D, a.ln_eps, s))) return rc; }     // rows from patch-embed + token init
+            else { if ((rc = fp_stats_finalize(part, stat, rstd, Mi, D, a.ln_eps, s))) return rc; }         // partials of the previous fc2
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
             FpGemmArgs g{};
-            g.X = Y; g.ldx = D; g.W = w.qkvw; g.ldw = D; g.C = QK; g.ldc = 2 * D; g.bias = w.qkvb;
-            g.M = Mi; g.N = 2 * D; g.K = D;
-            if ((rc = fp_gemm_bf16(g, FP_EPI_BIAS, s))) return rc;
+            g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.qkvw : w.qkvw; g.ldw = D; g.C = QK; g.ldc = 2 * D; g.bias = w.qkvb;
+            g.M = Mi; g.N = 2 * D; g.K = D; g.ln_ms = stat; g.ln_rstd = rstd; g.ln_cb = f.qkv_cb;
+            if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_BIAS : FP_EPI_BIAS, s))) return rc;
             FpGemmArgs gv{};
-            gv.X = Y; gv.ldx = D; gv.W = w.qkvw + (size_t)2 * D * D; gv.ldw = D; gv.C = Vt; gv.ldc = 8;
+            gv.X = lnf ? X : Y; gv.ldx = D; gv.W = (lnf ? f.qkvw : w.qkvw) + (size_t)2 * D * D; gv.ldw = D; gv.C = Vt; gv.ldc = 8;
             gv.bias = w.qkvb + 2 * D; gv.M = Mi; gv.N = D; gv.K = D; gv.npad = npad; gv.heads = a.heads;
-            if ((rc = fp_gemm_bf16(gv, FP_EPI_VT, s))) return rc;
+            gv.ln_ms = stat; gv.ln_rstd = rstd; gv.ln_cb = lnf ? f.qkv_cb + 2 * D : nullptr;
+            if ((rc = fp_gemm_bf16(gv, lnf ? FP_EPI_LN_VT : FP_EPI_VT, s))) return rc;
             if (v->prof) { v->gemm_flops += 2.0 * Malg * 3.0 * D * D; v->gemm_launches += 2; }
         }
         {
@@ -318,24 +370,25 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
             ProfScope ps(v, s, &v->ms_gemm);
             FpGemmArgs g{};
             g.X = AO; g.ldx = D; g.W = w.projw; g.ldw = D; g.C = X; g.ldc = D; g.bias = w.projb;
-            g.gamma = w.ls1 ? w.ls1 : v->ones; g.resid = X; g.ldr = D; g.M = Mi; g.N = D; g.K = D;
-            if ((rc = fp_gemm_bf16(g, FP_EPI_BIAS_LS_RES, s))) return rc;
+            g.gamma = w.ls1 ? w.ls1 : v->ones; g.resid = X; g.ldr = D; g.M = Mi; g.N = D; g.K = D; g.stat_part = part;
+            if ((rc = fp_gemm_bf16(g, stats_out ? FP_EPI_LS_RES_STATS : FP_EPI_BIAS_LS_RES, s))) return rc;
             if (v->prof) { v->gemm_flops += 2.0 * Malg * (double)D * D; v->gemm_launches += 1; }
         }
         {
             ProfScope ps(v, s, &v->ms_other);
-            if ((rc = fp_layernorm(X, Y, w.n2w, w.n2b, Mi, D, a.ln_eps, 0, 0, 0, s))) return rc;
+            if (!lnf) { if ((rc = fp_layernorm(X, Y, w.n2w, w.n2b, Mi, D, a.ln_eps, 0, 0, 0, s))) return rc; }
+            else { if ((rc = fp_stats_finalize(part, stat, rstd, Mi, D, a.ln_eps, s))) return rc; }
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
             FpGemmArgs g{};
-            g.X = Y; g.ldx = D; g.W = w.fc1w; g.ldw = D; g.C = H1; g.ldc = a.mlp_dim; g.bias = w.fc1b;
-            g.M = Mi; g.N = a.mlp_dim; g.K = D;
-            if ((rc = fp_gemm_bf16(g, FP_EPI_BIAS_GELU, s))) return rc;
+            g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.fc1w : w.fc1w; g.ldw = D; g.C = H1; g.ldc = a.mlp_dim; g.bias = w.fc1b;
+            g.M = Mi; g.N = a.mlp_dim; g.K = D; g.ln_ms = stat; g.ln_rstd = rstd; g.ln_cb = f.fc1_cb;
+            if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_GELU : FP_EPI_BIAS_GELU, s))) return rc;
             FpGemmArgs g2{};
             g2.X = H1; g2.ldx = a.mlp_dim; g2.W = w.fc2w; g2.ldw = a.mlp_dim; g2.C = X; g2.ldc = D; g2.bias = w.fc2b;
-            g2.gamma = w.ls2 ? w.ls2 : v->ones; g2.resid = X; g2.ldr = D; g2.M = Mi; g2.N = D; g2.K = a.mlp_dim;
-            if ((rc = fp_gemm_bf16(g2, FP_EPI_BIAS_LS_RES, s))) return rc;
+            g2.gamma = w.ls2 ? w.ls2 : v->ones; g2.resid = X; g2.ldr = D; g2.M = Mi; g2.N = D; g2.K = a.mlp_dim; g2.stat_part = part;
+            if ((rc = fp_gemm_bf16(g2, (stats_out && i + 1 < L) ? FP_EPI_LS_RES_STATS : FP_EPI_BIAS_LS_RES, s))) return rc;
             if (v->prof) { v->gemm_flops += 4.0 * Malg * (double)D * a.mlp_dim; v->gemm_launches += 2; }
         }
     }
@@ -486,6 +539,51 @@ extern "C" int fp_op_gemm_vt(const void* X, int ldx, const void* W, int ldw, voi
     g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Vt; g.ldc = 8;
     g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads;
     return fp_gemm_bf16(g, FP_EPI_VT, (hipStream_t)stream);
+}
+// LayerNorm folded into a linear layer, as fp_vit_forward runs LN1 -> qkv and LN2 -> fc1 (kernel-level entry for the tests):
+// fold W' / (colsum, b') -> row statistics of X -> the LN-folded GEMM.  mode 0: bias, 1: bias + GELU, 2: transposed V store.
+extern "C" int fp_op_ln_linear(fp_ctx* ctx, const void* X, int M, int K, const void* g_ln, const void* b_ln, float eps,
+                               const void* W, int N, const void* bias, int mode, int npad, int heads, void* out, void* stream) {
+    FP_REQUIRE(ctx && X && g_ln && b_ln && W && bias && out, "op_ln_linear: null argument");
+    FP_REQUIRE(mode >= 0 && mode <= 2, "op_ln_linear: mode %d (0..2)", mode);
+    hipStream_t s = (hipStream_t)stream;
+    bf16_t* Wf;
+    float2 *cb, *stat;
+    float* rstd;
+    int rc;
+    if ((rc = ctx->get("op.ln_wf", (size_t)N * K * 2, (void**)&Wf))) return rc;
+    if ((rc = ctx->get("op.ln_cb", (size_t)N * sizeof(float2), (void**)&cb))) return rc;
+    if ((rc = ctx->get("op.ln_stat", (size_t)M * sizeof(float2), (void**)&stat))) return rc;
+    if ((rc = ctx->get("op.ln_rstd", (size_t)M * sizeof(float), (void**)&rstd))) return rc;
+    if ((rc = fp_ln_fold((const bf16_t*)W, (const bf16_t*)g_ln, (const bf16_t*)b_ln, (const bf16_t*)bias, Wf, cb, N, K, s))) return rc;
+    if ((rc = fp_row_stats((const bf16_t*)X, stat, rstd, M, K, eps, s))) return rc;
+    FpGemmArgs g{};
+    g.X = (const bf16_t*)X; g.ldx = K; g.W = Wf; g.ldw = K; g.C = (bf16_t*)out; g.ldc = mode == 2 ? 8 : N;
+    g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads; g.ln_ms = stat; g.ln_rstd = rstd; g.ln_cb = cb;
+    return fp_gemm_bf16(g, mode == 0 ? FP_EPI_LN_BIAS : (mode == 1 ? FP_EPI_LN_GELU : FP_EPI_LN_VT), s);
+}
+// LayerScale + residual GEMM that also emits the row statistics of its OUTPUT (what the next LN-folded GEMM consumes):
+// d_stat f32 [M,2] = (mean, rstd) of the bf16 rows of C, from the epilogue's per-64-column partial sums.
+extern "C" int fp_op_gemm_stats(fp_ctx* ctx, const void* X, int ldx, const void* W, int ldw, void* Cc, int ldc, const void* bias,
+                                const void* gamma, const void* resid, int ldr, int M, int N, int K, float eps, float* d_stat,
+                                void* stream) {
+    FP_REQUIRE(ctx && X && W && Cc && bias && gamma && resid && d_stat, "op_gemm_stats: null argument");
+    float2 *part, *ms;
+    float* rstd;
+    int rc;
+    if ((rc = ctx->get("op.ln_part", (size_t)M * (N / 64) * sizeof(float2), (void**)&part))) return rc;
+    if ((rc = ctx->get("op.ln_stat", (size_t)M * sizeof(float2), (void**)&ms))) return rc;
+    if ((rc = ctx->get("op.ln_rstd", (size_t)M * sizeof(float), (void**)&rstd))) return rc;
+    FpGemmArgs g{};
+    g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Cc; g.ldc = ldc;
+    g.bias = (const bf16_t*)bias; g.gamma = (const bf16_t*)gamma; g.resid = (const bf16_t*)resid; g.ldr = ldr;
+    g.M = M; g.N = N; g.K = K; g.stat_part = part;
+    if ((rc = fp_gemm_bf16(g, FP_EPI_LS_RES_STATS, (hipStream_t)stream))) return rc;
+    if ((rc = fp_stats_finalize(part, ms, rstd, M, N, eps, (hipStream_t)stream))) return rc;
+    // d_stat [M,2] = (mean, rstd)
+    FP_HIP(hipMemcpy2DAsync(d_stat, 8, ms, 8, 4, M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    FP_HIP(hipMemcpy2DAsync(d_stat + 1, 8, rstd, 4, 4, M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FP_OK;
 }
 extern "C" int fp_op_attention(const void* QK, int ldqk, const void* Vt, void* O, int ldo, int B, int H, int n_tok,
                                int npad, void* stream) {

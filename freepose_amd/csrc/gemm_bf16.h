@@ -9,7 +9,25 @@ enum FpGemmEpi {
     FP_EPI_BIAS_GELU = 1,   // C = gelu_erf(acc + bias)                 (fc1)
     FP_EPI_BIAS_LS_RES = 2, // C = resid + gamma * (acc + bias)         (attn.proj / fc2 + LayerScale + residual)
     FP_EPI_PATCH = 3,       // C[tokrow(m)] = bf16(acc + bias) + pos[p] (patch-embed -> token buffer)
-    FP_EPI_VT = 4           // Vt[b,h,d,t] = acc + bias                 (V part of qkv, stored transposed per head)
+    FP_EPI_VT = 4,          // Vt[b,h,d,t] = acc + bias                 (V part of qkv, stored transposed per head)
+    // ---- LayerNorm folded into the consuming GEMM:  LN(x) W^T + b  =  rstd (x W'^T - mean colsum(W')) + b'
+    // with W' = W diag(gamma_ln) (bf16), colsum over the bf16 W', b' = b + W beta_ln (fp32).  X is the RAW residual stream.
+    // The correction rides in the ACCUMULATOR INIT: acc0[m][n] = b'[n] sigma[m] - mean[m] cs[n] (sigma = 1/rstd), the K loop adds
+    // x W'^T on top in fp32, and the epilogue is one multiply by rstd[m] — no per-feature constants are live in the epilogue.
+    FP_EPI_LN_BIAS = 5,     // C = rstd (acc - mean cs) + b'            (QK part of qkv on the un-normalised x)
+    FP_EPI_LN_GELU = 6,     // C = gelu_erf(bf16(rstd (acc - mean cs) + b'))   (fc1)
+    FP_EPI_LN_VT = 7,       // Vt[b,h,d,t] = rstd (acc - mean cs) + b'  (V part of qkv)
+    // ---- the producer side: LS_RES that also writes, per row and 64-column block, (sum x, sum x^2) of its bf16 OUTPUT rows
+    FP_EPI_LS_RES_STATS = 8 // C = resid + gamma * (acc + bias);  stat_part[n/64][m] = (sum, sum of squares) over the block
+};
+
+template <int EPI>
+struct FpEpiTraits {
+    static constexpr bool LN = EPI == FP_EPI_LN_BIAS || EPI == FP_EPI_LN_GELU || EPI == FP_EPI_LN_VT;
+    static constexpr bool TRANS = EPI == FP_EPI_VT || EPI == FP_EPI_LN_VT;
+    static constexpr bool GELU = EPI == FP_EPI_BIAS_GELU || EPI == FP_EPI_LN_GELU;
+    static constexpr bool LSRES = EPI == FP_EPI_BIAS_LS_RES || EPI == FP_EPI_LS_RES_STATS;
+    static constexpr bool STATS = EPI == FP_EPI_LS_RES_STATS;
 };
 
 struct FpGemmArgs {
@@ -26,6 +44,12 @@ struct FpGemmArgs {
     int heads;
     // FP_EPI_BIAS_GELU: device table of fp_gemm_gelu_table() (filled in by fp_gemm_bf16; callers leave it null)
     const uint16_t* gelu_tab;
+    // FP_EPI_LN_*: per-row (mean, sigma = sqrt(var + eps)) [M] and rstd = 1/sigma [M]; per-feature (colsum(W'), b') [N]; fp32
+    const float2* ln_ms;
+    const float* ln_rstd;
+    const float2* ln_cb;
+    // FP_EPI_LS_RES_STATS: partial row statistics [N/64][M] (sum, sum of squares), N % 64 == 0
+    float2* stat_part;
 };
 
 // Tile order shared by the GEMM kernels.  blockIdx -> logical id (XCD-contiguous, bijective) -> (tile_m, tile_n) in

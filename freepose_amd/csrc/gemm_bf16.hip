@@ -42,7 +42,8 @@ __device__ __forceinline__ int key_perm(int row) {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
-    constexpr bool TRANS = (EPI == FP_EPI_VT);
+    constexpr bool TRANS = FpEpiTraits<EPI>::TRANS;
+    constexpr bool LNF = FpEpiTraits<EPI>::LN;     // LayerNorm folded into this GEMM's epilogue (gemm_bf16.h)
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 16;  // 16-row fragments of X per wave
     constexpr int TN = BN / WN / 16;  // 16-row fragments of W per wave
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     // and the 4-wave 128x128 kernel would drop from two resident workgroups per CU to one (88 KiB instead of 80).  Their slabs
     // live in the K-tile buffer the LAST K step consumed (free during the epilogue: the next tile's first stage is prefetched
     // into the other one), behind one extra barrier per tile.
-    constexpr bool LUT = (EPI == FP_EPI_BIAS_GELU) && (VAR & 4) != 0;
+    constexpr bool LUT = FpEpiTraits<EPI>::GELU && (VAR & 4) != 0;
     constexpr bool RELOC = LUT;
     constexpr int TAB = LUT ? fp_gemm::GELU_TAB_BYTES : 0;
     extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
@@ -164,8 +165,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     // cannot hide under the matrix pipe on gfx950).  Same-box A/B of two builds: qk +0.9 %, proj +2.0 %, fc2 +0.7 %, fc1 0.
     // Layout (gemm_epilogue.h): acc[i][4 grp + j][r] is feature n0 + 64 (wn + grp) + 16 lg + 4 j + r for every row block i.
     f32x4_t acc[TC][TR];
-    auto init_acc = [&](int tn0) {
-        if constexpr (!TRANS) {
+    auto init_acc = [&](int m0_of_init, int tn0) {
+        (void)m0_of_init;
+        if constexpr (!TRANS && !LNF) {
 #pragma unroll
             for (int grp = 0; grp < TR / 4; ++grp) {
                 const int nb1 = tn0 + wn * (16 * TN) + grp * 64 + lg * 16;
@@ -185,6 +187,42 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
                     for (int i = 0; i < TC; ++i) acc[i][grp * 4 + j] = b4;
                 }
             }
+        } else if constexpr (LNF && !TRANS) {
+            // LayerNorm folded into this GEMM: acc0 = b'[n] sigma[m] - mean[m] cs[n]; the epilogue multiplies by rstd[m] (gemm_bf16.h)
+            float2 ms[TC];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) ms[i] = p.ln_ms[min(m0_of_init + wm * (16 * TM) + 16 * i + li, p.M - 1)];
+#pragma unroll
+            for (int grp = 0; grp < TR / 4; ++grp) {
+                const int nb1 = min(tn0 + wn * (16 * TN) + grp * 64 + lg * 16, p.N - 16);
+                const f32x4_t* cp = (const f32x4_t*)(p.ln_cb + nb1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t c0 = cp[2 * j], c1 = cp[2 * j + 1];     // (cs, b') of features 4j, 4j+1 | 4j+2, 4j+3
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) {
+                        const float nm = -ms[i].x, sg = ms[i].y;
+                        acc[i][grp * 4 + j] = f32x4_t{__fmaf_rn(nm, c0[0], c0[1] * sg), __fmaf_rn(nm, c0[2], c0[3] * sg),
+                                                      __fmaf_rn(nm, c1[0], c1[1] * sg), __fmaf_rn(nm, c1[2], c1[3] * sg)};
+                    }
+                }
+            }
+        } else if constexpr (LNF) {
+            // transposed V store: lane = feature 16 i + li (TC blocks), 16 consecutive tokens lg*16 + 4 j + r
+            float2 cb[TC];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) cb[i] = p.ln_cb[min(tn0 + wn * (16 * TN) + 16 * i + li, p.N - 1)];
+            const f32x4_t* mp = (const f32x4_t*)(p.ln_ms + min(m0_of_init + wm * (16 * TM) + lg * 16, p.M - 16));
+#pragma unroll
+            for (int j = 0; j < TR; ++j) {
+                const f32x4_t s0 = mp[2 * j], s1 = mp[2 * j + 1];         // (mean, sigma) of tokens 4j, 4j+1 | 4j+2, 4j+3
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const float ncs = -cb[i].x, bp = cb[i].y;
+                    acc[i][j] = f32x4_t{__fmaf_rn(s0[0], ncs, bp * s0[1]), __fmaf_rn(s0[2], ncs, bp * s0[3]),
+                                        __fmaf_rn(s1[0], ncs, bp * s1[1]), __fmaf_rn(s1[2], ncs, bp * s1[3])};
+                }
+            }
         } else {   // transposed V store: measured slower with the bias in the accumulators (-3.7 %: spills), it adds it in the epilogue
 #pragma unroll
             for (int i = 0; i < TC; ++i)
@@ -192,8 +230,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
                 for (int j = 0; j < TR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto zero_acc = [&]() { init_acc(n0); };   // (name kept: every loop form re-arms the accumulators through it)
-    init_acc(n0);
+    auto zero_acc = [&]() { init_acc(m0, n0); };   // (name kept: every loop form re-arms the accumulators through it)
+    init_acc(m0, n0);
 
     const int nkt = p.K / BK;
     auto load_frags = [&](const char* sb, int kk, bf16x8_t (&fr)[TR], bf16x8_t (&fc)[TC]) {
@@ -335,7 +373,7 @@ __global__ void gelu_table_kernel(uint16_t* tab) {
 template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
-    constexpr bool LUT = (EPI == FP_EPI_BIAS_GELU) && (VAR & 4) != 0;
+    constexpr bool LUT = FpEpiTraits<EPI>::GELU && (VAR & 4) != 0;
     constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + 2 * STAGE + (LUT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
@@ -374,6 +412,11 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // 64x64 tiles instead — 4x the workgroups, all CUs busy (bit 2048, A/B only: keep the 128x128 kernel).
     const long tiles_mid = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const bool tiny = !big && tiles_mid < ncu && !(var & 2048);
+    if constexpr (EPI >= FP_EPI_LN_BIAS) {   // LN-folded / stats epilogues: the default variant of each tile tier only
+        return big ? launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128>(a, stream)
+             : tiny ? launch_cfg<64, 64, 1, 1, EPI, 6>(a, stream)
+                    : launch_cfg<128, 128, 2, 2, EPI, 6>(a, stream);
+    } else {
 #define FP_GEMM_CASE(V)                                                          \
     case V: return big ? launch_cfg<256, 256, 2, 4, EPI, V>(a, stream)          \
                : tiny ? launch_cfg<64, 64, 1, 1, EPI, V>(a, stream)             \
@@ -398,6 +441,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     }
 #undef FP_GEMM_CASE
     return FP_ERR_INVALID;
+    }
 }
 
 }  // namespace
@@ -424,7 +468,7 @@ int fp_gemm_gelu_table(const uint16_t** out) {
 
 int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
     FpGemmArgs a = a_in;
-    if (epi == FP_EPI_BIAS_GELU) {
+    if (epi == FP_EPI_BIAS_GELU || epi == FP_EPI_LN_GELU) {
         const int rc = fp_gemm_gelu_table(&a.gelu_tab);
         if (rc != FP_OK) return rc;
     }
@@ -447,6 +491,18 @@ int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
             FP_REQUIRE(a.npad % 16 == 0 && a.M % 16 == 0 && a.heads > 0 && a.N == a.heads * 64,
                        "gemm: VT epilogue needs npad%%16==0, M%%16==0, N==heads*64");
             return launch_epi<FP_EPI_VT>(a, stream);
+        case FP_EPI_LN_BIAS:
+        case FP_EPI_LN_GELU:
+            FP_REQUIRE(a.ln_ms && a.ln_rstd && a.ln_cb && a.N % 64 == 0 && a.M >= 16, "gemm: LN-folded epilogue needs ln_ms, ln_rstd, ln_cb and N %% 64 == 0");
+            return epi == FP_EPI_LN_BIAS ? launch_epi<FP_EPI_LN_BIAS>(a, stream) : launch_epi<FP_EPI_LN_GELU>(a, stream);
+        case FP_EPI_LN_VT:
+            FP_REQUIRE(a.ln_ms && a.ln_rstd && a.ln_cb, "gemm: LN-folded epilogue needs ln_ms, ln_rstd and ln_cb");
+            FP_REQUIRE(a.npad % 16 == 0 && a.M % 16 == 0 && a.heads > 0 && a.N == a.heads * 64,
+                       "gemm: VT epilogue needs npad%%16==0, M%%16==0, N==heads*64");
+            return launch_epi<FP_EPI_LN_VT>(a, stream);
+        case FP_EPI_LS_RES_STATS:
+            FP_REQUIRE(a.gamma && a.resid && a.stat_part && a.N % 64 == 0, "gemm: LS_RES_STATS epilogue needs gamma, resid, stat_part, N %% 64 == 0");
+            return launch_epi<FP_EPI_LS_RES_STATS>(a, stream);
         default: fp_set_error("gemm: unknown epilogue %d", epi); return FP_ERR_INVALID;
     }
 }

@@ -103,10 +103,25 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 // round dirties the whole L2 and the next round stalls on its eviction — while non-temporal full-line stores bring the
 // bias-only GEMM to the vendor library's epilogue-free time.  From the accumulator layout (16 lines per 16-lane pass)
 // streaming stores would be partial-line writes.
+//
+// LN-folded epilogues (FP_EPI_LN_*, gemm_bf16.h): the kernels start the accumulators at  b'[n] sigma[m] - mean[m] cs[n]  instead of the
+// bias, so after the K loop  acc = x W'^T - mean cs + b' sigma  and phase 1 is ONE multiply by rstd[m] (the lane's token row; one
+// 4-byte load per 16-row block, all requested up front) before the bf16 rounding point.  A first version applied the correction here
+// (2 FMAs per element, the 64 (cs, b') pairs of the wave staged in LDS, relocated slabs in the 16-wave kernel): measured +4.8 % GEMM
+// time (r03), i.e. almost all of the LayerNorm kernel it replaced; the init form needs no per-feature constant in the epilogue.
+// (Carrying rstd from the init to the epilogue through LDS instead of re-loading it was also tried: the 128-VGPR kernels then
+// spill 17-21 registers around the epilogue and run 12 % slower.)
+// FP_EPI_LS_RES_STATS (producer side): phase 2 additionally reduces (sum, sum of squares) of each bf16 OUTPUT row over the wave's
+// 64 columns — v_dot2c_f32_bf16 on the packed pairs, xor-butterfly over the row's 8 lanes, fixed order — and writes them to
+// stat_part[n/64][m].  The partials are per 64-column block whatever the tile shape, so every tile tier produces the same bits.
 template <int BM, int BN, int WM, int WN, int EPI, int VAR, int TC, int TR>
 __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC][TR], int m0, int n0, int wm, int wn,
                                          int li, int lg, char* stg, const char* gelu_tab = nullptr) {
-    constexpr bool TRANS = (EPI == FP_EPI_VT);
+    constexpr bool TRANS = FpEpiTraits<EPI>::TRANS;
+    constexpr bool LNF = FpEpiTraits<EPI>::LN;
+    constexpr bool EGELU = FpEpiTraits<EPI>::GELU;
+    constexpr bool LSRES = FpEpiTraits<EPI>::LSRES;
+    constexpr bool STATS = FpEpiTraits<EPI>::STATS;
     constexpr int TM = BM / WM / 16;
     constexpr int TN = BN / WN / 16;
     if constexpr (!TRANS) {
@@ -139,14 +154,19 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                     r[h] = make_uint4(rv.x, rv.y, rv.z, rv.w);
                 }
             };
-            if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
+            if constexpr (LSRES) {
                 const uint4 g0 = *(const uint4*)(p.gamma + min(nb2, p.N - 8));
                 gamw[0] = g0.x; gamw[1] = g0.y; gamw[2] = g0.z; gamw[3] = g0.w;
                 load_res(0, res[0]);
             }
+            float rs[LNF ? TM : 1];                                // rstd of this lane's row in each 16-row block
+            if constexpr (LNF) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rs[i] = p.ln_rstd[min(mbase + 16 * i + li, p.M - 1)];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
+                if constexpr (LSRES) {
                     if (i + 1 < TM) load_res(i + 1, res[(i + 1) & 1]);
                 }
                 // ---- phase 1 ----------------------------------------------------------------------------------------
@@ -155,14 +175,18 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][grp * 4 + j][r];
+                if constexpr (LNF) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] *= rs[i];
+                }
                 u32x4_t w0, w1;                                  // bf16 rounding point of the linear layer (/ GELU) output
-                if constexpr (EPI == FP_EPI_BIAS_GELU && (VAR & 4) != 0) {
+                if constexpr (EGELU && (VAR & 4) != 0) {
                     uint32_t g[8];
                     gelu_tab16(v, g, gelu_tab);
                     w0 = u32x4_t{g[0], g[1], g[2], g[3]};
                     w1 = u32x4_t{g[4], g[5], g[6], g[7]};
                 } else {
-                    if constexpr (EPI == FP_EPI_BIAS_GELU) {
+                    if constexpr (EGELU) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) v[e] = gelu_erf(rbf(v[e]));
                     }
@@ -183,7 +207,7 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                     if (m >= p.M || nb2 >= p.N) continue;
                     size_t orow = (size_t)m;
                     u32x4_t o = t;
-                    if constexpr (EPI == FP_EPI_BIAS_LS_RES) {
+                    if constexpr (LSRES) {
                         const uint4 rr = res[i & 1][h];
                         const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
                         const uint32_t tw[4] = {t.x, t.y, t.z, t.w};
@@ -193,6 +217,23 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                             ow[e] = pack_bf2(lo_bf(rw[e]) + rbf(lo_bf(gamw[e]) * lo_bf(tw[e])),
                                              hi_bf(rw[e]) + rbf(hi_bf(gamw[e]) * hi_bf(tw[e])));
                         o = u32x4_t{ow[0], ow[1], ow[2], ow[3]};
+                        if constexpr (STATS) {
+                            // row statistics of the bf16 values just formed (what the consuming GEMM will read), 64 columns:
+                            // 8 per lane by dot2c, then the row's 8 lanes (pslot = lane & 7) by xor 4, 2, 1.  N % 64 == 0 and the
+                            // 8 lanes of a row share m, so the `continue` above never splits a reduction group.
+                            typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+                            float sm = 0.f, sq = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bf16x2_hw pr = __builtin_bit_cast(bf16x2_hw, ow[e]);
+                                sm = __builtin_amdgcn_fdot2_f32_bf16(pr, __builtin_bit_cast(bf16x2_hw, 0x3f803f80u), sm, false);
+                                sq = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, sq, false);
+                            }
+                            sm += lane_xor<4>(sm); sq += lane_xor<4>(sq);
+                            sm += lane_xor<2>(sm); sq += lane_xor<2>(sq);
+                            sm += lane_xor<1>(sm); sq += lane_xor<1>(sq);
+                            if (pslot == 0) p.stat_part[(size_t)(nbw >> 6) * p.M + m] = make_float2(sm, sq);
+                        }
                     } else if constexpr (EPI == FP_EPI_PATCH) {
                         const int b = m / p.P, pp = m - b * p.P;
                         orow = (size_t)b * p.npad + p.tok_off + pp;
@@ -221,15 +262,31 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
         const int wkey = (li >> 1) & 7;
         const int m2 = m0 + wm * (16 * TM) + pslot * 8;        // phase-2 tokens of this lane (first of 8)
         const int b2 = m2 / p.npad, t2 = m2 - b2 * p.npad;
+        float rt[LNF ? 16 : 1];                                // rstd of this lane's 16 consecutive tokens
+        if constexpr (LNF) {
+            const f32x4_t* rp = (const f32x4_t*)(p.ln_rstd + min(m0 + wm * (16 * TM) + lg * 16, p.M - 16));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4_t q = rp[j];
+                rt[4 * j] = q[0]; rt[4 * j + 1] = q[1]; rt[4 * j + 2] = q[2]; rt[4 * j + 3] = q[3];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int n1 = n0 + wn * (16 * TN) + 16 * i + li;
-            const float bias = (p.bias && n1 < p.N) ? bf2f(p.bias[n1]) : 0.f;
             float v[16];
+            if constexpr (LNF) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias;
+                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * rt[4 * j + r];
+            } else {
+                const float bias = (p.bias && n1 < p.N) ? bf2f(p.bias[n1]) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] + bias;
+            }
             u32x4_t w0, w1;
             w0.x = pack_bf2(v[0], v[1]);   w0.y = pack_bf2(v[2], v[3]);
             w0.z = pack_bf2(v[4], v[5]);   w0.w = pack_bf2(v[6], v[7]);
@@ -251,6 +308,7 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
         }
     } else {
         // transposed V store (direct form, wave tiles taller than 64 tokens): lane owns, for each of its TN features, 4*TM consecutive tokens
+        static_assert(!LNF, "the LN-folded V store exists for 64-token wave tiles only");
         constexpr int RUN = 4 * TM;
         static_assert(RUN % 16 == 0, "token runs are stored in 16-token groups");
 #pragma unroll

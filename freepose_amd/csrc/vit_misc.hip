@@ -287,7 +287,124 @@ __global__ __launch_bounds__(256) void l2norm_rows_vec_kernel(const bf16_t* X, b
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm folded into the consuming GEMM (gemm_bf16.h FP_EPI_LN_*): what is left of LN1 / LN2 are per-row statistics.
+// Both kernels write (mean, sigma = sqrt(var + eps)) pairs for the accumulator init and rstd = 1 / sigma for the epilogue.
+// row_stats_kernel: statistics straight from the rows (block 0, whose input comes from the patch-embed scatter + token init);
+// two-pass variance like layernorm_kernel.  One wave per row.
+template <int MAXC>
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ X, float2* __restrict__ ms, float* __restrict__ rstd_out,
+                                                        int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int nch = D / 8;
+    for (int r = wave; r < rows; r += nwave) {
+        const bf16_t* xr = X + (size_t)r * D;
+        float v[MAXC][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int ch = lane + 64 * c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+            if (ch < nch) {
+                const uint4 q = *(const uint4*)(xr + ch * 8);
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[c][2 * e] = lo_bf(w[e]); v[c][2 * e + 1] = hi_bf(w[e]); }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += v[c][e];
+            }
+        }
+        const float mean = wave_sum(sum) / (float)D;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (lane + 64 * c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+            }
+        const float sigma = __fsqrt_rn(wave_sum(sq) / (float)D + eps);
+        if (lane == 0) { ms[r] = make_float2(mean, sigma); rstd_out[r] = __builtin_amdgcn_rcpf(sigma); }   // v_rcp_f32: the LN-folded GEMMs compute the same from sigma
+        
+    }
+}
+
+// stats_finalize_kernel: (mean, rstd) from the per-64-column partial sums the producing GEMM's epilogue wrote
+// (part[nb][m] = (sum x, sum x^2) of row m over columns 64 nb .. 64 nb + 63; FP_EPI_LS_RES_STATS), added in block order.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ ms,
+                                                             float* __restrict__ rstd_out, int rows, int nb, float inv_d, float eps) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.f, q = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        const float2 p = part[(size_t)b * rows + r];
+        s += p.x;
+        q += p.y;
+    }
+    const float mean = s * inv_d;
+    const float var = fmaxf(__fmaf_rn(-mean, mean, q * inv_d), 0.f);
+    const float sigma = __fsqrt_rn(var + eps);
+    ms[r] = make_float2(mean, sigma);
+    rstd_out[r] = __builtin_amdgcn_rcpf(sigma);
+}
+
+// ln_fold_kernel (once per weight load): W' = bf16(W diag(gamma)),  cb[n] = (sum_k W'[n,k], bias[n] + sum_k W[n,k] beta[k]).
+// One wave per output feature n; the column sum runs over the ROUNDED W' — it must cancel what the MFMAs accumulate.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ gamma,
+                                                      const bf16_t* __restrict__ beta, const bf16_t* __restrict__ bias,
+                                                      bf16_t* __restrict__ Wf, float2* __restrict__ cb, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (n >= N) return;
+    float cs = 0.f, wb = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const uint4 w = *(const uint4*)(W + (size_t)n * K + k), g = *(const uint4*)(gamma + k), b = *(const uint4*)(beta + k);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w}, gw[4] = {g.x, g.y, g.z, g.w}, bw[4] = {b.x, b.y, b.z, b.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float f0 = rbf(lo_bf(ww[e]) * lo_bf(gw[e])), f1 = rbf(hi_bf(ww[e]) * hi_bf(gw[e]));
+            o[e] = pack_bf2(f0, f1);
+            cs += f0;
+            cs += f1;
+            wb = __fmaf_rn(lo_bf(ww[e]), lo_bf(bw[e]), wb);
+            wb = __fmaf_rn(hi_bf(ww[e]), hi_bf(bw[e]), wb);
+        }
+        *(uint4*)(Wf + (size_t)n * K + k) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    cs = wave_sum(cs);
+    wb = wave_sum(wb);
+    if (lane == 0) cb[n] = make_float2(cs, (bias ? bf2f(bias[n]) : 0.f) + wb);
+}
+
 }  // namespace
+
+int fp_row_stats(const bf16_t* X, float2* ms, float* rstd, int rows, int D, float eps, hipStream_t s) {
+    FP_REQUIRE(D % 8 == 0 && D <= 8 * 64 * 3, "row_stats: D=%d unsupported", D);
+    const int blocks = std::min(cdiv(rows, 4), 256 * 8);
+    if (D <= 512) hipLaunchKernelGGL(row_stats_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ms, rstd, rows, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(row_stats_kernel<2>, dim3(blocks), dim3(256), 0, s, X, ms, rstd, rows, D, eps);
+    else hipLaunchKernelGGL(row_stats_kernel<3>, dim3(blocks), dim3(256), 0, s, X, ms, rstd, rows, D, eps);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+int fp_stats_finalize(const float2* part, float2* ms, float* rstd, int rows, int D, float eps, hipStream_t s) {
+    FP_REQUIRE(D % 64 == 0, "stats_finalize: D=%d must be a multiple of 64", D);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, part, ms, rstd, rows, D / 64, 1.0f / (float)D, eps);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
+
+int fp_ln_fold(const bf16_t* W, const bf16_t* gamma, const bf16_t* beta, const bf16_t* bias, bf16_t* Wf, float2* cb, int N, int K,
+               hipStream_t s) {
+    FP_REQUIRE(K % 8 == 0, "ln_fold: K=%d must be a multiple of 8", K);
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, gamma, beta, bias, Wf, cb, N, K);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
+}
 
 int fp_im2col_norm(const bf16_t* img, bf16_t* A, int B, int H, int W, int ps, int KP, hipStream_t s) {
     FP_REQUIRE(H % ps == 0 && W % ps == 0 && KP % 8 == 0 && KP >= 3 * ps * ps, "im2col: bad shape");

@@ -28,7 +28,7 @@ def context(device: Optional[int] = None):
 
 
 def set_option(name: str, value: int):
-    """experiment toggle (A/B measurements): 'gemm_variant', 'attn_slots', 'raster_tiled'; value < 0 restores the default"""
+    """experiment toggle (A/B measurements): 'gemm_variant', 'attn_slots', 'raster_tiled', 'ln_fused'; value < 0 restores the default"""
     check(_lib.load().fp_set_option(name.encode(), int(value)), "fp_set_option")
 
 
@@ -433,6 +433,37 @@ def gemm_vt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, npad: int, hea
     vt = out if out is not None else torch.zeros((B, heads, 64, npad), dtype=torch.bfloat16, device=x.device)
     check(lib.fp_op_gemm_vt(ptr(x), K, ptr(w), K, ptr(vt), ptr(bias), M, N, K, npad, heads, current_stream()), "fp_op_gemm_vt")
     return vt
+
+
+def ln_linear(x: torch.Tensor, g_ln: torch.Tensor, b_ln: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, mode: int = 0,
+              npad: int = 0, heads: int = 0, eps: float = 1e-6) -> torch.Tensor:
+    """LayerNorm folded into the consuming linear layer (fp_op_ln_linear): mode 0 LN(x) w^T + b, 1 gelu(.), 2 transposed V store"""
+    lib = _lib.load()
+    x, w, bias = _dev(x, torch.bfloat16), _dev(w, torch.bfloat16), _dev(bias, torch.bfloat16)
+    g_ln, b_ln = _dev(g_ln, torch.bfloat16), _dev(b_ln, torch.bfloat16)
+    M, K = x.shape
+    N = w.shape[0]
+    if mode == 2:
+        out = torch.zeros((M // npad, heads, 64, npad), dtype=torch.bfloat16, device=x.device)
+    else:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    check(lib.fp_op_ln_linear(context(), ptr(x), M, K, ptr(g_ln), ptr(b_ln), float(eps), ptr(w), N, ptr(bias), int(mode), int(npad),
+                              int(heads), ptr(out), current_stream()), "fp_op_ln_linear")
+    return out
+
+
+def gemm_stats(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, resid: torch.Tensor, eps: float = 1e-6):
+    """resid + gamma * (x w^T + b) plus the (mean, rstd) of each output row from the epilogue's partial sums (fp_op_gemm_stats)"""
+    lib = _lib.load()
+    x, w, bias = _dev(x, torch.bfloat16), _dev(w, torch.bfloat16), _dev(bias, torch.bfloat16)
+    g, r = _dev(gamma, torch.bfloat16), _dev(resid, torch.bfloat16)
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    stat = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    check(lib.fp_op_gemm_stats(context(), ptr(x), K, ptr(w), K, ptr(out), N, ptr(bias), ptr(g), ptr(r), N, M, N, K, float(eps), ptr(stat),
+                               current_stream()), "fp_op_gemm_stats")
+    return out, stat
 
 
 def attention(qk: torch.Tensor, vt: torch.Tensor, n_tok: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:

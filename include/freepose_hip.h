@@ -35,6 +35,7 @@ int fp_version(void);
  *                   2048 keep the 128x128 kernel for grids smaller than the CU count (A/B only)
  *                   (default 238 = 2|4|8|32|64|128)
  *   "attn_slots":   LDS ring depth of the attention kernel, 2 (default), 3 or 4
+ *   "ln_fused":     1 (default) LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward, 0 the separate kernel (A/B)
  *   "raster_tiled": unset = LDS-tiled rasteriser for meshes up to 32 768 triangles and images up to 704 px, global
  *                   visibility-buffer path otherwise; 1 / 0 force one of them (both bit-identical) */
 int fp_set_option(const char* name, int value);
@@ -206,6 +207,17 @@ int fp_op_gemm(const void* d_X, int ldx, const void* d_W, int ldw, void* d_C, in
 /* V part of qkv stored transposed per head: Vt[b,h,d,t] for rows m = b*npad + t, n = h*64 + d */
 int fp_op_gemm_vt(const void* d_X, int ldx, const void* d_W, int ldw, void* d_Vt, const void* d_bias, int M, int N,
                   int K, int npad, int heads, void* stream);
+/* LayerNorm folded into the consuming linear layer, the way fp_vit_forward runs LN1 -> qkv and LN2 -> fc1 (hub DINOv2 block:
+ * x + ls1 * attn(norm1(x)); x + ls2 * mlp(norm2(x)) — the nn.LayerNorm + nn.Linear pairs behind src/pipeline/retrieval/dino.py:18-19):
+ *   LN(x) W^T + b  =  rstd (x W'^T - mean colsum(W')) + b',   W' = W diag(gamma_ln),  b' = b + W beta_ln
+ * d_X bf16 [M,K] raw rows, d_g_ln / d_b_ln bf16 [K], d_W bf16 [N,K], d_bias bf16 [N].  mode 0: d_out bf16 [M,N] = linear,
+ * 1: GELU(linear), 2: transposed per head like fp_op_gemm_vt (npad, heads).  Kernel-level entry used by the tests. */
+int fp_op_ln_linear(fp_ctx* ctx, const void* d_X, int M, int K, const void* d_g_ln, const void* d_b_ln, float eps, const void* d_W,
+                    int N, const void* d_bias, int mode, int npad, int heads, void* d_out, void* stream);
+/* fp_op_gemm with epilogue 2 (LayerScale + residual) that also emits d_stat f32 [M,2] = (mean, rstd) of the rows it wrote — the
+ * producer side of the folded LayerNorm (per-64-column partial sums in the epilogue, summed in block order). */
+int fp_op_gemm_stats(fp_ctx* ctx, const void* d_X, int ldx, const void* d_W, int ldw, void* d_C, int ldc, const void* d_bias,
+                     const void* d_gamma, const void* d_resid, int ldr, int M, int N, int K, float eps, float* d_stat, void* stream);
 /* flash attention forward on QK [B*npad, 2*H*64] (ldqk elements) + Vt [B,H,64,npad] -> O [B*npad, H*64] */
 int fp_op_attention(const void* d_QK, int ldqk, const void* d_Vt, void* d_O, int ldo, int B, int H, int n_tok,
                     int npad, void* stream);

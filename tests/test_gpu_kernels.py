@@ -90,6 +90,76 @@ def test_gemm_vt(B, npad, H):
     assert _rel(vt, ref) < 6e-3
 
 
+# M = 160: one-wave 64x64 tiles, 3000 / 17: 128x128, 70 000 x 1024 and 52 x 1376: persistent 256x256 (relocated slabs + constants)
+@pytest.mark.parametrize("M,N,K", [(160, 1152, 384), (3000, 2048, 1024), (70000, 1024, 1024), (30000, 4096, 1024), (1000, 768, 768)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_ln_folded_linear(M, N, K, mode):
+    """LayerNorm folded into the consuming GEMM (FP_EPI_LN_BIAS / LN_GELU) vs fp64 torch LayerNorm + Linear (+ GELU) of the same op
+    (hub DINOv2 block: attn.qkv(norm1(x)), mlp.fc1(norm2(x))).  Rows get a large common offset and per-row scale so that
+    mean >> std for some rows: the colsum correction must cancel the x W' term in fp32, not in bf16."""
+    from freepose_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn((M, K), generator=g) * (0.2 + 3.0 * torch.rand((M, 1), generator=g)) + 4.0 * torch.randn((M, 1), generator=g)
+    x[5 % M] = 0.0                                                       # a pad-like all-zero row: var = 0 -> rstd = 1/sqrt(eps), output = b'
+    x[:, 7] += 40.0                                                      # a massive-activation channel
+    x = x.to(torch.bfloat16)
+    w, bias = _rand((N, K), 32, 0.05), _rand((N,), 33, 0.5)
+    g_ln, b_ln = (1.0 + 0.3 * torch.randn(K, generator=g)).to(torch.bfloat16), (0.2 * torch.randn(K, generator=g)).to(torch.bfloat16)
+    out = ops.ln_linear(x, g_ln, b_ln, w, bias, mode)
+    torch.cuda.synchronize()
+    y = torch.nn.functional.layer_norm(x.double(), (K,), g_ln.double(), b_ln.double(), 1e-6)
+    ref = y @ w.double().t() + bias.double()
+    if mode == 1:
+        ref = torch.nn.functional.gelu(ref)
+    assert _rel(out, ref) < 8e-3, _rel(out, ref)
+    diff = (out.float().cpu() - ref.float()).abs()
+    tol = 0.02 * ref.float().abs() + 0.04
+    assert (diff <= tol).all(), f"max diff {diff.max().item()} at {np.unravel_index(int(diff.argmax()), diff.shape)}"
+    # against the SEPARATE LayerNorm kernel + plain GEMM (the reference's rounding points: LN output rounded to bf16 first)
+    sep = ops.gemm(ops.layernorm(x, g_ln, b_ln), w, bias, mode)
+    assert _rel(out, sep) < 8e-3
+    assert _rel(out, ref) <= 1.25 * _rel(sep, ref) + 1e-4, "the folded form must not be less accurate than LN-then-GEMM"
+
+
+@pytest.mark.parametrize("B,npad,H", [(1, 272, 6), (3, 912, 16), (52, 1376, 16)])
+def test_ln_folded_vt(B, npad, H):
+    from freepose_amd import ops
+    D, M = H * 64, B * npad
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn((M, D), generator=g) * (0.2 + 2.0 * torch.rand((M, 1), generator=g)) + 2.0 * torch.randn((M, 1), generator=g)).to(torch.bfloat16)
+    w, bias = _rand((D, D), 42, 0.05), _rand((D,), 43, 0.5)
+    g_ln, b_ln = (1.0 + 0.3 * torch.randn(D, generator=g)).to(torch.bfloat16), (0.2 * torch.randn(D, generator=g)).to(torch.bfloat16)
+    vt = ops.ln_linear(x, g_ln, b_ln, w, bias, 2, npad=npad, heads=H)
+    torch.cuda.synchronize()
+    y = torch.nn.functional.layer_norm(x.double(), (D,), g_ln.double(), b_ln.double(), 1e-6)
+    ref = (y @ w.double().t() + bias.double()).reshape(B, npad, H, 64).permute(0, 2, 3, 1)
+    assert _rel(vt, ref) < 8e-3, _rel(vt, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(160, 384, 384), (3000, 1024, 1024), (70000, 1024, 1024), (2600, 1024, 4096), (900, 768, 3072)])
+def test_gemm_emits_row_statistics(M, N, K):
+    """producer side of the folded LayerNorm: the LayerScale + residual epilogue also writes per-64-column (sum, sum of squares)
+    of its bf16 OUTPUT rows; finalised (mean, rstd) vs torch on those rows, and the output itself equal to the plain epilogue's bits"""
+    from freepose_amd import ops
+    x, w = _rand((M, K), 51, 1.0), _rand((N, K), 52, 0.05)
+    bias, gamma, resid = _rand((N,), 53, 0.5), _rand((N,), 54, 1.0), _rand((M, N), 55, 2.0)
+    resid = (resid.float() + 3.0 * torch.randn((M, 1), generator=torch.Generator().manual_seed(56))).to(torch.bfloat16)
+    out, stat = ops.gemm_stats(x, w, bias, gamma, resid)
+    plain = ops.gemm(x, w, bias, 2, gamma=gamma, resid=resid)
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain), "the statistics must not change the stored rows"
+    o = out.double().cpu()
+    mean, var = o.mean(dim=1), o.var(dim=1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-6)
+    st = stat.double().cpu()
+    assert ((st[:, 0] - mean).abs() <= 1e-5 * (1 + mean.abs())).all(), (st[:, 0] - mean).abs().max()
+    assert ((st[:, 1] - rstd).abs() <= 2e-4 * rstd).all(), ((st[:, 1] - rstd).abs() / rstd).max()
+    # tile-tier independence: partials are per 64-column block whatever the tile, so a sub-batch reproduces the same bits
+    m2 = min(M, 160)
+    out2, stat2 = ops.gemm_stats(x[:m2], w, bias, gamma, resid[:m2])
+    assert torch.equal(out2, out[:m2]) and torch.equal(stat2, stat[:m2])
+
+
 @pytest.mark.parametrize("B,H,n_tok", [(1, 6, 261), (2, 16, 905), (2, 16, 1374), (1, 16, 64), (1, 2, 17)])
 def test_attention(B, H, n_tok):
     from freepose_amd import ops

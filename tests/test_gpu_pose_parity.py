@@ -148,7 +148,7 @@ def test_pose_parity_vit_in_the_loop(capsys):
                 decisive += 1
                 assert same, f"[{regime}] query {b}: decisive lead of {lead_ulp:.1f} ulp but HIP picked {g_top}, oracle {io_k[0]}"
             if same:
-                assert r_err == 0.0 and t_err <= 1e-6, (regime, b, r_err, t_err)
+                assert r_err <= 1e-4 and t_err <= 1e-6, (regime, b, r_err, t_err)   # acos of a trace that is 3 to rounding
             else:
                 assert g_top in io_k.tolist(), f"[{regime}] query {b}: HIP pick {g_top} not in the oracle's top-3 {io_k}"
                 assert (so_k[0] - s_o[g_top]) / _ulp_bf16(so_k[0]) <= MARGIN_ULP

@@ -45,6 +45,7 @@ struct AttnArgs {
     bf16_t* O; int ldo;
     int B, H, n_tok, npad, D;
     float scale_log2e;           // log2(e) / sqrt(hd)
+    int q_base;                  // first query row (per crop) this launch covers: the 256-query kernel takes [0, q_base), this one the tail
 };
 
 // combine a value with the lane whose id differs in bit 4 (16-lane rows) / bit 5 (32-lane halves): gfx950
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
     const int li = lane & 15, lg = lane >> 4;
     // XCD-aware block order (1-D grid): the q-blocks of one (crop, head) are consecutive LOGICAL ids, hence run on one
     // XCD and share its L2 copy of that head's K / V^T (rocprofv3: 4.4x over-fetch when they were spread over 8 XCDs)
-    const int nqb = (p.npad + QB - 1) / QB;
+    const int nqb = (p.npad - p.q_base + QB - 1) / QB;
     int bid = blockIdx.x;
     {
         const int nwg = gridDim.x;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
     }
     const int qb = bid % nqb, bh = bid / nqb;
     const int h = bh % p.H, b = bh / p.H;
-    const int q0 = qb * QB + wave * QW;
+    const int q0 = p.q_base + qb * QB + wave * QW;
 
     const size_t rowbase = (size_t)b * p.npad;
     const char* gQK = (const char*)p.QK;
@@ -215,11 +216,9 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         const int kv0 = t * KVB;
 
         // ---- S^T = K Q^T -------------------------------------------------------------------------
+        // the first d-half starts from the inline constant 0 as the MFMA's C operand: no accumulator zeroing (32 v_mov per tile and
+        // wave, a quarter of the loop's vector-ALU instructions in the r03 PMC run)
         f32x4_t s[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) s[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
                 const bf16x8_t kf = *(const bf16x8_t*)(sb + baseK + (32 * (fk >> 1) + 4 * (fk & 1)) * ROWB + slot);
 #pragma unroll
                 for (int fq = 0; fq < 2; ++fq)
-                    s[fk][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[fq][kk], s[fk][fq], 0, 0, 0);
+                    s[fk][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[fq][kk], kk == 0 ? f32x4_t{0.f, 0.f, 0.f, 0.f} : s[fk][fq], 0, 0, 0);
             }
         }
         if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
@@ -393,7 +392,8 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     a.QK = QK; a.ldqk = ldqk; a.Vt = Vt; a.O = O; a.ldo = ldo;
     a.B = B; a.H = H; a.n_tok = n_tok; a.npad = npad; a.D = H * HD;
     a.scale_log2e = 1.4426950408889634f / 8.0f;
-    dim3 grid(cdiv(npad, QB) * H * B);
+    a.q_base = 0;
+    dim3 grid(cdiv(npad - a.q_base, QB) * H * B);
     const int nslot = fp_opt_get(FP_OPT_ATTN_SLOTS, 2);   // measured: 2 >= 3 > 4 (profiles/r01_ab.md)
     static int env_var = [] { const char* e = getenv("FP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
     if (nslot == 2 && (env_var & 2)) hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);

@@ -102,7 +102,7 @@ struct fp_vit {
     std::vector<VitBlockW> blk;
     // LayerNorm folded into the consuming GEMMs (gemm_bf16.h FP_EPI_LN_*): per block W' = W diag(gamma_ln) for qkv / fc1 and the
     // (colsum(W'), b') pairs, built on the device the first time a forward runs after the weights changed
-    struct VitFold { bf16_t *qkvw = nullptr, *fc1w = nullptr; float2 *qkv_cb = nullptr, *fc1_cb = nullptr; };
+    struct VitFold { bf16_t *qkvw = nullptr, *fc1w = nullptr; uint4 *qkv_cb = nullptr, *fc1_cb = nullptr; };
     std::vector<VitFold> fold;
     bool folded = false;
     // pos-embed cache per (gh,gw)
@@ -231,9 +231,9 @@ static int vit_fold(fp_vit* v, int L, hipStream_t s) {
         const VitBlockW& w = v->blk[i];
         fp_vit::VitFold& f = v->fold[i];
         if (!f.qkvw) FP_HIP(hipMalloc((void**)&f.qkvw, 3 * D * D * 2));
-        if (!f.qkv_cb) FP_HIP(hipMalloc((void**)&f.qkv_cb, 3 * D * sizeof(float2)));
+        if (!f.qkv_cb) FP_HIP(hipMalloc((void**)&f.qkv_cb, 3 * D * sizeof(uint4)));
         if (!f.fc1w) FP_HIP(hipMalloc((void**)&f.fc1w, Mm * D * 2));
-        if (!f.fc1_cb) FP_HIP(hipMalloc((void**)&f.fc1_cb, Mm * sizeof(float2)));
+        if (!f.fc1_cb) FP_HIP(hipMalloc((void**)&f.fc1_cb, Mm * sizeof(uint4)));
         int rc;
         if ((rc = fp_ln_fold(w.qkvw, w.n1w, w.n1b, w.qkvb, f.qkvw, f.qkv_cb, (int)(3 * D), (int)D, s))) return rc;
         if ((rc = fp_ln_fold(w.fc1w, w.n2w, w.n2b, w.fc1b, f.fc1w, f.fc1_cb, (int)Mm, (int)D, s))) return rc;
@@ -301,14 +301,15 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
     // LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs (default; fp_set_option("ln_fused", 0) runs the separate kernel for A/B)
     static const int ln_env = [] { const char* e = getenv("FP_LN_FUSED"); return e ? atoi(e) : 1; }();
     const bool lnf = fp_opt_get(FP_OPT_LN_FUSED, ln_env) != 0 && D % 64 == 0;
-    float2 *stat = nullptr, *part = nullptr;
+    uint4* stat = nullptr;     // per-row init-MFMA records (sigma, -mean splits)
+    float2* part = nullptr;
     float* rstd = nullptr;
     if (lnf) {
         if (!v->folded) {
             if ((rc = vit_fold(v, a.depth, s))) return rc;
             v->folded = true;
         }
-        if ((rc = v->ctx->get("vit.ln_stat", M * sizeof(float2), (void**)&stat))) return rc;
+        if ((rc = v->ctx->get("vit.ln_stat", M * sizeof(uint4), (void**)&stat))) return rc;
         if ((rc = v->ctx->get("vit.ln_rstd", M * sizeof(float), (void**)&rstd))) return rc;
         if ((rc = v->ctx->get("vit.ln_part", M * (size_t)(D / 64) * sizeof(float2), (void**)&part))) return rc;
     }
@@ -353,12 +354,12 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
             ProfScope ps(v, s, &v->ms_gemm);
             FpGemmArgs g{};
             g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.qkvw : w.qkvw; g.ldw = D; g.C = QK; g.ldc = 2 * D; g.bias = w.qkvb;
-            g.M = Mi; g.N = 2 * D; g.K = D; g.ln_ms = stat; g.ln_rstd = rstd; g.ln_cb = f.qkv_cb;
+            g.M = Mi; g.N = 2 * D; g.K = D; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = f.qkv_cb;
             if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_BIAS : FP_EPI_BIAS, s))) return rc;
             FpGemmArgs gv{};
             gv.X = lnf ? X : Y; gv.ldx = D; gv.W = (lnf ? f.qkvw : w.qkvw) + (size_t)2 * D * D; gv.ldw = D; gv.C = Vt; gv.ldc = 8;
             gv.bias = w.qkvb + 2 * D; gv.M = Mi; gv.N = D; gv.K = D; gv.npad = npad; gv.heads = a.heads;
-            gv.ln_ms = stat; gv.ln_rstd = rstd; gv.ln_cb = lnf ? f.qkv_cb + 2 * D : nullptr;
+            gv.ln_mfrag = stat; gv.ln_rstd = rstd; gv.ln_cfrag = lnf ? f.qkv_cb + 2 * D : nullptr;
             if ((rc = fp_gemm_bf16(gv, lnf ? FP_EPI_LN_VT : FP_EPI_VT, s))) return rc;
             if (v->prof) { v->gemm_flops += 2.0 * Malg * 3.0 * D * D; v->gemm_launches += 2; }
         }
@@ -383,7 +384,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
             ProfScope ps(v, s, &v->ms_gemm);
             FpGemmArgs g{};
             g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.fc1w : w.fc1w; g.ldw = D; g.C = H1; g.ldc = a.mlp_dim; g.bias = w.fc1b;
-            g.M = Mi; g.N = a.mlp_dim; g.K = D; g.ln_ms = stat; g.ln_rstd = rstd; g.ln_cb = f.fc1_cb;
+            g.M = Mi; g.N = a.mlp_dim; g.K = D; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = f.fc1_cb;
             if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_GELU : FP_EPI_BIAS_GELU, s))) return rc;
             FpGemmArgs g2{};
             g2.X = H1; g2.ldx = a.mlp_dim; g2.W = w.fc2w; g2.ldw = a.mlp_dim; g2.C = X; g2.ldc = D; g2.bias = w.fc2b;
@@ -548,18 +549,18 @@ extern "C" int fp_op_ln_linear(fp_ctx* ctx, const void* X, int M, int K, const v
     FP_REQUIRE(mode >= 0 && mode <= 2, "op_ln_linear: mode %d (0..2)", mode);
     hipStream_t s = (hipStream_t)stream;
     bf16_t* Wf;
-    float2 *cb, *stat;
+    uint4 *cb, *stat;
     float* rstd;
     int rc;
     if ((rc = ctx->get("op.ln_wf", (size_t)N * K * 2, (void**)&Wf))) return rc;
-    if ((rc = ctx->get("op.ln_cb", (size_t)N * sizeof(float2), (void**)&cb))) return rc;
-    if ((rc = ctx->get("op.ln_stat", (size_t)M * sizeof(float2), (void**)&stat))) return rc;
+    if ((rc = ctx->get("op.ln_cb", (size_t)N * sizeof(uint4), (void**)&cb))) return rc;
+    if ((rc = ctx->get("op.ln_stat", (size_t)M * sizeof(uint4), (void**)&stat))) return rc;
     if ((rc = ctx->get("op.ln_rstd", (size_t)M * sizeof(float), (void**)&rstd))) return rc;
     if ((rc = fp_ln_fold((const bf16_t*)W, (const bf16_t*)g_ln, (const bf16_t*)b_ln, (const bf16_t*)bias, Wf, cb, N, K, s))) return rc;
     if ((rc = fp_row_stats((const bf16_t*)X, stat, rstd, M, K, eps, s))) return rc;
     FpGemmArgs g{};
     g.X = (const bf16_t*)X; g.ldx = K; g.W = Wf; g.ldw = K; g.C = (bf16_t*)out; g.ldc = mode == 2 ? 8 : N;
-    g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads; g.ln_ms = stat; g.ln_rstd = rstd; g.ln_cb = cb;
+    g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = cb;
     return fp_gemm_bf16(g, mode == 0 ? FP_EPI_LN_BIAS : (mode == 1 ? FP_EPI_LN_GELU : FP_EPI_LN_VT), s);
 }
 // LayerScale + residual GEMM that also emits the row statistics of its OUTPUT (what the next LN-folded GEMM consumes):
@@ -568,11 +569,12 @@ extern "C" int fp_op_gemm_stats(fp_ctx* ctx, const void* X, int ldx, const void*
                                 const void* gamma, const void* resid, int ldr, int M, int N, int K, float eps, float* d_stat,
                                 void* stream) {
     FP_REQUIRE(ctx && X && W && Cc && bias && gamma && resid && d_stat, "op_gemm_stats: null argument");
-    float2 *part, *ms;
+    float2* part;
+    uint4* ms;
     float* rstd;
     int rc;
     if ((rc = ctx->get("op.ln_part", (size_t)M * (N / 64) * sizeof(float2), (void**)&part))) return rc;
-    if ((rc = ctx->get("op.ln_stat", (size_t)M * sizeof(float2), (void**)&ms))) return rc;
+    if ((rc = ctx->get("op.ln_stat", (size_t)M * sizeof(uint4), (void**)&ms))) return rc;
     if ((rc = ctx->get("op.ln_rstd", (size_t)M * sizeof(float), (void**)&rstd))) return rc;
     FpGemmArgs g{};
     g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Cc; g.ldc = ldc;
@@ -580,9 +582,10 @@ extern "C" int fp_op_gemm_stats(fp_ctx* ctx, const void* X, int ldx, const void*
     g.M = M; g.N = N; g.K = K; g.stat_part = part;
     if ((rc = fp_gemm_bf16(g, FP_EPI_LS_RES_STATS, (hipStream_t)stream))) return rc;
     if ((rc = fp_stats_finalize(part, ms, rstd, M, N, eps, (hipStream_t)stream))) return rc;
-    // d_stat [M,2] = (mean, rstd)
-    FP_HIP(hipMemcpy2DAsync(d_stat, 8, ms, 8, 4, M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    FP_HIP(hipMemcpy2DAsync(d_stat + 1, 8, rstd, 4, 4, M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    // d_stat [M,6] = the row record's 4 words {sh|sl, sh|-mh, -ml|-mh, 0} reinterpreted as floats are NOT meaningful: hand back the raw
+    // record words (4 x u32 as f32 bit patterns) followed by (rstd, 0); the Python wrapper decodes mean = -(mh + ml), sigma = sh + sl
+    FP_HIP(hipMemcpy2DAsync(d_stat, 24, ms, 16, 16, M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    FP_HIP(hipMemcpy2DAsync(d_stat + 4, 24, rstd, 4, 4, M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return FP_OK;
 }
 extern "C" int fp_op_attention(const void* QK, int ldqk, const void* Vt, void* O, int ldo, int B, int H, int n_tok,

@@ -14,6 +14,11 @@ enum FpGemmEpi {
     // with W' = W diag(gamma_ln) (bf16), colsum over the bf16 W', b' = b + W beta_ln (fp32).  X is the RAW residual stream.
     // The correction rides in the ACCUMULATOR INIT: acc0[m][n] = b'[n] sigma[m] - mean[m] cs[n] (sigma = 1/rstd), the K loop adds
     // x W'^T on top in fp32, and the epilogue is one multiply by rstd[m] — no per-feature constants are live in the epilogue.
+    // acc0 is a rank-2 outer product and is formed ON THE MATRIX PIPE: one extra MFMA per accumulator block whose operands carry,
+    // in 6 of their 32 k-slots, the two-piece bf16 splits (hi + lo, 16 mantissa bits) of (b', cs) per feature and (sigma, -mean) per
+    // row:  b' sigma ~ b'h sh + b'h sl + b'l sh  (relative error 2^-16), likewise mean cs.  Vector-ALU work at a tile boundary costs
+    // four times its instruction count (the four waves of a SIMD do it in lock-step with the matrix pipe idle): the VALU form of this
+    // init was +4-5 % on the qk / V / fc1 launches (profiles/r03_ab.md).
     FP_EPI_LN_BIAS = 5,     // C = rstd (acc - mean cs) + b'            (QK part of qkv on the un-normalised x)
     FP_EPI_LN_GELU = 6,     // C = gelu_erf(bf16(rstd (acc - mean cs) + b'))   (fc1)
     FP_EPI_LN_VT = 7,       // Vt[b,h,d,t] = rstd (acc - mean cs) + b'  (V part of qkv)
@@ -44,12 +49,14 @@ struct FpGemmArgs {
     int heads;
     // FP_EPI_BIAS_GELU: device table of fp_gemm_gelu_table() (filled in by fp_gemm_bf16; callers leave it null)
     const uint16_t* gelu_tab;
-    // FP_EPI_LN_*: per-row (mean, sigma = sqrt(var + eps)) [M] and rstd = 1/sigma [M]; per-feature (colsum(W'), b') [N]; fp32
-    const float2* ln_ms;
+    // FP_EPI_LN_*: init-MFMA operand records, 8 bf16 (16 bytes) each — per row   {sh, sl, sh, -mh, -ml, -mh, 0, 0}  (sigma, mean),
+    // per feature {b'h, b'h, b'l, ch, ch, cl, 0, 0}  (b', colsum(W')) — and rstd = 1/sigma [M] fp32 for the epilogue
+    const uint4* ln_mfrag;
     const float* ln_rstd;
-    const float2* ln_cb;
+    const uint4* ln_cfrag;
     // FP_EPI_LS_RES_STATS: partial row statistics [N/64][M] (sum, sum of squares), N % 64 == 0
     float2* stat_part;
+    int dbg;   // experiment bits (FP_GEMM_DBG; wrong numerics): 2 = LN-folded kernels start from zero accumulators
 };
 
 // Tile order shared by the GEMM kernels.  blockIdx -> logical id (XCD-contiguous, bijective) -> (tile_m, tile_n) in

@@ -166,68 +166,55 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     // Layout (gemm_epilogue.h): acc[i][4 grp + j][r] is feature n0 + 64 (wn + grp) + 16 lg + 4 j + r for every row block i.
     f32x4_t acc[TC][TR];
     auto init_acc = [&](int m0_of_init, int tn0) {
-        (void)m0_of_init;
-        if constexpr (!TRANS && !LNF) {
+        // The accumulators start at bias[n] (plain epilogues) or at b'[n] sigma[m] - mean[m] cs[n] (LN-folded ones, gemm_bf16.h) — formed
+        // by ONE MFMA per accumulator block from 16-byte operand records (only the k-chunk of lanes lg == 0 is non-zero) with the inline
+        // constant 0 as C: no accumulator zeroing, no unpacking, no vector-ALU arithmetic at the tile boundary, where every VALU
+        // instruction is paid four times (the SIMD's four waves in lock-step, matrix pipe idle).  bias * 1.0 is exact.
+        const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+        const bf16x8_t zfrag = __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u));
+        // feature index / token index of fragment f of the R operand (permuted rows) and of the C operand (plain rows)
+        const int rperm = (li >> 2) * 4 * TR + (li & 3);           // + 4 f
+        bf16x8_t fr0[TR], fc0[TC];
+        if constexpr (LNF) {
+            const int featw = tn0 + wn * (16 * TN), tokw = m0_of_init + wm * (16 * TM);
 #pragma unroll
-            for (int grp = 0; grp < TR / 4; ++grp) {
-                const int nb1 = tn0 + wn * (16 * TN) + grp * 64 + lg * 16;
-                uint32_t bw[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bw[e] = 0u;
-                if (nb1 < p.N) {
-                    const uint4* bp = (const uint4*)(p.bias + nb1);
-                    const uint4 b0 = bp[0], b1 = bp[1];
-                    bw[0] = b0.x; bw[1] = b0.y; bw[2] = b0.z; bw[3] = b0.w;
-                    bw[4] = b1.x; bw[5] = b1.y; bw[6] = b1.z; bw[7] = b1.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4_t b4 = {lo_bf(bw[2 * j]), hi_bf(bw[2 * j]), lo_bf(bw[2 * j + 1]), hi_bf(bw[2 * j + 1])};
-#pragma unroll
-                    for (int i = 0; i < TC; ++i) acc[i][grp * 4 + j] = b4;
-                }
+            for (int f = 0; f < TR; ++f) {
+                const int idx = TRANS ? min(tokw + rperm + 4 * f, p.M - 1) : min(featw + rperm + 4 * f, p.N - 1);
+                fr0[f] = lg == 0 ? __builtin_bit_cast(bf16x8_t, (TRANS ? p.ln_mfrag : p.ln_cfrag)[idx]) : zfrag;
             }
-        } else if constexpr (LNF && !TRANS) {
-            // LayerNorm folded into this GEMM: acc0 = b'[n] sigma[m] - mean[m] cs[n]; the epilogue multiplies by rstd[m] (gemm_bf16.h)
-            float2 ms[TC];
 #pragma unroll
-            for (int i = 0; i < TC; ++i) ms[i] = p.ln_ms[min(m0_of_init + wm * (16 * TM) + 16 * i + li, p.M - 1)];
-#pragma unroll
-            for (int grp = 0; grp < TR / 4; ++grp) {
-                const int nb1 = min(tn0 + wn * (16 * TN) + grp * 64 + lg * 16, p.N - 16);
-                const f32x4_t* cp = (const f32x4_t*)(p.ln_cb + nb1);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4_t c0 = cp[2 * j], c1 = cp[2 * j + 1];     // (cs, b') of features 4j, 4j+1 | 4j+2, 4j+3
-#pragma unroll
-                    for (int i = 0; i < TC; ++i) {
-                        const float nm = -ms[i].x, sg = ms[i].y;
-                        acc[i][grp * 4 + j] = f32x4_t{__fmaf_rn(nm, c0[0], c0[1] * sg), __fmaf_rn(nm, c0[2], c0[3] * sg),
-                                                      __fmaf_rn(nm, c1[0], c1[1] * sg), __fmaf_rn(nm, c1[2], c1[3] * sg)};
-                    }
-                }
+            for (int f = 0; f < TC; ++f) {
+                const int idx = TRANS ? min(featw + 16 * f + li, p.N - 1) : min(tokw + 16 * f + li, p.M - 1);
+                fc0[f] = lg == 0 ? __builtin_bit_cast(bf16x8_t, (TRANS ? p.ln_cfrag : p.ln_mfrag)[idx]) : zfrag;
             }
-        } else if constexpr (LNF) {
-            // transposed V store: lane = feature 16 i + li (TC blocks), 16 consecutive tokens lg*16 + 4 j + r
-            float2 cb[TC];
+        } else if constexpr (!TRANS) {
+            const int featw = tn0 + wn * (16 * TN);
 #pragma unroll
-            for (int i = 0; i < TC; ++i) cb[i] = p.ln_cb[min(tn0 + wn * (16 * TN) + 16 * i + li, p.N - 1)];
-            const f32x4_t* mp = (const f32x4_t*)(p.ln_ms + min(m0_of_init + wm * (16 * TM) + lg * 16, p.M - 16));
+            for (int f = 0; f < TR; ++f) {
+                const int idx = min(featw + rperm + 4 * f, p.N - 1);
+                fr0[f] = lg == 0 ? __builtin_bit_cast(bf16x8_t, make_uint4((uint32_t)p.bias[idx], 0u, 0u, 0u)) : zfrag;
+            }
+            const bf16x8_t onef = lg == 0 ? __builtin_bit_cast(bf16x8_t, make_uint4(0x3f80u, 0u, 0u, 0u)) : zfrag;
 #pragma unroll
-            for (int j = 0; j < TR; ++j) {
-                const f32x4_t s0 = mp[2 * j], s1 = mp[2 * j + 1];         // (mean, sigma) of tokens 4j, 4j+1 | 4j+2, 4j+3
+            for (int f = 0; f < TC; ++f) fc0[f] = onef;
+        }
+        if constexpr (LNF || !TRANS) {
+            if (LNF && (p.dbg & 2)) {
 #pragma unroll
-                for (int i = 0; i < TC; ++i) {
-                    const float ncs = -cb[i].x, bp = cb[i].y;
-                    acc[i][j] = f32x4_t{__fmaf_rn(s0[0], ncs, bp * s0[1]), __fmaf_rn(s0[2], ncs, bp * s0[3]),
-                                        __fmaf_rn(s1[0], ncs, bp * s1[1]), __fmaf_rn(s1[2], ncs, bp * s1[3])};
-                }
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TR; ++j) acc[i][j] = zero4;
+            } else {
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TR; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[j], fc0[i], zero4, 0, 0, 0);
             }
         } else {   // transposed V store: measured slower with the bias in the accumulators (-3.7 %: spills), it adds it in the epilogue
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int j = 0; j < TR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < TR; ++j) acc[i][j] = zero4;
         }
     };
     auto zero_acc = [&]() { init_acc(m0, n0); };   // (name kept: every loop form re-arms the accumulators through it)
@@ -468,6 +455,8 @@ int fp_gemm_gelu_table(const uint16_t** out) {
 
 int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
     FpGemmArgs a = a_in;
+    static const int dbg_env = [] { const char* e = getenv("FP_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg_env;
     if (epi == FP_EPI_BIAS_GELU || epi == FP_EPI_LN_GELU) {
         const int rc = fp_gemm_gelu_table(&a.gelu_tab);
         if (rc != FP_OK) return rc;
@@ -493,10 +482,10 @@ int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
             return launch_epi<FP_EPI_VT>(a, stream);
         case FP_EPI_LN_BIAS:
         case FP_EPI_LN_GELU:
-            FP_REQUIRE(a.ln_ms && a.ln_rstd && a.ln_cb && a.N % 64 == 0 && a.M >= 16, "gemm: LN-folded epilogue needs ln_ms, ln_rstd, ln_cb and N %% 64 == 0");
+            FP_REQUIRE(a.ln_mfrag && a.ln_rstd && a.ln_cfrag && a.N % 64 == 0 && a.M >= 16, "gemm: LN-folded epilogue needs ln_mfrag, ln_rstd, ln_cfrag and N %% 64 == 0");
             return epi == FP_EPI_LN_BIAS ? launch_epi<FP_EPI_LN_BIAS>(a, stream) : launch_epi<FP_EPI_LN_GELU>(a, stream);
         case FP_EPI_LN_VT:
-            FP_REQUIRE(a.ln_ms && a.ln_rstd && a.ln_cb, "gemm: LN-folded epilogue needs ln_ms, ln_rstd and ln_cb");
+            FP_REQUIRE(a.ln_mfrag && a.ln_rstd && a.ln_cfrag, "gemm: LN-folded epilogue needs ln_mfrag, ln_rstd and ln_cfrag");
             FP_REQUIRE(a.npad % 16 == 0 && a.M % 16 == 0 && a.heads > 0 && a.N == a.heads * 64,
                        "gemm: VT epilogue needs npad%%16==0, M%%16==0, N==heads*64");
             return launch_epi<FP_EPI_LN_VT>(a, stream);

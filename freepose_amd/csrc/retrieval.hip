@@ -38,18 +38,6 @@ __global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
-    float qv[QT][NCH][8];
-#pragma unroll
-    for (int q = 0; q < QT; ++q)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int base = (c * 64 + lane) * 8;
-            const bool ok = (q_begin + q < Q) && (FULL || base < D);
-            const uint4 qw = ok ? *(const uint4*)(queries + (size_t)(q_begin + q) * D + base) : make_uint4(0, 0, 0, 0);
-            const uint32_t w[4] = {qw.x, qw.y, qw.z, qw.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { qv[q][c][2 * e] = lo_bf(w[e]); qv[q][c][2 * e + 1] = hi_bf(w[e]); }
-        }
     // Balanced partition: wave w owns a contiguous run of floor(N/nwave) (+1 for the first N%nwave waves) rows, streamed in
     // chunks of RU rows (RU x 2 KB in flight) with the next chunk requested before the current one is reduced.  The host
     // picks the grid (2..8 workgroups per CU) that leaves the smallest remainder, e.g. 3 per CU for N = 46 037 (0.1 %).
@@ -58,6 +46,7 @@ __global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict
     const int r_begin = wave * base_rows + min(wave, rem);
     const int r_end = r_begin + base_rows + (wave < rem ? 1 : 0);
     uint4 bufA[RU][NCH], bufB[RU][NCH];
+    float qv[QT][NCH][8];                 // the queries, unpacked (filled in after the first row requests are out)
     auto fetch = [&](uint4 (&dst)[RU][NCH], int r0) {
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
@@ -101,9 +90,24 @@ __global__ __launch_bounds__(256) void bank_scan_kernel(const bf16_t* __restrict
         }
     };
     // two chunk buffers used alternately (no register copy at the hand-over): B is requested before A is reduced, etc.
+    // The first two chunks are requested BEFORE the queries: a wave owns only ~9 rows of the 46 037-row bank (5 120 waves), so the
+    // kernel is a start-up transient, and queries-then-rows cost two dependent memory round trips where one suffices (r03: the
+    // cold-bank pass went 19.3 -> see profiles/r03_ab.md).
     if (r_begin < r_end) fetch(bufA, r_begin);
+    if (r_begin + RU < r_end) fetch(bufB, r_begin + RU);
+#pragma unroll
+    for (int q = 0; q < QT; ++q)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int base = (c * 64 + lane) * 8;
+            const bool ok = (q_begin + q < Q) && (FULL || base < D);
+            const uint4 qw = ok ? *(const uint4*)(queries + (size_t)(q_begin + q) * D + base) : make_uint4(0, 0, 0, 0);
+            const uint32_t w[4] = {qw.x, qw.y, qw.z, qw.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qv[q][c][2 * e] = lo_bf(w[e]); qv[q][c][2 * e + 1] = hi_bf(w[e]); }
+        }
     for (int r0 = r_begin; r0 < r_end; r0 += 2 * RU) {
-        if (r0 + RU < r_end) fetch(bufB, r0 + RU);
+        if (r0 != r_begin && r0 + RU < r_end) fetch(bufB, r0 + RU);
         reduce_chunk(bufA, r0);
         if (r0 + RU < r_end) {
             if (r0 + 2 * RU < r_end) fetch(bufA, r0 + 2 * RU);

@@ -289,11 +289,16 @@ __global__ __launch_bounds__(256) void l2norm_rows_vec_kernel(const bf16_t* X, b
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm folded into the consuming GEMM (gemm_bf16.h FP_EPI_LN_*): what is left of LN1 / LN2 are per-row statistics.
-// Both kernels write (mean, sigma = sqrt(var + eps)) pairs for the accumulator init and rstd = 1 / sigma for the epilogue.
+// Both kernels write, per row, the init-MFMA operand record of gemm_bf16.h — {sh, sl, sh, -mh, -ml, -mh, 0, 0}: sigma = sqrt(var + eps)
+// and -mean as two-piece bf16 splits (x ~ xh + xl, xh = bf16(x), xl = bf16(x - xh): 16 mantissa bits) — and rstd = 1 / sigma (fp32).
 // row_stats_kernel: statistics straight from the rows (block 0, whose input comes from the patch-embed scatter + token init);
 // two-pass variance like layernorm_kernel.  One wave per row.
+__device__ __forceinline__ uint4 ln_row_record(float mean, float sigma) {
+    const float sh = rbf(sigma), sl = rbf(sigma - sh), nm = -mean, mh = rbf(nm), ml = rbf(nm - mh);
+    return make_uint4(pack_bf2(sh, sl), pack_bf2(sh, mh), pack_bf2(ml, mh), 0u);
+}
 template <int MAXC>
-__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ X, float2* __restrict__ ms, float* __restrict__ rstd_out,
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ X, uint4* __restrict__ mfrag, float* __restrict__ rstd_out,
                                                         int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -326,14 +331,14 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict
                 for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
             }
         const float sigma = __fsqrt_rn(wave_sum(sq) / (float)D + eps);
-        if (lane == 0) { ms[r] = make_float2(mean, sigma); rstd_out[r] = __builtin_amdgcn_rcpf(sigma); }   // v_rcp_f32: the LN-folded GEMMs compute the same from sigma
-        
+        if (lane == 0) { mfrag[r] = ln_row_record(mean, sigma); rstd_out[r] = __builtin_amdgcn_rcpf(sigma); }
+
     }
 }
 
 // stats_finalize_kernel: (mean, rstd) from the per-64-column partial sums the producing GEMM's epilogue wrote
 // (part[nb][m] = (sum x, sum x^2) of row m over columns 64 nb .. 64 nb + 63; FP_EPI_LS_RES_STATS), added in block order.
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const float2* __restrict__ part, float2* __restrict__ ms,
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float2* __restrict__ part, uint4* __restrict__ mfrag,
                                                              float* __restrict__ rstd_out, int rows, int nb, float inv_d, float eps) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
@@ -346,15 +351,16 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float2* __res
     const float mean = s * inv_d;
     const float var = fmaxf(__fmaf_rn(-mean, mean, q * inv_d), 0.f);
     const float sigma = __fsqrt_rn(var + eps);
-    ms[r] = make_float2(mean, sigma);
+    mfrag[r] = ln_row_record(mean, sigma);
     rstd_out[r] = __builtin_amdgcn_rcpf(sigma);
 }
 
-// ln_fold_kernel (once per weight load): W' = bf16(W diag(gamma)),  cb[n] = (sum_k W'[n,k], bias[n] + sum_k W[n,k] beta[k]).
+// ln_fold_kernel (once per weight load): W' = bf16(W diag(gamma)),  cs[n] = sum_k W'[n,k],  b'[n] = bias[n] + sum_k W[n,k] beta[k];
+// written as the per-feature init-MFMA record {b'h, b'h, b'l, ch, ch, cl, 0, 0} (two-piece bf16 splits).
 // One wave per output feature n; the column sum runs over the ROUNDED W' — it must cancel what the MFMAs accumulate.
 __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ gamma,
                                                       const bf16_t* __restrict__ beta, const bf16_t* __restrict__ bias,
-                                                      bf16_t* __restrict__ Wf, float2* __restrict__ cb, int N, int K) {
+                                                      bf16_t* __restrict__ Wf, uint4* __restrict__ cfrag, int N, int K) {
     const int lane = threadIdx.x & 63;
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (n >= N) return;
@@ -376,12 +382,16 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__
     }
     cs = wave_sum(cs);
     wb = wave_sum(wb);
-    if (lane == 0) cb[n] = make_float2(cs, (bias ? bf2f(bias[n]) : 0.f) + wb);
+    if (lane == 0) {
+        const float bp = (bias ? bf2f(bias[n]) : 0.f) + wb;
+        const float bh = rbf(bp), bl = rbf(bp - bh), ch = rbf(cs), cl = rbf(cs - ch);
+        cfrag[n] = make_uint4(pack_bf2(bh, bh), pack_bf2(bl, ch), pack_bf2(ch, cl), 0u);
+    }
 }
 
 }  // namespace
 
-int fp_row_stats(const bf16_t* X, float2* ms, float* rstd, int rows, int D, float eps, hipStream_t s) {
+int fp_row_stats(const bf16_t* X, uint4* ms, float* rstd, int rows, int D, float eps, hipStream_t s) {
     FP_REQUIRE(D % 8 == 0 && D <= 8 * 64 * 3, "row_stats: D=%d unsupported", D);
     const int blocks = std::min(cdiv(rows, 4), 256 * 8);
     if (D <= 512) hipLaunchKernelGGL(row_stats_kernel<1>, dim3(blocks), dim3(256), 0, s, X, ms, rstd, rows, D, eps);
@@ -391,14 +401,14 @@ int fp_row_stats(const bf16_t* X, float2* ms, float* rstd, int rows, int D, floa
     return FP_OK;
 }
 
-int fp_stats_finalize(const float2* part, float2* ms, float* rstd, int rows, int D, float eps, hipStream_t s) {
+int fp_stats_finalize(const float2* part, uint4* ms, float* rstd, int rows, int D, float eps, hipStream_t s) {
     FP_REQUIRE(D % 64 == 0, "stats_finalize: D=%d must be a multiple of 64", D);
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, part, ms, rstd, rows, D / 64, 1.0f / (float)D, eps);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }
 
-int fp_ln_fold(const bf16_t* W, const bf16_t* gamma, const bf16_t* beta, const bf16_t* bias, bf16_t* Wf, float2* cb, int N, int K,
+int fp_ln_fold(const bf16_t* W, const bf16_t* gamma, const bf16_t* beta, const bf16_t* bias, bf16_t* Wf, uint4* cb, int N, int K,
                hipStream_t s) {
     FP_REQUIRE(K % 8 == 0, "ln_fold: K=%d must be a multiple of 8", K);
     hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, gamma, beta, bias, Wf, cb, N, K);

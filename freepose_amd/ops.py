@@ -453,16 +453,19 @@ def ln_linear(x: torch.Tensor, g_ln: torch.Tensor, b_ln: torch.Tensor, w: torch.
 
 
 def gemm_stats(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, resid: torch.Tensor, eps: float = 1e-6):
-    """resid + gamma * (x w^T + b) plus the (mean, rstd) of each output row from the epilogue's partial sums (fp_op_gemm_stats)"""
+    """resid + gamma * (x w^T + b) plus the row statistics from the epilogue's partial sums (fp_op_gemm_stats): returns (out,
+    stat f32 [M,3] = (mean, sigma, rstd)) — mean and sigma decoded from the two-piece bf16 splits the consuming GEMM reads"""
     lib = _lib.load()
     x, w, bias = _dev(x, torch.bfloat16), _dev(w, torch.bfloat16), _dev(bias, torch.bfloat16)
     g, r = _dev(gamma, torch.bfloat16), _dev(resid, torch.bfloat16)
     M, K = x.shape
     N = w.shape[0]
     out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    stat = torch.empty((M, 2), dtype=torch.float32, device=x.device)
-    check(lib.fp_op_gemm_stats(context(), ptr(x), K, ptr(w), K, ptr(out), N, ptr(bias), ptr(g), ptr(r), N, M, N, K, float(eps), ptr(stat),
+    raw = torch.zeros((M, 6), dtype=torch.float32, device=x.device)
+    check(lib.fp_op_gemm_stats(context(), ptr(x), K, ptr(w), K, ptr(out), N, ptr(bias), ptr(g), ptr(r), N, M, N, K, float(eps), ptr(raw),
                                current_stream()), "fp_op_gemm_stats")
+    rec = raw[:, :4].contiguous().view(torch.bfloat16).float()          # [M, 8]: sh, sl, sh, -mh, -ml, -mh, 0, 0
+    stat = torch.stack([-(rec[:, 3] + rec[:, 4]), rec[:, 0] + rec[:, 1], raw[:, 4]], dim=1)
     return out, stat
 
 

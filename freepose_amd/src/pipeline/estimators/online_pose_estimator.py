@@ -57,7 +57,7 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
             raise RuntimeError("no fine-grid rotation within the neighbourhood of the previous pose")
         selected = self.fine_mesh_poses[close]
         renders = self.renderer.render_from_poses(mesh, selected, scale=self.rendering_scale)
-        crops, poses, masks, ext = MeshRenderer.generate_proposals(renders, out_bf16=True, return_extents=True)
+        crops, poses, masks, ext = MeshRenderer.generate_proposals(renders, out_bf16=True, return_extents=True, need_masks=mask_scores)
         if query_feat is None and tuple(proposal.shape[-2:]) == tuple(crops.shape[-2:]):
             # the query crop rides in the same ViT batch as the hypothesis crops: a separate B = 1 forward is launch-bound
             # (~2.5 ms of a ~19 ms step) and a crop's features do not depend on its batch neighbours (bit-exact, tested)
@@ -78,8 +78,10 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
         # max / argmax (first maximum): canonical (score desc, index asc)
         idx_all = torch.arange(len(close), dtype=torch.int32, device=scores.device)
         top_s, top_i = ops.topk_merge(scores[None], idx_all[None], 1)
-        top = int(top_i[0, 0])
-        e = ext[top].cpu().numpy()
+        # winner index, its score and its two cloud extents come back in ONE device -> host copy (the score is a bf16 value held
+        # in fp32, the index is small: both are exact in float64)
+        packed = torch.cat([top_i[0, :1].double(), top_s[0, :1].double(), ext[top_i[0, 0].long(), 4:6].double()]).cpu().numpy()
+        top = int(packed[0])
         ratio = float(est_scale) / 0.25
-        TCO = z_from_extents(bbox, e[4] * ratio, e[5] * ratio, K, poses[top])
-        return {"TCO": [TCO], "scores": [top_s[0, 0].cpu().numpy()], "proposal": proposal, "K": K, "bbox": bbox}
+        TCO = z_from_extents(bbox, packed[2] * ratio, packed[3] * ratio, K, poses[top])
+        return {"TCO": [TCO], "scores": [np.float32(packed[1])], "proposal": proposal, "K": K, "bbox": bbox}

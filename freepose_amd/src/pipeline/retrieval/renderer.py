@@ -115,8 +115,9 @@ class MeshRenderer:
         return np.array([xs.min(), ys.min(), xs.max(), ys.max()])
 
     @staticmethod
-    def generate_proposals(res, resolution=420, bbox_extend=0, out_bf16=False, return_extents=False):
-        """(crops [n,3,res,res], poses, masks) from renders; masks = depth > 0 with the <100 px fallback square."""
+    def generate_proposals(res, resolution=420, bbox_extend=0, out_bf16=False, return_extents=False, need_masks=True):
+        """(crops [n,3,res,res], poses, masks) from renders; masks = depth > 0 with the <100 px fallback square.  `need_masks=False`
+        (the video step without mask_scores) skips the mask tensors — and with them a host synchronisation per call."""
         if not isinstance(res, RenderBatch):  # reference-style list of numpy tuples
             rgb = torch.from_numpy(np.stack([r[0] for r in res])).cuda()
             depth = torch.from_numpy(np.stack([r[1] for r in res]).astype(np.float32)).cuda()
@@ -125,11 +126,13 @@ class MeshRenderer:
         ext = ops.depth_extents(res.depth, fx, fy, cx, cy)
         boxes = ext[:, :4].to(torch.int32)
         crops = ops.crop_resize_pad(res.rgb, boxes, resolution, float(bbox_extend), out_bf16=out_bf16)
-        masks = res.depth > 0
-        small = ext[:, 6] < 100
-        if bool(small.any()):
-            masks = masks.clone()
-            masks[small, 105:315, 105:315] = True
+        masks = None
+        if need_masks:
+            masks = res.depth > 0
+            small = ext[:, 6] < 100
+            if bool(small.any()):
+                masks = masks.clone()
+                masks[small, 105:315, 105:315] = True
         if return_extents:
             return crops, res.thirds, masks, ext
         return crops, res.thirds, masks

@@ -214,8 +214,10 @@ int fp_op_gemm_vt(const void* d_X, int ldx, const void* d_W, int ldw, void* d_Vt
  * 1: GELU(linear), 2: transposed per head like fp_op_gemm_vt (npad, heads).  Kernel-level entry used by the tests. */
 int fp_op_ln_linear(fp_ctx* ctx, const void* d_X, int M, int K, const void* d_g_ln, const void* d_b_ln, float eps, const void* d_W,
                     int N, const void* d_bias, int mode, int npad, int heads, void* d_out, void* stream);
-/* fp_op_gemm with epilogue 2 (LayerScale + residual) that also emits d_stat f32 [M,2] = (mean, rstd) of the rows it wrote — the
- * producer side of the folded LayerNorm (per-64-column partial sums in the epilogue, summed in block order). */
+/* fp_op_gemm with epilogue 2 (LayerScale + residual) that also emits the row statistics of what it wrote — the producer side of the
+ * folded LayerNorm (per-64-column partial sums in the epilogue, summed in block order).  d_stat u32/f32 [M,6]: words 0-3 the 16-byte
+ * init-MFMA record of the row as the consuming GEMM reads it — bf16 {sh, sl, sh, -mh, -ml, -mh, 0, 0}, sigma = sqrt(var + eps) and
+ * -mean as two-piece bf16 splits —, word 4 rstd = 1 / sigma (f32), word 5 unused. */
 int fp_op_gemm_stats(fp_ctx* ctx, const void* d_X, int ldx, const void* d_W, int ldw, void* d_C, int ldc, const void* d_bias,
                      const void* d_gamma, const void* d_resid, int ldr, int M, int N, int K, float eps, float* d_stat, void* stream);
 /* flash attention forward on QK [B*npad, 2*H*64] (ldqk elements) + Vt [B,H,64,npad] -> O [B*npad, H*64] */

@@ -152,8 +152,11 @@ def test_gemm_emits_row_statistics(M, N, K):
     mean, var = o.mean(dim=1), o.var(dim=1, unbiased=False)
     rstd = 1.0 / torch.sqrt(var + 1e-6)
     st = stat.double().cpu()
-    assert ((st[:, 0] - mean).abs() <= 1e-5 * (1 + mean.abs())).all(), (st[:, 0] - mean).abs().max()
-    assert ((st[:, 1] - rstd).abs() <= 2e-4 * rstd).all(), ((st[:, 1] - rstd).abs() / rstd).max()
+    # mean and sigma come back as the two-piece bf16 splits the consuming GEMM's init MFMA reads: 16 mantissa bits
+    sigma = torch.sqrt(var + 1e-6)
+    assert ((st[:, 0] - mean).abs() <= 3e-5 * (1e-3 + mean.abs())).all(), (st[:, 0] - mean).abs().max()
+    assert ((st[:, 1] - sigma).abs() <= 3e-5 * sigma).all(), ((st[:, 1] - sigma).abs() / sigma).max()
+    assert ((st[:, 2] - rstd).abs() <= 2e-4 * rstd).all(), ((st[:, 2] - rstd).abs() / rstd).max()
     # tile-tier independence: partials are per 64-column block whatever the tile, so a sub-batch reproduces the same bits
     m2 = min(M, 160)
     out2, stat2 = ops.gemm_stats(x[:m2], w, bias, gamma, resid[:m2])

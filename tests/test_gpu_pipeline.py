@@ -70,7 +70,9 @@ def test_pose_estimator_forward_matches_reference(golden_dir, tmp_path):
         assert len(out["TCO"]) == 3 and len(out["retrieved_proposals"]) == 3
     assert list(est.feature_cache) == ["m"]
     # all 16 scores through the public scorer
-    s = est.score_templates(est.feature_cache["m"], out["query_feat"]).cpu().numpy()
+    # (the device store holds the rows PRE-NORMALISED, SURVEY §8 f-1: the streaming-dot scorer must reproduce the reference's
+    #  normalise-every-call scores bit for bit)
+    s = est.score_templates(est.feature_cache["m"], out["query_feat"], templates_normalized=True).cpu().numpy()
     assert np.array_equal(s, g["scores_all"])
 
 

@@ -6,7 +6,14 @@
 //   vertex : s = scale*v ; Xc = fma(R00,sx, fma(R01,sy, fma(R02,sz, tx))) (same for Yc, Zc)
 //            iz = 1/Zc ; u = fma(fx, Xc*iz, cx) ; v = fma(fy, Yc*iz, cy)
 //            fixed point 24.8 : xi = rint(u*256), yi = rint(v*256)      (image coords, y down)
-//   a triangle with any Zc <= znear (0.05) is dropped (no clipping; objects sit at z ~ 1.1 m)
+//   near plane (znear = 0.05, renderer.py:62-67 / pyrender's default): a triangle with all three Zc <= znear is dropped; one that
+//   STRADDLES the plane is rasterised in homogeneous coordinates, which clips it exactly at z = znear without generating geometry:
+//       vertex k -> (xk, yk, wk) = (pixel x * z, pixel y * z, z): for Zc > znear from the snapped fixed-point pixel (xi / 256 * Zc, so
+//       edges shared with ordinary triangles coincide), else xk = fma(fx, Xc, cx * Zc), yk likewise (stored as float bits in xi / yi);
+//       in double: a0 = y1 w2 - y2 w1, b0 = x2 w1 - x1 w2, c0 = x1 y2 - x2 y1 (cyclic for 1, 2), det = x0 a0 + y0 b0 + w0 c0;
+//       pixel (px, py): X = px + 0.5, Y = py + 0.5, e_i = (a_i X + b_i Y) + c_i, all negated when det < 0;
+//       covered iff e0, e1, e2 >= 0, S = (e0 + e1) + e2 > 0 and z = |det| / S > znear; depth = (float) z;
+//       barycentrics (float)(e_i / S) are perspective-correct; colour / uv interpolate with them directly, textures at level 0.
 //   coverage: sample (256 px + 128, 256 py + 128); int64 edge functions; orientation normalised by
 //            swapping v1,v2 when the doubled area is negative (SKIP_CULL_FACES); top-left rule on ties
 //   depth  : b_i = float(E_i)/float(area2) ; izp = fma(b2,iz2, fma(b1,iz1, b0*iz0)) ; depth = 1/izp
@@ -91,8 +98,10 @@ __global__ void raster_vertex_kernel(const float* __restrict__ verts, int V, con
         o.xi = (int)rintf(uc * 256.0f);
         o.yi = (int)rintf(vc * 256.0f);
         o.iz = iz;
-    } else {
-        o.xi = 0; o.yi = 0; o.iz = 0.f;
+    } else {   // behind the near plane: homogeneous pixel coordinates for straddling triangles (contract in the header)
+        o.xi = (int)__float_as_uint(fmaf(fx, Xc, cx * Zc));
+        o.yi = (int)__float_as_uint(fmaf(fy, Yc, cy * Zc));
+        o.iz = 0.f;
     }
     sv[(size_t)h * V + i] = o;
 }
@@ -105,7 +114,53 @@ struct TriSetup {
     int i0, i1, i2;          // vertex ids after orientation normalisation
     bool ok;
     bool swapped;            // corners 1 and 2 were exchanged (per-corner attributes follow)
+    bool strad;              // straddles the near plane: homogeneous rasterisation over the whole frame (struct Strad)
 };
+
+// homogeneous edge functions of a triangle that straddles the near plane (contract in the header)
+struct Strad { double a[3], b[3], c[3], det; };
+__device__ __forceinline__ void strad_vertex(const SVert& v, double& x, double& y, double& w) {
+    w = (double)v.zc;
+    if (v.zc > ZNEAR) {
+        x = ((double)v.xi * (1.0 / 256.0)) * w;
+        y = ((double)v.yi * (1.0 / 256.0)) * w;
+    } else {
+        x = (double)__uint_as_float((unsigned)v.xi);
+        y = (double)__uint_as_float((unsigned)v.yi);
+    }
+}
+__device__ __forceinline__ Strad strad_setup(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, int f) {
+    double x[3], y[3], w[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) strad_vertex(sv[faces[3 * f + k]], x[k], y[k], w[k]);
+    Strad q;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        q.a[k] = y[k1] * w[k2] - y[k2] * w[k1];
+        q.b[k] = x[k2] * w[k1] - x[k1] * w[k2];
+        q.c[k] = x[k1] * y[k2] - x[k2] * y[k1];
+    }
+    q.det = (x[0] * q.a[0] + y[0] * q.b[0]) + w[0] * q.c[0];
+    return q;
+}
+// coverage, depth and perspective-correct barycentrics of pixel (px, py)
+__device__ __forceinline__ bool strad_pixel(const Strad& q, int px, int py, float& d, float& b0, float& b1, float& b2) {
+    const double X = (double)px + 0.5, Y = (double)py + 0.5;
+    double e0 = (q.a[0] * X + q.b[0] * Y) + q.c[0];
+    double e1 = (q.a[1] * X + q.b[1] * Y) + q.c[1];
+    double e2 = (q.a[2] * X + q.b[2] * Y) + q.c[2];
+    double det = q.det;
+    if (det < 0.0) { e0 = -e0; e1 = -e1; e2 = -e2; det = -det; }
+    if (!(det > 0.0) || e0 < 0.0 || e1 < 0.0 || e2 < 0.0) return false;
+    const double S = (e0 + e1) + e2;
+    if (!(S > 0.0)) return false;
+    const double z = det / S;
+    if (!(z > (double)ZNEAR)) return false;
+    d = (float)z;
+    b0 = (float)(e0 / S); b1 = (float)(e1 / S); b2 = (float)(e2 / S);
+    return true;
+}
 
 __device__ __forceinline__ bool topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
 
@@ -114,7 +169,17 @@ __device__ __forceinline__ TriSetup tri_setup(const SVert* __restrict__ sv, cons
     TriSetup t;
     int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     SVert a = sv[i0], b = sv[i1], c = sv[i2];
-    t.ok = (a.zc > ZNEAR) && (b.zc > ZNEAR) && (c.zc > ZNEAR);
+    const int nfront = (a.zc > ZNEAR) + (b.zc > ZNEAR) + (c.zc > ZNEAR);
+    t.ok = nfront == 3;
+    t.strad = nfront == 1 || nfront == 2;
+    if (t.strad) {   // near-plane straddler: candidate pixels = the whole frame, original corner order, no fixed-point set-up
+        t.ok = true; t.swapped = false; t.area2 = 1;
+        t.x0 = t.y0 = t.x1 = t.y1 = t.x2 = t.y2 = 0;
+        t.iz0 = t.iz1 = t.iz2 = 0.f;
+        t.i0 = i0; t.i1 = i1; t.i2 = i2;
+        t.bx0 = 0; t.by0 = 0; t.bx1 = W - 1; t.by1 = Hh - 1;
+        return t;
+    }
     long long area2 = (long long)(b.xi - a.xi) * (c.yi - a.yi) - (long long)(b.yi - a.yi) * (c.xi - a.xi);
     t.swapped = area2 < 0;
     if (area2 < 0) {
@@ -170,6 +235,13 @@ __device__ __forceinline__ void tri_pixel(const TriSetup& t, int f, int px, int 
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)f;
     // (a read-before-atomic "cannot win" test was measured here: the scattered 8-byte loads cost more than the L2 atomics
     //  they save — 2.4 -> 3.5 ms per 576 views — so the atomic is issued unconditionally)
+    atomicMin(&zb[(size_t)py * W + px], key);
+}
+
+__device__ __forceinline__ void strad_pixel_global(const Strad& q, int f, int px, int py, unsigned long long* __restrict__ zb, int W) {
+    float d, b0, b1, b2;
+    if (!strad_pixel(q, px, py, d, b0, b1, b2)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)f;
     atomicMin(&zb[(size_t)py * W + px], key);
 }
 
@@ -229,7 +301,7 @@ __device__ __forceinline__ float log2p(float t) {
 
 // tab: DEC[256] then THR[256] (LDS copy)
 __device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetup& t, int f, float q0, float q1, float q2,
-                                               float dd, const float* tab, uint8_t (&out)[3]) {
+                                               float dd, const float* tab, uint8_t (&out)[3], bool lod0 = false) {
     const float* dec = tab;
     const float* thr = tab + 256;
     if (s.uv) {
@@ -242,7 +314,7 @@ __device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetu
         int l0 = 0;
         bool two = false;
         float fr = 0.f;
-        if (s.filter && s.nlev > 1) {
+        if (s.filter && s.nlev > 1 && !lod0) {
             const float fa = (float)t.area2;
             // d(w_i)/d(px) = -256 (y_b - y_a), d(w_i)/d(py) = 256 (x_b - x_a) of the edge opposite corner i
             const float gx0 = (float)(-(long long)(t.y2 - t.y1) * 256) / fa * t.iz0, gy0 = (float)((long long)(t.x2 - t.x1) * 256) / fa * t.iz0;
@@ -305,9 +377,16 @@ __device__ __forceinline__ void resolve_pixel(const SVert* __restrict__ sv, cons
     const int f = (int)(unsigned)(key & 0xffffffffu);
     d = __uint_as_float((unsigned)(key >> 32));
     const TriSetup t = tri_setup(sv, faces, f, W, Hh);
+    float b0, b1, b2;
+    if (t.strad) {   // near-plane straddler: true (3-D) barycentrics, level-0 texture
+        const Strad q = strad_setup(sv, faces, f);
+        float ds;
+        strad_pixel(q, px, py, ds, b0, b1, b2);
+        shade_fragment(s, t, f, b0, b1, b2, 1.0f, tab, out, true);
+        return;
+    }
     long long w0, w1, w2;
     tri_cover(t, px, py, w0, w1, w2);
-    float b0, b1, b2;
     const float dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
     shade_fragment(s, t, f, b0 * t.iz0, b1 * t.iz1, b2 * t.iz2, dd, tab, out);
 }
@@ -324,10 +403,16 @@ __global__ __launch_bounds__(256) void raster_tri_kernel(const SVert* __restrict
     const TriSetup t = tri_setup(sv, faces, f, W, Hh);
     if (!t.ok) return;
     const int area = (t.bx1 - t.bx0 + 1) * (t.by1 - t.by0 + 1);
-    if (area > BIG_AREA) {
+    if (area > BIG_AREA || t.strad) {
         const int slot = atomicAdd(qcount, 1);
         if (slot < qcap) { queue[2 * slot] = h; queue[2 * slot + 1] = f; return; }
         // queue full: fall through and rasterise here (slow but correct)
+    }
+    if (t.strad) {
+        const Strad q = strad_setup(sv, faces, f);
+        for (int py = 0; py < Hh; ++py)
+            for (int px = 0; px < W; ++px) strad_pixel_global(q, f, px, py, zb, W);
+        return;
     }
     for (int py = t.by0; py <= t.by1; ++py)
         for (int px = t.bx0; px <= t.bx1; ++px) tri_pixel(t, f, px, py, zb, W);
@@ -347,6 +432,11 @@ __global__ __launch_bounds__(256) void raster_big_kernel(const SVert* __restrict
         const TriSetup t = tri_setup(sv_all + (size_t)h * V, faces, f, W, Hh);
         unsigned long long* zb = zb_all + (size_t)h * W * Hh;
         const int bw = t.bx1 - t.bx0 + 1, bh = t.by1 - t.by0 + 1;
+        if (t.strad) {   // wave-uniform
+            const Strad sq = strad_setup(sv_all + (size_t)h * V, faces, f);
+            for (int i = lane; i < bw * bh; i += 64) strad_pixel_global(sq, f, i % bw, i / bw, zb, W);
+            continue;
+        }
         for (int i = lane; i < bw * bh; i += 64) tri_pixel(t, f, t.bx0 + i % bw, t.by0 + i / bw, zb, W);
     }
 }
@@ -415,6 +505,15 @@ __global__ __launch_bounds__(BIN_CHUNK) void raster_bin_kernel(const SVert* __re
     if (threadIdx.x == 0) cmask[(size_t)h * nchunk + chunk] = m_s;
 }
 
+__device__ __forceinline__ void strad_pixel_tile(const Strad& q, int f, int px, int py, unsigned long long* tile, int X0, int Y0, int T) {
+    float d, b0, b1, b2;
+    if (!strad_pixel(q, px, py, d, b0, b1, b2)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)f;
+    unsigned long long* slot = &tile[(py - Y0) * T + (px - X0)];
+    if (key >= *(volatile unsigned long long*)slot) return;
+    atomicMin(slot, key);
+}
+
 __device__ __forceinline__ void tile_pixel(const TriSetup& t, int f, int px, int py, unsigned long long* tile, int X0, int Y0, int T) {
     long long w0, w1, w2;
     if (!tri_cover(t, px, py, w0, w1, w2)) return;
@@ -460,7 +559,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
                 t = tri_setup(sv, faces, f, W, Hh);
                 x0 = max(t.bx0, X0); y0 = max(t.by0, Y0); x1 = min(t.bx1, X1); y1 = min(t.by1, Y1);
                 mine = t.ok && x0 <= x1 && y0 <= y1;
-                big = mine && (x1 - x0 + 1) * (y1 - y0 + 1) > BIG_TILE_AREA;
+                big = mine && ((x1 - x0 + 1) * (y1 - y0 + 1) > BIG_TILE_AREA || t.strad);   // straddlers always take the wave loop
             }
         }
         if (mine && !big)
@@ -475,6 +574,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
             const TriSetup tb = tri_setup(sv, faces, fb, W, Hh);
             const int ax0 = max(tb.bx0, X0), ay0 = max(tb.by0, Y0), ax1 = min(tb.bx1, X1), ay1 = min(tb.by1, Y1);
             const int bw = ax1 - ax0 + 1, n = bw * (ay1 - ay0 + 1);
+            if (tb.strad) {
+                const Strad sq = strad_setup(sv, faces, fb);
+                for (int i = lane; i < n; i += 64) strad_pixel_tile(sq, fb, ax0 + i % bw, ay0 + i / bw, tile, X0, Y0, T);
+                continue;
+            }
             for (int i = lane; i < n; i += 64) tile_pixel(tb, fb, ax0 + i % bw, ay0 + i / bw, tile, X0, Y0, T);
         }
     }
@@ -499,7 +603,8 @@ __global__ void raster_export_kernel(const SVert* __restrict__ sv, size_t n, int
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const SVert v = sv[i];
-    xy[2 * i] = v.xi; xy[2 * i + 1] = v.yi;
+    const bool front = v.zc > ZNEAR;     // behind the near plane the fields hold homogeneous coordinates (straddler path), not pixels
+    xy[2 * i] = front ? v.xi : 0; xy[2 * i + 1] = front ? v.yi : 0;
     zc[i] = v.zc;
 }
 

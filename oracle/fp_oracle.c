@@ -377,7 +377,44 @@ void fpo_depth_extents(const float* depth, int Hn, int Hh, int W, double fx, dou
  * (pyrender/OpenGL is not in /root/reference: renderer.py:37-41,53-55,66 fix K, flip, ambient, no-cull;
  * bop_toolkit_lib/renderer_py.py:186-231 the K->projection convention).  Scan order here is triangle-major
  * with an explicit (depth, id) min — the same total order the atomic 64-bit min realises on the GPU. */
-typedef struct { int xi, yi; float iz, zc; } svert_t;
+typedef struct { int xi, yi; float iz, zc; float xh, yh; } svert_t;   /* xh, yh: homogeneous pixel coords of a vertex behind the near plane */
+
+/* Near plane (renderer.py:62-67: znear 0.05): a triangle that STRADDLES it is rasterised in homogeneous coordinates — an exact clip at
+ * z = znear without new geometry (contract in raster.hip's header).  Vertex k -> (xk, yk, wk) = (pixel x * z, pixel y * z, z): from the
+ * snapped fixed-point pixel when in front (shared edges coincide with ordinary triangles), from the camera-space point otherwise. */
+typedef struct { double a[3], b[3], c[3], det; } strad_t;
+static void strad_vertex(const svert_t* v, double* x, double* y, double* w) {
+    *w = (double)v->zc;
+    if (v->zc > 0.05f) { *x = ((double)v->xi * (1.0 / 256.0)) * *w; *y = ((double)v->yi * (1.0 / 256.0)) * *w; }
+    else { *x = (double)v->xh; *y = (double)v->yh; }
+}
+static void strad_setup(const svert_t* v0, const svert_t* v1, const svert_t* v2, strad_t* q) {
+    double x[3], y[3], w[3];
+    strad_vertex(v0, &x[0], &y[0], &w[0]); strad_vertex(v1, &x[1], &y[1], &w[1]); strad_vertex(v2, &x[2], &y[2], &w[2]);
+    for (int k = 0; k < 3; ++k) {
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        q->a[k] = y[k1] * w[k2] - y[k2] * w[k1];
+        q->b[k] = x[k2] * w[k1] - x[k1] * w[k2];
+        q->c[k] = x[k1] * y[k2] - x[k2] * y[k1];
+    }
+    q->det = (x[0] * q->a[0] + y[0] * q->b[0]) + w[0] * q->c[0];
+}
+static int strad_pixel(const strad_t* q, int px, int py, float* d, float* b0, float* b1, float* b2) {
+    const double X = (double)px + 0.5, Y = (double)py + 0.5;
+    double e0 = (q->a[0] * X + q->b[0] * Y) + q->c[0];
+    double e1 = (q->a[1] * X + q->b[1] * Y) + q->c[1];
+    double e2 = (q->a[2] * X + q->b[2] * Y) + q->c[2];
+    double det = q->det;
+    if (det < 0.0) { e0 = -e0; e1 = -e1; e2 = -e2; det = -det; }
+    if (!(det > 0.0) || e0 < 0.0 || e1 < 0.0 || e2 < 0.0) return 0;
+    const double S = (e0 + e1) + e2;
+    if (!(S > 0.0)) return 0;
+    const double z = det / S;
+    if (!(z > (double)0.05f)) return 0;
+    *d = (float)z;
+    *b0 = (float)(e0 / S); *b1 = (float)(e1 / S); *b2 = (float)(e2 / S);
+    return 1;
+}
 static int topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
 
 /* Shading contract (shared with raster.hip; pyrender's shader is not in /root/reference, so this is a stated rule, not a pin):
@@ -530,19 +567,34 @@ void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, c
             const float Xc = fmaf(P[0], sx, fmaf(P[1], sy, fmaf(P[2], sz, P[3])));
             const float Yc = fmaf(P[4], sx, fmaf(P[5], sy, fmaf(P[6], sz, P[7])));
             const float Zc = fmaf(P[8], sx, fmaf(P[9], sy, fmaf(P[10], sz, P[11])));
-            sv[i].zc = Zc; sv[i].xi = 0; sv[i].yi = 0; sv[i].iz = 0.f;
+            sv[i].zc = Zc; sv[i].xi = 0; sv[i].yi = 0; sv[i].iz = 0.f; sv[i].xh = 0.f; sv[i].yh = 0.f;
             if (Zc > ZNEAR) {
                 const float iz = 1.0f / Zc;
                 float u = fmaf(fx, Xc * iz, cx), v = fmaf(fy, Yc * iz, cy);
                 u = fminf(fmaxf(u, -30000.f), 30000.f); v = fminf(fmaxf(v, -30000.f), 30000.f);
                 sv[i].xi = (int)rintf(u * 256.0f); sv[i].yi = (int)rintf(v * 256.0f); sv[i].iz = iz;
+            } else {   /* behind the near plane: homogeneous pixel coordinates, used by triangles that straddle it */
+                sv[i].xh = fmaf(fx, Xc, cx * Zc); sv[i].yh = fmaf(fy, Yc, cy * Zc);
             }
         }
         for (size_t i = 0; i < (size_t)W * Hh; ++i) zb[i] = ~0ull;
         for (int f = 0; f < F; ++f) {
             int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
             svert_t a = sv[i0], b = sv[i1], c = sv[i2];
-            if (!(a.zc > ZNEAR && b.zc > ZNEAR && c.zc > ZNEAR)) continue;
+            const int nfront = (a.zc > ZNEAR) + (b.zc > ZNEAR) + (c.zc > ZNEAR);
+            if (nfront == 1 || nfront == 2) {   /* straddles the near plane: homogeneous rasterisation over the whole frame */
+                strad_t q; strad_setup(&a, &b, &c, &q);
+                for (int py = 0; py < Hh; ++py)
+                    for (int px = 0; px < W; ++px) {
+                        float d, b0, b1, b2;
+                        if (!strad_pixel(&q, px, py, &d, &b0, &b1, &b2)) continue;
+                        uint32_t db; memcpy(&db, &d, 4);
+                        const uint64_t key = ((uint64_t)db << 32) | (uint32_t)f;
+                        if (key < zb[(size_t)py * W + px]) zb[(size_t)py * W + px] = key;
+                    }
+                continue;
+            }
+            if (nfront != 3) continue;
             int64_t area2 = (int64_t)(b.xi - a.xi) * (c.yi - a.yi) - (int64_t)(b.yi - a.yi) * (c.xi - a.xi);
             if (area2 < 0) { svert_t t = b; b = c; c = t; area2 = -area2; }
             if (area2 == 0) continue;
@@ -583,17 +635,26 @@ void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, c
                     int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
                     int k0 = 0, k1 = 1, k2 = 2;                       /* corner order follows the orientation swap */
                     svert_t a = sv[i0], b = sv[i1], c = sv[i2];
+                    const int nfront = (a.zc > ZNEAR) + (b.zc > ZNEAR) + (c.zc > ZNEAR);
+                    const int strad = nfront != 3;                    /* a winner with a vertex behind the plane is a straddler */
+                    float fa = 1.f, dd = 1.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+                    if (strad) {       /* true (3-D) barycentrics, original corner order, level-0 texture */
+                        strad_t sq; strad_setup(&a, &b, &c, &sq);
+                        float ds;
+                        strad_pixel(&sq, px, py, &ds, &q0, &q1, &q2);
+                    } else {
                     int64_t area2 = (int64_t)(b.xi - a.xi) * (c.yi - a.yi) - (int64_t)(b.yi - a.yi) * (c.xi - a.xi);
                     if (area2 < 0) { svert_t t = b; b = c; c = t; int ti = i1; i1 = i2; i2 = ti; k1 = 2; k2 = 1; area2 = -area2; }
                     const int64_t sx = (int64_t)px * 256 + 128, sy = (int64_t)py * 256 + 128;
                     const int64_t w0 = (int64_t)(c.xi - b.xi) * (sy - b.yi) - (int64_t)(c.yi - b.yi) * (sx - b.xi);
                     const int64_t w1 = (int64_t)(a.xi - c.xi) * (sy - c.yi) - (int64_t)(a.yi - c.yi) * (sx - c.xi);
                     const int64_t w2 = (int64_t)(b.xi - a.xi) * (sy - a.yi) - (int64_t)(b.yi - a.yi) * (sx - a.xi);
-                    const float fa = (float)area2;
+                    fa = (float)area2;
                     const float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
                     const float izp = fmaf(b2, c.iz, fmaf(b1, b.iz, b0 * a.iz));
-                    const float dd = 1.0f / izp;
-                    const float q0 = b0 * a.iz, q1 = b1 * b.iz, q2 = b2 * c.iz;
+                    dd = 1.0f / izp;
+                    q0 = b0 * a.iz; q1 = b1 * b.iz; q2 = b2 * c.iz;
+                    }
                     if (textured) {
                         const float* t = uv + (size_t)f * 6;
                         const float u0 = t[2 * k0], u1 = t[2 * k1], u2 = t[2 * k2];
@@ -602,7 +663,7 @@ void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, c
                         const float Vv = fmaf(q2, v2, fmaf(q1, v1, q0 * v0)) * dd;
                         float val[3];
                         int l0 = 0, two = 0; float fr = 0.f;
-                        if (filter && nlev > 1) {
+                        if (filter && nlev > 1 && !strad) {
                             /* d(w_i)/d(px) = -256 (y_b - y_a), d(w_i)/d(py) = 256 (x_b - x_a) of the edge opposite corner i */
                             const float gx0 = (float)(-(int64_t)(c.yi - b.yi) * 256) / fa * a.iz, gy0 = (float)((int64_t)(c.xi - b.xi) * 256) / fa * a.iz;
                             const float gx1 = (float)(-(int64_t)(a.yi - c.yi) * 256) / fa * b.iz, gy1 = (float)((int64_t)(a.xi - c.xi) * 256) / fa * b.iz;

@@ -248,3 +248,43 @@ def test_trimesh_like_texture_visual_is_honoured():
     app = mesh_appearance(mesh)
     assert np.allclose(app["uv"], uv) and app["texture"].shape == (32, 32, 3)
     assert np.allclose(app["kd"], [1.0, 128 / 255, 1.0])
+
+
+def test_near_plane_clipping_known_answers():
+    """renderer.py:62-67 renders with znear = 0.05 (pyrender clips there).  A floor quad that runs from BEHIND the camera to 3 m in
+    front of it (both triangles straddle the near plane): depth must equal the analytic ray / plane intersection wherever that lies in
+    (0.05, 3], nothing may be drawn where it is nearer than the plane, and vertex colours must interpolate perspective-correctly."""
+    from oracle import fp_oracle as fo
+    W = H = 420
+    fx = fy = 600.0
+    cx = cy = 210.0
+    y0 = 0.01
+    v = np.array([[-2, y0, -1], [2, y0, -1], [2, y0, 3], [-2, y0, 3]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    col = np.array([[0, 10, 0], [0, 250, 0], [255, 250, 0], [255, 10, 0]], np.uint8)      # red = 255 (z + 1) / 4, green = 10 + 60 (x + 2)
+    pose = np.eye(4, dtype=np.float32)[None]
+    rgb, depth = fo.rasterize(v, f, col, pose, 1.0, fx, fy, cx, cy, W, H, ambient=1.0, shade=0)
+    py = np.arange(H)[:, None] + 0.5
+    px = np.arange(W)[None, :] + 0.5
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = np.where(py > cy, y0 * fy / (py - cy), np.inf) * np.ones((1, W))
+    x = (px - cx) / fx * z
+    inside = (z > 0.05) & (z <= 3.0) & (np.abs(x) <= 2.0)
+    # coverage: every clearly-inside pixel is drawn, every clearly-outside pixel is empty (one-pixel band at the far edge left open:
+    # the far edge is an ordinary projected edge, snapped to 1/256 px)
+    band = np.abs(z - 3.0) < 0.5
+    got = depth[0] > 0
+    assert np.array_equal(got[~band], inside[~band])
+    assert got[:, :].sum() > 40000
+    rows = np.nonzero(got.any(axis=1))[0]
+    assert rows.max() == 329, rows.max()                   # z(329) = 0.0502 > 0.05 >= z(330) = 0.0498: clipped exactly at the near plane
+    sel = got & inside
+    assert np.allclose(depth[0][sel], z[sel], rtol=2e-5)
+    red = 255.0 * (z + 1.0) / 4.0
+    green = 10.0 + 60.0 * (x + 2.0)
+    assert np.abs(rgb[0][..., 0][sel].astype(np.float64) - np.minimum(255, np.floor(red[sel] + 0.5))).max() <= 1
+    assert np.abs(rgb[0][..., 1][sel].astype(np.float64) - np.minimum(255, np.floor(green[sel] + 0.5))).max() <= 1
+    # a triangle entirely behind the plane draws nothing; one entirely in front is untouched by the new path
+    v2 = v.copy()
+    v2[:, 2] = [-3, -3, -0.5, -0.5]
+    assert not (fo.rasterize(v2, f, col, pose, 1.0, fx, fy, cx, cy, W, H)[1] > 0).any()

@@ -213,3 +213,41 @@ def test_web_template_dataset_matches_reference_golden(tmp_path, golden_dir):
             assert e["model_name"] == str(g["model_name"]) and e["tar_file"] == str(g["tar_file"])
     nc = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), crop=False).get_template_by_name(names[0])
     assert [sha(x) for x in nc["templates"].cpu().numpy()[:20]] == [str(x) for x in g["nocrop_templates_sha"]]
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_near_plane_straddlers_bit_exact_both_strategies(textured):
+    """triangles that straddle z = 0.05 (renderer.py:62-67): the camera sits INSIDE a textured / vertex-coloured cube and next to a floor
+    quad that runs from behind it to 3 m ahead — homogeneous-coordinate rasterisation, both visibility strategies, bit for bit against
+    the oracle (whose clipping is checked against the analytic answer in tests/test_golden_r2_cpu.py)"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    v, f, uv = textured_cube()
+    floor_v = np.array([[-8, 0.04, -4], [8, 0.04, -4], [8, 0.04, 12], [-8, 0.04, 12]], np.float32)
+    floor_f = np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(v)
+    floor_uv = np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], np.float32)
+    v = np.concatenate([v, floor_v])
+    f = np.concatenate([f, floor_f])
+    uv = np.concatenate([uv, floor_uv])
+    tex = checker_gradient_texture(256)
+    col = np.random.default_rng(5).integers(0, 256, size=(len(v), 3), dtype=np.uint8)
+    P = np.tile(np.eye(4, dtype=np.float32), (4, 1, 1))
+    P[:, :3, :3] = fo.generate_rotations(4)
+    P[0, :3, 3] = [0.0, 0.0, 0.10]       # camera inside the (scaled) cube: every face straddles or lies behind
+    P[1, :3, 3] = [0.05, -0.02, 0.30]    # a corner pokes through the near plane
+    P[2, :3, 3] = [0.0, 0.0, 1.10]       # the ordinary case in the same batch
+    P[3, :3, 3] = [0.3, 0.1, 0.02]
+    W = H = 420
+    kw = dict(uv=uv, texture=tex) if textured else {}
+    rgb_o, d_o = fo.rasterize(v, f, None if textured else col, P, 0.25, 600, 600, 210, 210, W, H, **kw)
+    mesh = ops.Mesh(v, f, uv=uv, texture=tex) if textured else ops.Mesh(v, f, col)
+    try:
+        for mode in (1, 0):
+            ops.set_option("raster_tiled", mode)
+            rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(P), 0.25, 600, 600, 210, 210, W, H)
+            assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32)), f"depth differs (tiled={mode})"
+            assert np.array_equal(rgb_g.cpu().numpy(), rgb_o), f"rgb differs (tiled={mode})"
+    finally:
+        ops.set_option("raster_tiled", -1)
+    assert (d_o[0] > 0).mean() > 0.5 and d_o[0][d_o[0] > 0].min() > 0.05      # something is drawn in the inside view, nothing nearer than znear
+    assert (d_o[2] > 0).mean() > 0.05

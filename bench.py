@@ -129,7 +129,7 @@ def cpu_baseline(args, mesh_arrays, bank_f32):
     def vit32():
         feats[0] = vit_ref.vit_forward(sd, x, layer=22, feature_type="patch")
     t_vit = _median_time(vit32, 2, 3)
-    t_vit_bf16 = _median_time(lambda: vit_ref.vit_forward(sd_bf, x, layer=22, feature_type="patch", dtype=torch.bfloat16), 1, 3)
+    t_vit_bf16 = _median_time(lambda: vit_ref.vit_forward(sd_bf, x, layer=22, feature_type="patch", dtype=torch.bfloat16), 2, 3)
     # bank scan + top-100: the reference's expressions on the full bank
     rf = F.normalize(torch.from_numpy(bank_f32).to(torch.bfloat16), dim=-1)
     q = F.normalize(torch.randn(1024, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16), dim=-1)
@@ -143,9 +143,7 @@ def cpu_baseline(args, mesh_arrays, bank_f32):
     v, f, c = mesh_arrays
     from freepose_amd.src.pipeline.retrieval.renderer import grid_poses
     poses = np.array(grid_poses(args.hyp))[:2].astype(np.float32)
-    t0 = time.perf_counter()
-    fo.rasterize(v, f, c, poses, 0.25, 600, 600, 210, 210, 420, 420)
-    t_raster = (time.perf_counter() - t0) / 2 * args.hyp
+    t_raster = _median_time(lambda: fo.rasterize(v, f, c, poses, 0.25, 600, 600, 210, 210, 420, 420), 1, 3) / 2 * args.hyp
     per_prop = (1 + args.hyp) * t_vit + t_scan + t_score + t_raster
     per_prop_bf16 = (1 + args.hyp) * t_vit_bf16 + t_scan + t_score + t_raster
     return {"value": 1.0 / per_prop, "unit": "proposals/s", "cores": ncores, "kind": "port",
@@ -153,7 +151,9 @@ def cpu_baseline(args, mesh_arrays, bank_f32):
             "sample": f"ViT-L/14 layer-22 forward @{args.res}^2 on {ncores} torch threads: fp32 {t_vit:.2f} s/crop, bf16 {t_vit_bf16:.2f} s/crop "
                       f"(2 warm-ups, median of 3); reference torch expressions for bank scan + top-100 over {bank_f32.shape[0]} rows "
                       f"(median of 5) and template score on {Ts} of {args.hyp} hypotheses (median of 3); 2 renders of the {len(f)}-triangle "
-                      f"mesh with the single-thread C oracle; extrapolated to 1+{args.hyp} forwards and {args.hyp} hypotheses",
+                      f"mesh with the single-thread C oracle (1 warm-up, median of 3); extrapolated to 1+{args.hyp} forwards and "
+                      f"{args.hyp} hypotheses; thread count = the fastest of 8/16/32/64/128 on a 6-block 224^2 probe, "
+                      f"{avail} logical CPUs available",
             "seconds_per_proposal": per_prop, "value_bf16": 1.0 / per_prop_bf16, "seconds_per_proposal_bf16": per_prop_bf16,
             "stage_seconds": {"vit_per_crop_fp32": t_vit, "vit_per_crop_bf16": t_vit_bf16, "bank_scan_topk": t_scan,
                               "template_score": t_score, "raster": t_raster}}
@@ -366,8 +366,9 @@ def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
         "P*D*2 bytes per crop; one crop per call here = 512 threads summing in the oracle's fixed order: latency-bound")
     add("bank_scan_topk", stage_ms.get("bank_scan_topk", 0), "hbm", args.bank * D * 2.0 * args.steps,
         f"one pass over the bf16 bank per step, shared by its Q = {args.proposals_per_step} queries; the stage is scan + exact "
-        "top-100 select (single-query select is latency-bound, ~43 us); the scan kernel alone: 15.9 us = 5.9 TB/s "
-        "(profiles/r01_scan_kernel_stats.csv)")
+        "top-100 select + merge (single-query select ~17 us, latency-bound); the scan kernel alone, measured with the bank evicted / "
+        "resident: profiles/r03_scan_cold_warm.log (18.2 us = 5.2 TB/s after a clean 1 GiB read sweep, 15.7 us = 6.0 TB/s resident in the "
+        "Infinity Cache; in this pipeline, behind the ViT's dirty activations: see the bank_scan_kernel row of profiles/r03_bench_kernel_stats.csv)")
     add("rasterize", stage_ms.get("rasterize", 0), "hbm", (H * 420 * 420 * 7.0 + n_vert * 32.0 + n_tri * 12.0) * n_prop,
         f"mandatory rgb+depth writes; {H * n_tri * n_prop / max(stage_ms.get('rasterize', 1e9), 1e-9) / 1e6:.1f} G triangle set-ups/s")
     add("depth_extents", stage_ms.get("depth_extents", 0), "hbm", H * 420 * 420 * 4.0 * n_prop, "depth read")
@@ -392,7 +393,7 @@ def csrc_hash() -> str:
 def _pmc_traffic():
     """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary (tools/profile_job.sh -> profiles/), only if that
     summary was taken on exactly these kernel sources (its csrc_sha16 equals csrc_hash()); otherwise null"""
-    for name in ("r02_gemm_pmc.json",):
+    for name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json"):
         p = ROOT / "profiles" / name
         if p.exists():
             try:

@@ -90,3 +90,22 @@ def test_vit_ref_matches_transformers_at_vitl_and_vitb_widths(model, dim, heads,
     assert rel <= 1e-4, rel                           # fp32 summation-order noise only (measured ~1e-6)
     cls = vit_ref.vit_forward(sd, x, layer=1, feature_type="cls")
     assert (cls - _hf_forward(m, x, 1)[:, 0]).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("res", [420, 518])
+def test_vit_ref_matches_transformers_full_depth_vitl(res):
+    """the bench / pipeline configuration itself: ViT-L/14-reg, the first 22 of 24 blocks + final norm (dino.py:18-23, layer = 22),
+    at 420^2 (pose estimators) and 518^2 (BASELINE metric), non-trivial LayerScale — the oracle restatement against transformers'
+    Dinov2WithRegistersModel with the same weights, all 22 blocks deep"""
+    sd = _sd("dinov2_vitl14_reg", 9)
+    g = torch.Generator().manual_seed(13)
+    for i in range(24):
+        sd[f"blocks.{i}.ls1.gamma"] = 0.05 + 0.3 * torch.rand(1024, generator=g)
+        sd[f"blocks.{i}.ls2.gamma"] = 0.05 + 0.3 * torch.rand(1024, generator=g)
+    m = _hf(sd, 1024, 24, 16, 4)
+    x = torch.rand(1, 3, res, res, generator=torch.Generator().manual_seed(3))
+    ref = _hf_forward(m, x, 22)
+    mine = vit_ref.vit_forward(sd, x, layer=22, feature_type="patch")
+    assert mine.shape == ref[:, 5:].shape == (1, (res // 14) ** 2, 1024)
+    rel = (mine - ref[:, 5:]).abs().max().item() / ref[:, 5:].abs().max().item()
+    assert rel <= 1e-4, rel

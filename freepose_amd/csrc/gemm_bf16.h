@@ -56,7 +56,7 @@ struct FpGemmArgs {
     const uint4* ln_cfrag;
     // FP_EPI_LS_RES_STATS: partial row statistics [N/64][M] (sum, sum of squares), N % 64 == 0
     float2* stat_part;
-    int dbg;   // experiment bits (FP_GEMM_DBG; wrong numerics): 2 = LN-folded kernels start from zero accumulators
+    int dbg;   // experiment bits (FP_GEMM_DBG; wrong numerics): 2 = LN-folded kernels start from zero accumulators, 8 = persistent kernels skip the epilogue
 };
 
 // Tile order shared by the GEMM kernels.  blockIdx -> logical id (XCD-contiguous, bijective) -> (tile_m, tile_n) in

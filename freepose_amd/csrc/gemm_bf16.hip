@@ -116,6 +116,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         }
     };
     int tile = blockIdx.x;
+    if constexpr ((VAR & 32) != 0) {
+        // experiment (FP_GEMM_DBG=32): stagger the resident workgroups over one tile period so that the chip's 256 epilogues (each a
+        // 128 KiB store burst) do not all hit the memory system at the same moment
+        if (p.dbg & 32) {
+            const int phase = (blockIdx.x >> 3) & 7;
+            const int n = phase * (p.K / BK) * 6;      // ~ phase/8 of a tile: a K step is ~3 000 cycles = 48 x s_sleep(1)
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+    }
     set_tile(tile, m0, n0);
     const char* gX = (const char*)p.X;
     const char* gW = (const char*)p.W;
@@ -284,8 +293,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
                     __builtin_amdgcn_s_setprio(0);
                 }
             }
+            if (p.dbg & 8) {   // measurement only (FP_GEMM_DBG=8): the main loop without its epilogue — one store keeps the accumulators live
+                if (acc[0][0][0] == 123456.789f) p.C[0] = 0;
+            } else {
             if constexpr (RELOC) epi_stage = reloc_stage((g - 1) & 1);
             fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage, smem_raw);
+            }
             if (!has_next) return;
             tile += tstride;
             m0 = m0n;

@@ -360,8 +360,14 @@ def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
 
     add("vit_linear_layers", prof["ms_gemm"], "mfma", prof["gemm_flops"], "22 x (qk, v, proj, fc1, fc2) + patch embed")
     add("vit_attention", prof["ms_attn"], "mfma", 22 * 4.0 * n_tok * n_tok * D * crops, "4 n^2 D flops per block per crop")
-    add("vit_layernorm_etc", prof["ms_other"], "hbm", (22 * 2 + 1) * 2.0 * n_tok * D * 2 * crops + 3.0 * 518 * 518 * 2 * crops,
-        "LayerNorm read+write per call, im2col, token init")
+    ln_fused = os.environ.get("FP_LN_FUSED", "1") != "0"
+    if ln_fused:   # LN1 / LN2 live in the GEMMs: what is left is the block-0 statistics pass, 43 finalisations of 16 partials, final norm, im2col
+        other_bytes = (n_tok * D * 2.0 + 43 * n_tok * (128.0 + 20.0) + 2.0 * P * D * 2 + 3.0 * args.res * args.res * 2 + P * 640 * 2.0) * crops
+        note = "LayerNorm 1/2 are folded into the GEMMs; this stage = block-0 row statistics, statistics finalisation, final norm + slice, im2col, token init"
+    else:
+        other_bytes = (22 * 2 + 1) * 2.0 * n_tok * D * 2 * crops + 3.0 * 518 * 518 * 2 * crops
+        note = "LayerNorm read+write per call, im2col, token init"
+    add("vit_layernorm_etc", prof["ms_other"], "hbm", other_bytes, note)
     add("ffa", stage_ms.get("ffa", 0), "hbm", P * D * 2.0 * n_prop,
         "P*D*2 bytes per crop; one crop per call here = 512 threads summing in the oracle's fixed order: latency-bound")
     add("bank_scan_topk", stage_ms.get("bank_scan_topk", 0), "hbm", args.bank * D * 2.0 * args.steps,

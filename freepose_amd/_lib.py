@@ -56,6 +56,7 @@ SIGNATURES = {
     "fp_mesh_set_ambient": (c_int, [c_void_p, c_float]),
     "fp_mesh_set_shading": (c_int, [c_void_p, c_int]),
     "fp_mesh_set_filter": (c_int, [c_void_p, c_int]),
+    "fp_mesh_set_cull": (c_int, [c_void_p, c_int]),
     "fp_project_vertices": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_void_p,
                                     c_void_p, c_void_p]),
     "fp_mesh_destroy": (c_int, [c_void_p]),

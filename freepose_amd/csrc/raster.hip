@@ -62,6 +62,7 @@ struct fp_mesh {
     int nlev = 0;
     uint32_t lev_off[16] = {};
     int filter = 1;            // 1 = trilinear mip-maps, 0 = bilinear level 0
+    int cull = 0;              // 1 = back faces are not drawn (renderer.py:63-66: render without SKIP_CULL_FACES), 0 = both sides
     float* tables = nullptr;   // DEC[256] sRGB->linear, THR[256] gamma-encode thresholds
     int th = 0, tw = 0;
     float kd[3] = {1.f, 1.f, 1.f};   // material diffuse factor (MTL Kd / glTF baseColorFactor)
@@ -238,6 +239,14 @@ __device__ __forceinline__ void tri_pixel(const TriSetup& t, int f, int px, int 
     atomicMin(&zb[(size_t)py * W + px], key);
 }
 
+// Back face (renderer.py:63-66, cull_faces = True -> GL_CULL_FACE with counter-clockwise front faces): in this frame (x right, y down,
+// z forward) a counter-clockwise-from-outside triangle that faces the camera has a NEGATIVE screen-space area, i.e. tri_setup swapped
+// its corners; a straddler is classified by the sign of its homogeneous determinant (same sign as the area when all w > 0).
+__device__ __forceinline__ bool back_facing(const TriSetup& t, const SVert* __restrict__ sv, const int32_t* __restrict__ faces, int f) {
+    if (t.strad) return strad_setup(sv, faces, f).det > 0.0;
+    return !t.swapped;
+}
+
 __device__ __forceinline__ void strad_pixel_global(const Strad& q, int f, int px, int py, unsigned long long* __restrict__ zb, int W) {
     float d, b0, b1, b2;
     if (!strad_pixel(q, px, py, d, b0, b1, b2)) return;
@@ -394,7 +403,7 @@ __device__ __forceinline__ void resolve_pixel(const SVert* __restrict__ sv, cons
 __global__ __launch_bounds__(256) void raster_tri_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
                                                          int V, int F, int W, int Hh,
                                                          unsigned long long* __restrict__ zb_all,
-                                                         int* __restrict__ queue, int* __restrict__ qcount, int qcap) {
+                                                         int* __restrict__ queue, int* __restrict__ qcount, int qcap, int cull) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
     if (f >= F) return;
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(256) void raster_tri_kernel(const SVert* __restrict
     unsigned long long* zb = zb_all + (size_t)h * W * Hh;
     const TriSetup t = tri_setup(sv, faces, f, W, Hh);
     if (!t.ok) return;
+    if (cull && back_facing(t, sv, faces, f)) return;
     const int area = (t.bx1 - t.bx0 + 1) * (t.by1 - t.by0 + 1);
     if (area > BIG_AREA || t.strad) {
         const int slot = atomicAdd(qcount, 1);
@@ -482,7 +492,7 @@ constexpr uint16_t TBOX_NONE = 0x000f;   // tx0 = 15 > tx1 = 0: overlaps nothing
 
 __global__ __launch_bounds__(BIN_CHUNK) void raster_bin_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
                                                                int V, int F, int W, int Hh, int T,
-                                                               uint16_t* __restrict__ tbox, unsigned long long* __restrict__ cmask) {
+                                                               uint16_t* __restrict__ tbox, unsigned long long* __restrict__ cmask, int cull) {
     __shared__ unsigned long long m_s;
     const int h = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int f = chunk * BIN_CHUNK + threadIdx.x;
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(BIN_CHUNK) void raster_bin_kernel(const SVert* __re
     if (f < F) {
         const TriSetup t = tri_setup(sv_all + (size_t)h * V, faces, f, W, Hh);
         uint16_t box = TBOX_NONE;
-        if (t.ok) {
+        if (t.ok && !(cull && back_facing(t, sv_all + (size_t)h * V, faces, f))) {
             const int tx0 = t.bx0 / T, ty0 = t.by0 / T, tx1 = t.bx1 / T, ty1 = t.by1 / T;
             box = (uint16_t)(tx0 | (ty0 << 4) | (tx1 << 8) | (ty1 << 12));
             unsigned long long m = 0ull;
@@ -773,7 +783,7 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
         unsigned long long* cmask;
         if ((rc = ctx->get("raster.tbox", (size_t)Hn * F * 2, (void**)&tbox))) return rc;
         if ((rc = ctx->get("raster.cmask", (size_t)Hn * nchunk * 8, (void**)&cmask))) return rc;
-        hipLaunchKernelGGL(raster_bin_kernel, dim3(nchunk, Hn), dim3(BIN_CHUNK), 0, s, sv, mesh->faces, V, F, W, Hh, T, tbox, cmask);
+        hipLaunchKernelGGL(raster_bin_kernel, dim3(nchunk, Hn), dim3(BIN_CHUNK), 0, s, sv, mesh->faces, V, F, W, Hh, T, tbox, cmask, mesh->cull);
         FP_LAUNCH_CHECK();
         const size_t lds = (size_t)T * T * 8 + 2048;   // visibility keys + DEC/THR tables
         FP_DYN_LDS_ONCE(raster_tile_kernel, 88 * 88 * 8 + 2048);
@@ -793,7 +803,7 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
     FP_HIP(hipMemsetAsync(zb, 0xff, (size_t)Hn * W * Hh * 8, s));
     FP_HIP(hipMemsetAsync(qcount, 0, 4, s));
     hipLaunchKernelGGL(raster_tri_kernel, dim3(cdiv(F, 256), Hn), dim3(256), 0, s, sv, mesh->faces, V, F, W, Hh, zb,
-                       queue, qcount, qcap);
+                       queue, qcount, qcap, mesh->cull);
     FP_LAUNCH_CHECK();
     hipLaunchKernelGGL(raster_big_kernel, dim3(1024), dim3(256), 0, s, sv, mesh->faces, V, W, Hh, zb, queue, qcount, qcap);
     FP_LAUNCH_CHECK();
@@ -806,6 +816,11 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
 extern "C" int fp_mesh_set_ambient(fp_mesh* mesh, float ambient) {
     FP_REQUIRE(mesh && ambient >= 0.f, "mesh_set_ambient: bad argument");
     mesh->ambient = ambient;
+    return FP_OK;
+}
+extern "C" int fp_mesh_set_cull(fp_mesh* mesh, int mode) {
+    FP_REQUIRE(mesh && (mode == 0 || mode == 1), "mesh_set_cull: mode must be 0 (both sides) or 1 (back faces culled)");
+    mesh->cull = mode;
     return FP_OK;
 }
 extern "C" int fp_mesh_set_filter(fp_mesh* mesh, int mode) {

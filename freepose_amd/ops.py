@@ -351,6 +351,11 @@ class Mesh:
         check(self.lib.fp_mesh_set_filter(self.handle, int(mode)), "fp_mesh_set_filter")
         return self
 
+    def set_cull(self, mode: int):
+        """back-face culling: 0 = both sides (default; the reference's callers), 1 = pyrender's default culling (cull_faces=True)"""
+        check(self.lib.fp_mesh_set_cull(self.handle, int(mode)), "fp_mesh_set_cull")
+        return self
+
     def set_shading(self, mode: int):
         """1 = gamma output rule (default), 0 = linear (csrc/raster.hip header)"""
         check(self.lib.fp_mesh_set_shading(self.handle, int(mode)), "fp_mesh_set_shading")

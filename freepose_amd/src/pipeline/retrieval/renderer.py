@@ -92,22 +92,23 @@ class MeshRenderer:
         self._mesh_cache = {key: (dm, sig)}  # keep one: meshes are large
         return dm
 
-    def _render(self, mesh, poses, thirds, scale=1.0) -> RenderBatch:
+    def _render(self, mesh, poses, thirds, scale=1.0, cull_faces=False) -> RenderBatch:
         poses = np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4)
-        rgb, depth = ops.rasterize(self._device_mesh(mesh), torch.from_numpy(poses), scale, self.fx, self.fy, self.cx,
-                                   self.cy, self.resolution, self.resolution)
+        dm = self._device_mesh(mesh)
+        dm.set_cull(1 if cull_faces else 0)          # reference :63-66 / :90-93: SKIP_CULL_FACES unless cull_faces
+        try:
+            rgb, depth = ops.rasterize(dm, torch.from_numpy(poses), scale, self.fx, self.fy, self.cx,
+                                       self.cy, self.resolution, self.resolution)
+        finally:
+            dm.set_cull(0)
         return RenderBatch(rgb, depth, thirds, (self.fx, self.fy, self.cx, self.cy))
 
     def render(self, mesh, cull_faces=False, scale=1.0):
-        if cull_faces:
-            raise NotImplementedError("back-face culling is never enabled by the pipeline")
-        return self._render(mesh, self.mesh_poses, self.rotations, scale)
+        return self._render(mesh, self.mesh_poses, self.rotations, scale, cull_faces)
 
     def render_from_poses(self, mesh, poses, cull_faces=False, scale=1.0):
-        if cull_faces:
-            raise NotImplementedError("back-face culling is never enabled by the pipeline")
         poses = list(poses)
-        return self._render(mesh, poses, poses, scale)
+        return self._render(mesh, poses, poses, scale, cull_faces)
 
     @staticmethod
     def mask_to_bbox(mask):

@@ -164,6 +164,9 @@ int fp_mesh_set_shading(fp_mesh* mesh, int mode);
 /* texture minification: 1 (default) = trilinear mip-maps, level of detail from the analytic UV derivatives of the fragment;
  * 0 = bilinear fetch of level 0 only.  Replaces the sampler state of pyrender's texture objects (renderer.py:43-47,70-74). */
 int fp_mesh_set_filter(fp_mesh* mesh, int mode);
+/* back-face culling: 0 (default, what every caller of the reference uses: renderer.py:66,93 pass SKIP_CULL_FACES) = both sides drawn;
+ * 1 = `cull_faces=True` (renderer.py:63-64,90-91): triangles whose counter-clockwise-from-outside side faces away are not drawn. */
+int fp_mesh_set_cull(fp_mesh* mesh, int mode);
 /* vertex stage of the rasteriser alone: window coordinates in 24.8 fixed point d_xy i32 [Hn,V,2] (x right, y down, pixel
  * centres at +0.5; 0,0 for vertices at or behind the near plane) and camera-frame depth d_zc f32 [Hn,V].  Conventions pinned
  * against the reference's K -> OpenGL projection (bop_toolkit_lib/renderer_py.py:186-231, renderer.py:37-41). */

@@ -515,11 +515,11 @@ static float log2p(float t) {
 void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
                        const float* uv /* [F,3,2] or NULL */, const uint8_t* tex /* [th,tw,3] or NULL */, int th, int tw,
                        const float* kd3 /* or NULL = 1,1,1 */, const float* poses, int Hn, float scale, float fx, float fy,
-                       float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade, int filter);
+                       float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade, int filter, int cull);
 void fpo_rasterize_amb(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors /* [V,3] or NULL */,
                        const float* poses, int Hn, float scale, float fx, float fy, float cx, float cy, int W, int Hh,
                        uint8_t* rgb, float* depth, float ambient) {
-    fpo_rasterize_tex(verts, V, faces, F, colors, NULL, NULL, 0, 0, NULL, poses, Hn, scale, fx, fy, cx, cy, W, Hh, rgb, depth, ambient, 0, 0);
+    fpo_rasterize_tex(verts, V, faces, F, colors, NULL, NULL, 0, 0, NULL, poses, Hn, scale, fx, fy, cx, cy, W, Hh, rgb, depth, ambient, 0, 0, 0);
 }
 
 /* vertex stage alone: fixed-point 24.8 window coordinates (image convention: x right, y down, pixel centres at +0.5) and the
@@ -550,7 +550,8 @@ void fpo_project_vertices(const float* verts, int V, const float* poses, int Hn,
 
 void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, const uint8_t* colors, const float* uv,
                        const uint8_t* tex, int th, int tw, const float* kd3, const float* poses, int Hn, float scale, float fx,
-                       float fy, float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade, int filter) {
+                       float fy, float cx, float cy, int W, int Hh, uint8_t* rgb, float* depth, float ambient, int shade, int filter,
+                       int cull /* 1: back faces (renderer.py:63-66 without SKIP_CULL_FACES) are not drawn */) {
     const float ZNEAR = 0.05f;
     const int textured = uv && tex && th > 0 && tw > 0;
     int nlev = 0, lw[FPO_MAX_LEV], lh[FPO_MAX_LEV];
@@ -584,6 +585,7 @@ void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, c
             const int nfront = (a.zc > ZNEAR) + (b.zc > ZNEAR) + (c.zc > ZNEAR);
             if (nfront == 1 || nfront == 2) {   /* straddles the near plane: homogeneous rasterisation over the whole frame */
                 strad_t q; strad_setup(&a, &b, &c, &q);
+                if (cull && q.det > 0.0) continue;             /* back face: same sign convention as the screen-space area below */
                 for (int py = 0; py < Hh; ++py)
                     for (int px = 0; px < W; ++px) {
                         float d, b0, b1, b2;
@@ -596,6 +598,8 @@ void fpo_rasterize_tex(const float* verts, int V, const int32_t* faces, int F, c
             }
             if (nfront != 3) continue;
             int64_t area2 = (int64_t)(b.xi - a.xi) * (c.yi - a.yi) - (int64_t)(b.yi - a.yi) * (c.xi - a.xi);
+            /* x right, y down, z forward: a counter-clockwise-from-outside triangle that faces the camera has NEGATIVE area here */
+            if (cull && area2 > 0) continue;
             if (area2 < 0) { svert_t t = b; b = c; c = t; area2 = -area2; }
             if (area2 == 0) continue;
             int mnx = a.xi < b.xi ? a.xi : b.xi; if (c.xi < mnx) mnx = c.xi;

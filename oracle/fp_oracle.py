@@ -196,7 +196,7 @@ def roi_align(images: np.ndarray, rois: np.ndarray, ph: int, pw: int, sampling_r
 
 
 def rasterize(verts, faces, colors, poses, scale, fx, fy, cx, cy, W, H, ambient: float = 2.0, shade: int = 1, uv=None, texture=None,
-              kd=None, filter: int = 1):
+              kd=None, filter: int = 1, cull: int = 0):
     """colors u8 [V,3] | None; uv f32 [F,3,2] + texture u8 [th,tw,3] select the textured path; shade 1 = gamma rule, 0 = linear;
     filter 1 = trilinear mip-maps (default), 0 = bilinear level 0"""
     v = np.ascontiguousarray(verts, dtype=np.float32)
@@ -213,7 +213,7 @@ def rasterize(verts, faces, colors, poses, scale, fx, fy, cx, cy, W, H, ambient:
     depth = np.empty((Hn, H, W), dtype=np.float32)
     lib().fpo_rasterize_tex(_p(v), C.c_int(v.shape[0]), _p(f), C.c_int(f.shape[0]), _p(c), _p(t), _p(x), C.c_int(th), C.c_int(tw),
                             _p(k), _p(p), C.c_int(Hn), C.c_float(scale), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
-                            C.c_int(W), C.c_int(H), _p(rgb), _p(depth), C.c_float(ambient), C.c_int(shade), C.c_int(filter))
+                            C.c_int(W), C.c_int(H), _p(rgb), _p(depth), C.c_float(ambient), C.c_int(shade), C.c_int(filter), C.c_int(cull))
     return rgb, depth
 
 

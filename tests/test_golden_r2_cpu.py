@@ -288,3 +288,57 @@ def test_near_plane_clipping_known_answers():
     v2 = v.copy()
     v2[:, 2] = [-3, -3, -0.5, -0.5]
     assert not (fo.rasterize(v2, f, col, pose, 1.0, fx, fy, cx, cy, W, H)[1] > 0).any()
+
+
+def test_back_face_culling_known_answers():
+    """renderer.py:63-66 / :90-93: `cull_faces=True` drops pyrender's SKIP_CULL_FACES flag, so OpenGL's default culling applies
+    (front = counter-clockwise seen from outside).  Known answers: a closed, outward-wound box seen from outside renders the same
+    with and without culling; a single triangle is drawn from its front side only; the near-plane path (homogeneous rasterisation)
+    uses the same sign as the ordinary path."""
+    from oracle import fp_oracle as fo
+    from tests._meshes import textured_cube
+    W = H = 128
+    fx = fy = 200.0
+    cx = cy = 64.0
+    v, f, _ = textured_cube()
+    f = f[:, ::-1].copy()                                     # the test cube is wound inwards; make it outward (CCW from outside)
+    n = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    assert ((n * (v[f].mean(1) - v.mean(0))).sum(1) > 0).all()
+    col = (np.arange(v.shape[0] * 3).reshape(-1, 3) * 9 % 256).astype(np.uint8)
+    poses = []
+    rng = np.random.Generator(np.random.PCG64(4))
+    from scipy.spatial.transform import Rotation as Rot
+    for _ in range(6):
+        P = np.eye(4, dtype=np.float32)
+        P[:3, :3] = Rot.random(random_state=int(rng.integers(1 << 30))).as_matrix()
+        P[:3, 3] = [0.0, 0.0, 4.0]
+        poses.append(P)
+    poses = np.array(poses)
+    a = fo.rasterize(v, f, col, poses, 1.0, fx, fy, cx, cy, W, H)
+    b = fo.rasterize(v, f, col, poses, 1.0, fx, fy, cx, cy, W, H, cull=1)
+    assert (a[1] > 0).sum() > 1000
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # the same box with every face reversed: only the far inside walls would be front-facing -> a different (deeper) image
+    c = fo.rasterize(v, f[:, ::-1].copy(), col, poses, 1.0, fx, fy, cx, cy, W, H, cull=1)
+    assert np.array_equal(c[1] > 0, a[1] > 0) and (c[1][a[1] > 0] >= a[1][a[1] > 0]).all() and (c[1] > a[1]).any()
+    # one triangle, camera looks down +z with y down: (0,0) (1,0) (0,1) at z = 2 runs clockwise on screen as seen by the camera, i.e.
+    # counter-clockwise from BEHIND: it is a back face; reversed it is a front face
+    tri = np.array([[0, 0, 2], [0.5, 0, 2], [0, 0.5, 2]], np.float32)
+    one = np.array([[0, 1, 2]], np.int32)
+    eye = np.eye(4, dtype=np.float32)[None]
+    tc = np.full((3, 3), 200, np.uint8)
+    assert (fo.rasterize(tri, one, tc, eye, 1.0, fx, fy, cx, cy, W, H)[1] > 0).sum() > 500
+    assert not (fo.rasterize(tri, one, tc, eye, 1.0, fx, fy, cx, cy, W, H, cull=1)[1] > 0).any()
+    assert (fo.rasterize(tri, one[:, ::-1].copy(), tc, eye, 1.0, fx, fy, cx, cy, W, H, cull=1)[1] > 0).sum() > 500
+    # floor strip under the camera, split into a part that straddles the near plane and a part that does not: one winding, one verdict
+    y0 = 0.05
+    fl = np.array([[-1, y0, -1], [1, y0, -1], [1, y0, 1], [-1, y0, 1], [1, y0, 3], [-1, y0, 3]], np.float32)
+    quads = np.array([[0, 1, 2], [0, 2, 3], [3, 2, 4], [3, 4, 5]], np.int32)
+    fc = np.full((6, 3), 180, np.uint8)
+    full = fo.rasterize(fl, quads, fc, eye, 1.0, fx, fy, cx, cy, W, H)[1] > 0
+    near_part = fo.rasterize(fl, quads[:2], fc, eye, 1.0, fx, fy, cx, cy, W, H)[1] > 0
+    far_part = fo.rasterize(fl, quads[2:], fc, eye, 1.0, fx, fy, cx, cy, W, H)[1] > 0
+    assert near_part.sum() > 500 and far_part.sum() > 100
+    seen = [(fo.rasterize(fl, q, fc, eye, 1.0, fx, fy, cx, cy, W, H, cull=1)[1] > 0) for q in (quads, quads[:, ::-1].copy())]
+    assert sorted([int(s.sum()) for s in seen]) == [0, int(full.sum())]
+    assert np.array_equal(seen[0] | seen[1], full)

@@ -251,3 +251,71 @@ def test_near_plane_straddlers_bit_exact_both_strategies(textured):
         ops.set_option("raster_tiled", -1)
     assert (d_o[0] > 0).mean() > 0.5 and d_o[0][d_o[0] > 0].min() > 0.05      # something is drawn in the inside view, nothing nearer than znear
     assert (d_o[2] > 0).mean() > 0.05
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_back_face_culling_bit_exact_both_strategies(textured):
+    """`cull_faces=True` (renderer.py:63-66, :90-93): same scene as the straddler test (so that both the ordinary and the homogeneous
+    path decide facing), both visibility strategies, bit for bit against the oracle; then the MeshRenderer wrapper: a closed
+    outward-wound box renders the same either way and the flag does not stick to the cached device mesh."""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    v, f, uv = textured_cube()
+    floor_v = np.array([[-8, 0.04, -4], [8, 0.04, -4], [8, 0.04, 12], [-8, 0.04, 12]], np.float32)
+    floor_f = np.array([[0, 1, 2], [0, 2, 3]], np.int32) + len(v)
+    floor_uv = np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], np.float32)
+    v = np.concatenate([v, floor_v])
+    f = np.concatenate([f, floor_f])
+    uv = np.concatenate([uv, floor_uv])
+    tex = checker_gradient_texture(256)
+    col = np.random.default_rng(5).integers(0, 256, size=(len(v), 3), dtype=np.uint8)
+    P = np.tile(np.eye(4, dtype=np.float32), (6, 1, 1))
+    P[:, :3, :3] = fo.generate_rotations(6)
+    P[0, :3, 3] = [0.0, 0.0, 0.10]
+    P[1, :3, 3] = [0.05, -0.02, 0.30]
+    P[2, :3, 3] = [0.0, 0.0, 1.10]
+    P[3, :3, 3] = [0.3, 0.1, 0.02]
+    P[4, :3, 3] = [0.1, 0.0, 0.9]
+    P[5, :3, 3] = [-0.2, 0.1, 1.5]
+    W = H = 420
+    kw = dict(uv=uv, texture=tex) if textured else {}
+    differs = 0
+    for faces in (f, f[:, ::-1].copy()):
+        uvf = uv[:, ::-1].copy() if faces is not f else uv
+        kwf = dict(uv=uvf, texture=tex) if textured else {}
+        rgb_o, d_o = fo.rasterize(v, faces, None if textured else col, P, 0.25, 600, 600, 210, 210, W, H, cull=1, **kwf)
+        rgb_n, d_n = fo.rasterize(v, faces, None if textured else col, P, 0.25, 600, 600, 210, 210, W, H, **kwf)
+        differs += int((d_o != d_n).sum())
+        mesh = (ops.Mesh(v, faces, uv=uvf, texture=tex) if textured else ops.Mesh(v, faces, col)).set_cull(1)
+        try:
+            for mode in (1, 0):
+                ops.set_option("raster_tiled", mode)
+                rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(P), 0.25, 600, 600, 210, 210, W, H)
+                assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32)), f"depth differs (tiled={mode})"
+                assert np.array_equal(rgb_g.cpu().numpy(), rgb_o), f"rgb differs (tiled={mode})"
+            mesh.set_cull(0)
+            rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(P), 0.25, 600, 600, 210, 210, W, H)
+            assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_n.view(np.uint32))
+            assert np.array_equal(rgb_g.cpu().numpy(), rgb_n)
+        finally:
+            ops.set_option("raster_tiled", -1)
+        assert (d_o > 0).sum() > 10000
+    assert differs > 10000                       # culling removed something in these views (inside views, the floor from below)
+
+
+def test_mesh_renderer_cull_faces():
+    """the reference's MeshRenderer.render / render_from_poses keyword (renderer.py:56, :83)"""
+    from freepose_amd import ops
+    from freepose_amd.src.pipeline.retrieval.renderer import MeshRenderer
+    v, f, _ = textured_cube()                                        # wound inwards (tests/test_golden_r2_cpu.py)
+    v = v * np.array([1.0, 0.7, 0.45], np.float32)
+    col = np.random.default_rng(2).integers(0, 255, size=(len(v), 3), dtype=np.uint8)
+    outward, inward = ops.Mesh(v, f[:, ::-1].copy(), col), ops.Mesh(v, f, col)
+    r = MeshRenderer(n_poses=8, resolution=224)
+    a = r.render(outward, scale=0.25)
+    b = r.render(outward, cull_faces=True, scale=0.25)
+    assert torch.equal(a.depth, b.depth) and torch.equal(a.rgb, b.rgb) and int((a.depth > 0).sum()) > 1000
+    c = r.render_from_poses(inward, r.mesh_poses, cull_faces=True, scale=0.25)      # only the far inside walls face the camera
+    d = r.render_from_poses(inward, r.mesh_poses, scale=0.25)                       # the flag does not stick to the device mesh
+    assert torch.equal(d.depth, a.depth)
+    assert torch.equal(c.depth > 0, a.depth > 0) and bool((c.depth > a.depth).any()) and not bool((c.depth < a.depth).any())

@@ -28,6 +28,7 @@ extern "C" int fp_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_slots")) g_opts[FP_OPT_ATTN_SLOTS] = value;
     else if (!strcmp(name, "raster_tiled")) g_opts[FP_OPT_RASTER_TILED] = value;
     else if (!strcmp(name, "ln_fused")) g_opts[FP_OPT_LN_FUSED] = value;
+    else if (!strcmp(name, "gemm_dbg")) g_opts[FP_OPT_GEMM_DBG] = value;   // measurement hooks (FP_GEMM_DBG bits), for in-process A/B
     else { fp_set_error("set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
     return FP_OK;
 }

@@ -203,5 +203,5 @@ void fp_set_error(const char* fmt, ...);
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // experiment toggles (fp_set_option in the C ABI); a value < 0 means "use the built-in default"
-enum { FP_OPT_GEMM_VARIANT = 0, FP_OPT_ATTN_SLOTS = 1, FP_OPT_RASTER_TILED = 2, FP_OPT_LN_FUSED = 3, FP_OPT_COUNT = 8 };
+enum { FP_OPT_GEMM_VARIANT = 0, FP_OPT_ATTN_SLOTS = 1, FP_OPT_RASTER_TILED = 2, FP_OPT_LN_FUSED = 3, FP_OPT_GEMM_DBG = 4, FP_OPT_COUNT = 8 };
 int fp_opt_get(int key, int dflt);

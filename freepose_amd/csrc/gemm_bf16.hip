@@ -469,7 +469,7 @@ int fp_gemm_gelu_table(const uint16_t** out) {
 int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
     FpGemmArgs a = a_in;
     static const int dbg_env = [] { const char* e = getenv("FP_GEMM_DBG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg_env;
+    a.dbg = fp_opt_get(FP_OPT_GEMM_DBG, dbg_env);
     if (epi == FP_EPI_BIAS_GELU || epi == FP_EPI_LN_GELU) {
         const int rc = fp_gemm_gelu_table(&a.gelu_tab);
         if (rc != FP_OK) return rc;

@@ -54,16 +54,30 @@ def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, 
         boxes = torch.from_numpy(np.stack([np.array(p["bbox"]) for p in sp]))
         boxes[:, 2:] += boxes[:, :2]
         proposals = Proposals(img, {"boxes": boxes, "masks": masks}, 420, bbox_extend=args.bbox_extend)
+        outs = {}
+        with torch.inference_mode():
+            if rescoring:
+                # objects that already have a pose: ONE batched render-and-compare step for the whole frame (the reference visits
+                # them one by one, :124-156; they are independent, and the batched ViT call returns the same bits per crop)
+                many = [o for o in obj_ids if prev[o] is not None]
+                if many:
+                    items = [dict(proposal=proposals.proposals[o], proposal_mask=proposals.proposals_masks[o],
+                                  template_dict=templates.get_template_by_name(mesh_ids[o]), mesh=meshes[o], K=K, bbox=boxes[o],
+                                  est_scale=scales[o], prev_pose=prev[o]) for o in many]
+                    for o, out in zip(many, model.forward_fine_many(items, neighborhood=15, layer=args.layer)):
+                        outs[o] = out
+                for o in obj_ids:
+                    if o not in outs:     # first frame visited: coarse estimate, then the fine step (prev_pose None)
+                        outs[o] = model(proposals.proposals[o], proposals.proposals_masks[o], templates.get_template_by_name(mesh_ids[o]),
+                                        meshes[o], K, boxes[o], scales[o], prev_pose=None, neighborhood=15, layer=args.layer,
+                                        batch_size=args.batch_size)
+                    prev[o] = outs[o]["TCO"][0]
+            else:
+                for o in obj_ids:
+                    outs[o] = model(proposals.proposals[o], templates.get_template_by_name(mesh_ids[o]), K, boxes[o], scales[o],
+                                    layer=args.layer, batch_size=args.batch_size)
         for o in obj_ids:
-            entry = templates.get_template_by_name(mesh_ids[o])
-            with torch.inference_mode():
-                if rescoring:
-                    out = model(proposals.proposals[o], proposals.proposals_masks[o], entry, meshes[o], K, boxes[o], scales[o],
-                                prev_pose=prev[o], neighborhood=15, layer=args.layer, batch_size=args.batch_size)
-                    prev[o] = out["TCO"][0]
-                else:
-                    out = model(proposals.proposals[o], entry, K, boxes[o], scales[o], layer=args.layer, batch_size=args.batch_size)
-            rows.append((f, o, float(out["scores"][0]), out["TCO"][0], boxes[o].numpy()))
+            rows.append((f, o, float(outs[o]["scores"][0]), outs[o]["TCO"][0], boxes[o].numpy()))
     return rows
 
 

@@ -52,36 +52,65 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
 
     def forward_fine(self, proposal, proposal_mask, template_dict, mesh, K, bbox, est_scale, prev_pose, neighborhood=15,
                      layer=22, mask_scores=False, query_feat=None):
-        close = ops.geodesic_select(self._fine_rots_dev, np.asarray(prev_pose)[:3, :3], float(neighborhood))
-        if len(close) == 0:
-            raise RuntimeError("no fine-grid rotation within the neighbourhood of the previous pose")
-        selected = self.fine_mesh_poses[close]
-        renders = self.renderer.render_from_poses(mesh, selected, scale=self.rendering_scale)
-        crops, poses, masks, ext = MeshRenderer.generate_proposals(renders, out_bf16=True, return_extents=True, need_masks=mask_scores)
-        if query_feat is None and tuple(proposal.shape[-2:]) == tuple(crops.shape[-2:]):
+        item = dict(proposal=proposal, proposal_mask=proposal_mask, template_dict=template_dict, mesh=mesh, K=K, bbox=bbox,
+                    est_scale=est_scale, prev_pose=prev_pose, query_feat=query_feat)
+        return self.forward_fine_many([item], neighborhood, layer, mask_scores)[0]
+
+    def forward_fine_many(self, items, neighborhood=15, layer=22, mask_scores=False):
+        """The render-and-compare step (reference :43-96) for SEVERAL (frame, object) pairs at once — the objects of one video
+        frame, which the reference visits one after the other (scripts/dino_inference_video.py:124-156) and which do not depend on
+        each other.  Each object is rendered from its own mesh at its own neighbour poses; all hypothesis crops and all query crops
+        then go through ONE ViT call (a crop's features do not depend on its batch neighbours — bit-exact, tested — and ~20-crop
+        batches leave the 256-CU GEMM grids a third empty), every object is scored against its own query, and the winners of all
+        objects return in ONE device -> host copy.  `items`: dicts with proposal, proposal_mask, template_dict, mesh, K, bbox,
+        est_scale, prev_pose and optionally query_feat (frame 0: the coarse estimator's un-normalised query, reference :40-41).
+        Returns one reference-style result dict per item, identical to calling `forward_fine` per item."""
+        work, pieces = [], []
+        for it in items:
+            close = ops.geodesic_select(self._fine_rots_dev, np.asarray(it["prev_pose"])[:3, :3], float(neighborhood))
+            if len(close) == 0:
+                raise RuntimeError("no fine-grid rotation within the neighbourhood of the previous pose")
+            selected = self.fine_mesh_poses[close]
+            renders = self.renderer.render_from_poses(it["mesh"], selected, scale=self.rendering_scale)
+            crops, poses, masks, ext = MeshRenderer.generate_proposals(renders, out_bf16=True, return_extents=True,
+                                                                       need_masks=mask_scores)
+            proposal, query_feat = it["proposal"], it.get("query_feat")
             # the query crop rides in the same ViT batch as the hypothesis crops: a separate B = 1 forward is launch-bound
-            # (~2.5 ms of a ~19 ms step) and a crop's features do not depend on its batch neighbours (bit-exact, tested)
-            both = torch.cat([torch.as_tensor(proposal)[None].to(crops.device, crops.dtype), crops], dim=0)
-            both_feats = self.feature_extractor(both, layer=layer, feature_type="patch")
-            query_feat, feats = ops.l2_normalize(both_feats[:1]), both_feats[1:]
-        else:
-            if query_feat is None:
+            # (~2.5 ms of a ~19 ms step)
+            rides = query_feat is None and tuple(proposal.shape[-2:]) == tuple(crops.shape[-2:])
+            if rides:
+                pieces.append(torch.as_tensor(proposal)[None].to(crops.device, crops.dtype))
+            elif query_feat is None:
                 query_feat = ops.l2_normalize(self.feature_extractor(proposal[None], layer=layer, feature_type="patch"))
-            feats = self.feature_extractor(crops, layer=layer, feature_type="patch")
-        q = query_feat.reshape(-1, query_feat.shape[-1])
-        weights = None
-        if mask_scores:
-            m = torch.logical_or(masks, torch.as_tensor(proposal_mask).to(masks.device)[None]).float()
-            g = int(round(feats.shape[1] ** 0.5))
-            weights = torch.nn.functional.interpolate(m[None], size=(g, g), mode="bilinear")[0].reshape(len(close), -1)
-        scores = ops.template_score(feats, q, weights)
-        # max / argmax (first maximum): canonical (score desc, index asc)
-        idx_all = torch.arange(len(close), dtype=torch.int32, device=scores.device)
-        top_s, top_i = ops.topk_merge(scores[None], idx_all[None], 1)
-        # winner index, its score and its two cloud extents come back in ONE device -> host copy (the score is a bf16 value held
-        # in fp32, the index is small: both are exact in float64)
-        packed = torch.cat([top_i[0, :1].double(), top_s[0, :1].double(), ext[top_i[0, 0].long(), 4:6].double()]).cpu().numpy()
-        top = int(packed[0])
-        ratio = float(est_scale) / 0.25
-        TCO = z_from_extents(bbox, packed[2] * ratio, packed[3] * ratio, K, poses[top])
-        return {"TCO": [TCO], "scores": [np.float32(packed[1])], "proposal": proposal, "K": K, "bbox": bbox}
+            pieces.append(crops)
+            work.append(dict(n=len(close), poses=poses, masks=masks, ext=ext, rides=rides, query_feat=query_feat))
+        feats_all = self.feature_extractor(pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=0), layer=layer,
+                                           feature_type="patch")
+        at, packed = 0, []
+        for it, w in zip(items, work):
+            if w["rides"]:
+                w["query_feat"] = ops.l2_normalize(feats_all[at:at + 1])
+                at += 1
+            feats = feats_all[at:at + w["n"]]
+            at += w["n"]
+            q = w["query_feat"].reshape(-1, w["query_feat"].shape[-1])
+            weights = None
+            if mask_scores:
+                m = torch.logical_or(w["masks"], torch.as_tensor(it["proposal_mask"]).to(w["masks"].device)[None]).float()
+                g = int(round(feats.shape[1] ** 0.5))
+                weights = torch.nn.functional.interpolate(m[None], size=(g, g), mode="bilinear")[0].reshape(w["n"], -1)
+            scores = ops.template_score(feats, q, weights)
+            # max / argmax (first maximum): canonical (score desc, index asc)
+            idx_all = torch.arange(w["n"], dtype=torch.int32, device=scores.device)
+            top_s, top_i = ops.topk_merge(scores[None], idx_all[None], 1)
+            # winner index, its score and its two cloud extents (the score is a bf16 value held in fp32, the index is small: both
+            # are exact in float64)
+            packed.append(torch.cat([top_i[0, :1].double(), top_s[0, :1].double(), w["ext"][top_i[0, 0].long(), 4:6].double()]))
+        packed = torch.stack(packed).cpu().numpy()          # ONE device -> host copy for all objects of the frame
+        outs = []
+        for it, w, pk in zip(items, work, packed):
+            top = int(pk[0])
+            ratio = float(it["est_scale"]) / 0.25
+            TCO = z_from_extents(it["bbox"], pk[2] * ratio, pk[3] * ratio, it["K"], w["poses"][top])
+            outs.append({"TCO": [TCO], "scores": [np.float32(pk[1])], "proposal": it["proposal"], "K": it["K"], "bbox": it["bbox"]})
+        return outs

@@ -80,6 +80,7 @@ class MeshRenderer:
         self.cx = self.cy = resolution / 2
         self.opencv2opengl = np.diag([1.0, -1.0, -1.0, 1.0])  # kept for API parity; the rasteriser works in the OpenCV frame
         self._mesh_cache = {}
+        self.mesh_cache_size = 8
 
     def _device_mesh(self, mesh) -> ops.Mesh:
         if isinstance(mesh, ops.Mesh):
@@ -87,9 +88,13 @@ class MeshRenderer:
         key, sig = id(mesh), mesh_signature(mesh)
         hit = self._mesh_cache.get(key)
         if hit is not None and hit[1] == sig:
+            self._mesh_cache[key] = self._mesh_cache.pop(key)         # most recently used last
             return hit[0]
         dm = device_mesh(mesh)
-        self._mesh_cache = {key: (dm, sig)}  # keep one: meshes are large
+        self._mesh_cache.pop(key, None)
+        self._mesh_cache[key] = (dm, sig)
+        while len(self._mesh_cache) > self.mesh_cache_size:           # the objects of a video frame alternate: keep a few resident
+            self._mesh_cache.pop(next(iter(self._mesh_cache)))
         return dm
 
     def _render(self, mesh, poses, thirds, scale=1.0, cull_faces=False) -> RenderBatch:

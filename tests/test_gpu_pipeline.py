@@ -135,6 +135,27 @@ def test_online_estimator_recovers_planted_pose(tmp_path):
     # mask-weighted scoring variant runs and still finds the pose
     out2 = est.forward_fine(crops[0].float(), masks[0], None, mesh, K, bbox, 0.25, est.fine_mesh_poses[nb], mask_scores=True)
     assert np.allclose(out2["TCO"][0][:3, :3], true_pose[:3, :3])
+    # the objects of a frame in ONE batched step (scripts.dino_inference_video): three items — another planted pose, a second
+    # mesh, the mask-free first item again — give exactly the results of three separate steps
+    from tests._meshes import textured_cube
+    from freepose_amd.mesh_io import TriMesh
+    v2, f2, _ = textured_cube()
+    mesh2 = TriMesh(v2 * np.array([1.0, 0.6, 0.4], np.float32), f2, np.random.default_rng(3).integers(0, 255, size=(len(v2), 3), dtype=np.uint8))
+    items = []
+    for (msh, j, k) in ((mesh, 7777, 3), (mesh2, 1234, 2), (mesh, 15000, 4)):
+        tp = est.fine_mesh_poses[j]
+        rj = est.renderer.render_from_poses(msh, [tp], scale=0.25)
+        cj, _, mj, ej = MeshRenderer.generate_proposals(rj, return_extents=True)
+        dj = DinoOnlinePoseEstimator.geodesic_distance(est.fine_mesh_poses[:, :3, :3], tp)
+        ee = ej[0].cpu().numpy()
+        items.append(dict(proposal=cj[0].float(), proposal_mask=mj[0], template_dict=None, mesh=msh, K=K,
+                          bbox=torch.tensor([int(ee[0]), int(ee[1]), int(ee[2]), int(ee[3])]), est_scale=0.25,
+                          prev_pose=est.fine_mesh_poses[np.argsort(dj)[k]]))
+    many = est.forward_fine_many(items)
+    for it, got in zip(items, many):
+        one = est.forward_fine(it["proposal"], it["proposal_mask"], None, it["mesh"], K, it["bbox"], 0.25, it["prev_pose"])
+        assert np.array_equal(got["TCO"][0], one["TCO"][0]) and got["scores"][0] == one["scores"][0]
+    assert np.allclose(many[1]["TCO"][0][:3, :3], est.fine_mesh_poses[1234][:3, :3])
 
 
 def _png(arr, mode):

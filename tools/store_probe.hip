@@ -66,5 +66,17 @@ int main() {
         run<5>("plain 2 x dwordx2", buf, ncu, iters, ld_words);
         (void)hipFree(buf);
     }
+    // per-CU limit or memory-side limit?  the same 8-tile stream from fewer workgroups (one per CU, spread over the XCDs by the dispatcher)
+    for (int g : {8, 32, 64, 128}) {
+        const int iters = 8, ld_words = 512;
+        uint32_t* buf;
+        if (hipMalloc((void**)&buf, (size_t)g * iters * 256 * ld_words * 4) != hipSuccess) return 2;
+        char name[64];
+        snprintf(name, sizeof name, "plain dwordx4, %d workgroups", g);
+        run<0>(name, buf, g, iters, ld_words);
+        snprintf(name, sizeof name, "nontemporal dwordx4, %d workgroups", g);
+        run<1>(name, buf, g, iters, ld_words);
+        (void)hipFree(buf);
+    }
     return 0;
 }

@@ -31,21 +31,30 @@ def main():
         e = ext[0].cpu().numpy()
         bbox = torch.tensor([int(e[0]), int(e[1]), int(e[2]), int(e[3])])
         prev = est.fine_mesh_poses[np.argsort(DinoOnlinePoseEstimator.geodesic_distance(est.fine_mesh_poses[:, :3, :3], pose))[3]]
-        for neighborhood in (15, 25):
-            n_nb = len(ops.geodesic_select(est._fine_rots_dev, np.asarray(prev)[:3, :3], float(neighborhood)))
-            p = prev
-            for _ in range(3):
-                p = est.forward_fine(crops[0].float(), masks[0], None, mesh, K, bbox, 0.25, p, neighborhood=neighborhood)["TCO"][0]
-            torch.cuda.synchronize()
-            n = 20
-            t0 = time.perf_counter()
-            p = prev
-            for _ in range(n):
-                p = est.forward_fine(crops[0].float(), masks[0], None, mesh, K, bbox, 0.25, p, neighborhood=neighborhood)["TCO"][0]
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / n
-            print(f"video step (ViT-L @420^2 crops, 81 920-triangle mesh), neighbourhood {neighborhood} deg = {n_nb} hypotheses at the "
-                  f"start pose: {dt * 1e3:.2f} ms per (frame, object) = {1 / dt:.1f} frame-objects/s per GPU", flush=True)
+        import os
+        objs = [int(x) for x in os.environ.get("VIDEO_OBJECTS", "1").split(",")]
+        for n_obj in objs:
+            meshes = [mesh] + [TriMesh(v, f, c) for _ in range(n_obj - 1)]
+            for neighborhood in ((15, 25) if n_obj == 1 else (15,)):
+                n_nb = len(ops.geodesic_select(est._fine_rots_dev, np.asarray(prev)[:3, :3], float(neighborhood)))
+
+                def step(ps):
+                    items = [dict(proposal=crops[0].float(), proposal_mask=masks[0], template_dict=None, mesh=meshes[o], K=K, bbox=bbox,
+                                  est_scale=0.25, prev_pose=ps[o]) for o in range(n_obj)]
+                    return [r["TCO"][0] for r in est.forward_fine_many(items, neighborhood=neighborhood)]
+                ps = [prev] * n_obj
+                for _ in range(3):
+                    ps = step(ps)
+                torch.cuda.synchronize()
+                n = 20
+                t0 = time.perf_counter()
+                ps = [prev] * n_obj
+                for _ in range(n):
+                    ps = step(ps)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n / n_obj
+                print(f"video step (ViT-L @420^2 crops, 81 920-triangle mesh), {n_obj} object(s) per frame, neighbourhood {neighborhood} deg = "
+                      f"{n_nb} hypotheses at the start pose: {dt * 1e3:.2f} ms per (frame, object) = {1 / dt:.1f} frame-objects/s per GPU", flush=True)
 
 
 if __name__ == "__main__":

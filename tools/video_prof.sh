@@ -13,8 +13,10 @@ python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-nfr = 2 * (3 + 20)      # two neighbourhoods x (3 warm-up + 20 timed) frames
-print(f"sum of kernel time per frame: {tot / nfr / 1e6:.2f} ms over {nfr} frames")
+import os
+nobj = [int(x) for x in os.environ.get("VIDEO_OBJECTS", "1").split(",")]
+nfr = sum((2 if n == 1 else 1) * (3 + 20) * n for n in nobj)      # frame-objects: (3 warm-up + 20 timed) frames per setting
+print(f"sum of kernel time per frame-object: {tot / nfr / 1e6:.2f} ms over {nfr} frame-objects")
 for r in rows[:16]:
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:60]
     print(f"  {n:60s} calls/frame={int(r['Calls']) / nfr:6.1f} avg_us={float(r['AverageNs'])/1e3:8.1f} ms/frame={float(r['TotalDurationNs']) / nfr / 1e6:7.3f}")

@@ -70,7 +70,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    char* epi_stage = smem + 2 * STAGE + wave * fp_gemm::EPI_STAGE_BYTES;   // row-coalescing slab of the epilogue
+    // The epilogue's row-coalescing slabs are a STATIC shared array of their own: the K-tile buffers are filled by LDS-DMA, and for LDS
+    // accesses that may alias a DMA destination hipcc waits until the copy has landed (vmcnt(0)) — carved out of the same dynamic
+    // array, the slabs made the first ds_write of every epilogue wait for the next tile's prefetch.  Distinct LDS variables carry
+    // no-alias scopes through the LDS lowering.  (The table-GELU kernels declare none: their slabs live in a K-tile buffer, and
+    // their table must sit at LDS address 0.)
+    char* epi_stage = nullptr;                                              // row-coalescing slab of the epilogue
+    if constexpr (!RELOC) {
+        __shared__ __attribute__((aligned(1024))) char slab_mem[NW * fp_gemm::EPI_STAGE_BYTES];
+        epi_stage = slab_mem + wave * fp_gemm::EPI_STAGE_BYTES;
+    }
     if constexpr (LUT) {
         // gelu_tab16's inline-asm gathers use table-relative byte offsets as absolute LDS addresses
         if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem_raw != 0u) __builtin_trap();
@@ -374,7 +383,7 @@ template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr bool LUT = FpEpiTraits<EPI>::GELU && (VAR & 4) != 0;
-    constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + 2 * STAGE + (LUT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
+    constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + 2 * STAGE;   // dynamic part; the slabs are static (see the kernel)
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
     FP_DYN_LDS_ONCE(kern, SMEM);

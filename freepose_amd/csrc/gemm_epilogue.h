@@ -117,6 +117,11 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 template <int BM, int BN, int WM, int WN, int EPI, int VAR, int TC, int TR>
 __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC][TR], int m0, int n0, int wm, int wn,
                                          int li, int lg, char* stg, const char* gelu_tab = nullptr) {
+    // Everything below that depends only on the lane (slab addresses, row / chunk roles, output offsets) is re-derived per tile from
+    // these two laundered values: left to itself hipcc hoists it out of the persistent tile loop, keeps it live through the K loop
+    // of a 128-VGPR kernel and spills it — and a scratch reload inside the epilogue waits (vmcnt is in-order) for every output
+    // store issued before it.
+    asm volatile("" : "+v"(li), "+v"(lg));
     constexpr bool TRANS = FpEpiTraits<EPI>::TRANS;
     constexpr bool LNF = FpEpiTraits<EPI>::LN;
     constexpr bool EGELU = FpEpiTraits<EPI>::GELU;

@@ -58,6 +58,62 @@ def test_vit_forward_vs_fp32_oracle(model, H, layer, B):
         assert rg <= 2.0 * r16 + 2e-3
 
 
+def _massive_state_dict(model, seed):
+    """random-init weights bent towards what trained DINOv2-reg checkpoints look like (parity caveat i): a few residual
+    channels carry activations hundreds of times the typical magnitude at the CLS / register tokens and at a handful of patch
+    positions, LayerNorm gains span an order of magnitude with non-zero shifts, LayerScale gammas are small and uneven."""
+    from freepose_amd import ops
+    sd = {k: v.float() for k, v in ops.random_state_dict(model, seed=seed).items()}
+    g = torch.Generator().manual_seed(seed + 100)
+    dim = sd["norm.weight"].numel()
+    big = [5, dim // 3, dim - 7]
+    sd["cls_token"][..., big[0]] += 90.0
+    if "register_tokens" in sd:
+        sd["register_tokens"][..., big[1]] += 160.0
+        sd["register_tokens"][:, :2, big[2]] -= 70.0
+    sd["pos_embed"][:, 40:44, big[1]] += 220.0            # a few patch tokens with a massive channel
+    sd["pos_embed"][:, 300:302, big[0]] -= 130.0
+    for k in list(sd):
+        if k.endswith("norm1.weight") or k.endswith("norm2.weight") or k == "norm.weight":
+            sd[k] = torch.exp(torch.empty(dim).uniform_(-1.2, 1.0, generator=g))
+        elif k.endswith("norm1.bias") or k.endswith("norm2.bias") or k == "norm.bias":
+            sd[k] = torch.empty(dim).uniform_(-0.5, 0.5, generator=g)
+        elif k.endswith("gamma"):
+            sd[k] = torch.exp(torch.empty(dim).uniform_(-4.0, 0.0, generator=g))
+    return {k: v.to(torch.bfloat16) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("model,H,layer,B", [("dinov2_vits14_reg", 224, 22, 2), ("dinov2_vitl14_reg", 420, 22, 1)])
+def test_vit_massive_activation_regime(model, H, layer, B):
+    """Seeded weights with massive-activation channels, wide LayerNorm gains and small LayerScale (what real checkpoints have and
+    plain random init does not).  Stated bar: against the fp32 oracle the HIP forward — with the LayerNorm folded into the GEMMs and
+    with the separate LayerNorm kernel — is no further away than twice the distance of the reference's own regime (the torch bf16
+    model, dino.py:14 / pose_estimator.py:21) plus 2e-3, per-patch cosine >= 0.995."""
+    from freepose_amd import ops
+    from oracle import vit_ref
+    sd = _massive_state_dict(model, 5)
+    img = _images(B, H, 11)
+    sdf = {k: v.float() for k, v in sd.items()}
+    ref32 = vit_ref.vit_forward(sdf, img.float(), layer=layer, feature_type="patch", dtype=torch.float32)
+    ref16 = vit_ref.vit_forward(sd, img.float(), layer=layer, feature_type="patch", dtype=torch.bfloat16)
+    c16, r16 = _metrics(ref16, ref32)
+    # the regime is really there: the residual stream the last block sees has channels far above its typical magnitude
+    x = vit_ref.vit_forward(sdf, img.float(), layer=max(layer - 1, 1), feature_type="patch", dtype=torch.float32)
+    vit = ops.ViT(model, sd)
+    try:
+        for fused in (1, 0):
+            ops.set_option("ln_fused", fused)
+            got = vit(img, layer=layer, feature_type="patch")
+            torch.cuda.synchronize()
+            cg, rg = _metrics(got, ref32)
+            print(f"{model} massive-activation regime, ln_fused={fused}: hip vs fp32 cos {cg:.5f} rel {rg:.4f} | torch-bf16 vs fp32 cos {c16:.5f} rel {r16:.4f}")
+            assert torch.isfinite(got.float()).all()
+            assert cg >= 0.995 and rg <= 2.0 * r16 + 2e-3, (model, fused, cg, rg, c16, r16)
+    finally:
+        ops.set_option("ln_fused", -1)
+    assert float(x.abs().max()) > 20.0 * float(x.abs().median())
+
+
 def test_vit_batch_invariance_and_layer_semantics():
     from freepose_amd import ops
     vit = ops.ViT("dinov2_vits14_reg", seed=1)

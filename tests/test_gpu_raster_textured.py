@@ -213,6 +213,25 @@ def test_web_template_dataset_matches_reference_golden(tmp_path, golden_dir):
             assert e["model_name"] == str(g["model_name"]) and e["tar_file"] == str(g["tar_file"])
     nc = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), crop=False).get_template_by_name(names[0])
     assert [sha(x) for x in nc["templates"].cpu().numpy()[:20]] == [str(x) for x in g["nocrop_templates_sha"]]
+    # ---- the device-resident store: a hit returns a FRESH dict over the SAME device tensors (nothing is decoded), still
+    # equal to the reference golden; the LRU holds `cache_meshes` entries; cache_meshes = 0 is the reference's decode-per-call
+    ds = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), bbox_extend=0, cache_meshes=1)
+    e1 = ds.get_template_by_name(names[1])
+    spent = ds.decode_seconds
+    e2 = ds.get_template_by_name(names[1])
+    assert ds.decode_seconds == spent and e2 is not e1
+    assert all(e2[k].data_ptr() == e1[k].data_ptr() for k in ("templates", "masks", "depths", "bboxes"))
+    e2["model_name"] = "scribbled"                                   # a caller editing its dict does not reach the store
+    assert ds.get_template_by_name(names[1])["model_name"] == str(g["model_name"])
+    assert not [i for i in range(0, 600, 7) if sha(e2["templates"][i].cpu().numpy()) != str(g["e0_templates_sha"][i])]
+    ds.get_template_by_name(names[0])                                # evicts names[1] (one slot)
+    assert ds.decode_seconds > spent
+    spent = ds.decode_seconds
+    e3 = ds.get_template_by_name(names[1])
+    assert ds.decode_seconds > spent and torch.equal(e3["templates"], e1["templates"]) and torch.equal(e3["depths"], e1["depths"])
+    ds0 = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), bbox_extend=0, cache_meshes=0)
+    a, b = ds0.get_template_by_name(names[1]), ds0.get_template_by_name(names[1])
+    assert a["templates"].data_ptr() != b["templates"].data_ptr() and torch.equal(a["templates"], b["templates"])
 
 
 @pytest.mark.parametrize("textured", [False, True])

@@ -35,7 +35,7 @@ def main():
         objs = [int(x) for x in os.environ.get("VIDEO_OBJECTS", "1").split(",")]
         for n_obj in objs:
             meshes = [mesh] + [TriMesh(v, f, c) for _ in range(n_obj - 1)]
-            for neighborhood in ((15, 25) if n_obj == 1 else (15,)):
+            for neighborhood in ((15, 25) if n_obj == 1 and not os.environ.get("VIDEO_ONLY15") else (15,)):
                 n_nb = len(ops.geodesic_select(est._fine_rots_dev, np.asarray(prev)[:3, :3], float(neighborhood)))
 
                 def step(ps):

@@ -15,7 +15,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 import os
 nobj = [int(x) for x in os.environ.get("VIDEO_OBJECTS", "1").split(",")]
-nfr = sum((2 if n == 1 else 1) * (3 + 20) * n for n in nobj)      # frame-objects: (3 warm-up + 20 timed) frames per setting
+nfr = sum((2 if n == 1 and not os.environ.get("VIDEO_ONLY15") else 1) * (3 + 20) * n for n in nobj)      # frame-objects: (3 warm-up + 20 timed) frames per setting
 print(f"sum of kernel time per frame-object: {tot / nfr / 1e6:.2f} ms over {nfr} frame-objects")
 for r in rows[:16]:
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:60]

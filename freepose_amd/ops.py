@@ -354,6 +354,7 @@ class Mesh:
     def set_cull(self, mode: int):
         """back-face culling: 0 = both sides (default; the reference's callers), 1 = pyrender's default culling (cull_faces=True)"""
         check(self.lib.fp_mesh_set_cull(self.handle, int(mode)), "fp_mesh_set_cull")
+        self.cull = int(mode)
         return self
 
     def set_shading(self, mode: int):

@@ -65,6 +65,8 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
         objects return in ONE device -> host copy.  `items`: dicts with proposal, proposal_mask, template_dict, mesh, K, bbox,
         est_scale, prev_pose and optionally query_feat (frame 0: the coarse estimator's un-normalised query, reference :40-41).
         Returns one reference-style result dict per item, identical to calling `forward_fine` per item."""
+        if len(items) == 0:
+            return []
         work, pieces = [], []
         for it in items:
             close = ops.geodesic_select(self._fine_rots_dev, np.asarray(it["prev_pose"])[:3, :3], float(neighborhood))

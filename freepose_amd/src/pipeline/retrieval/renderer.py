@@ -100,12 +100,13 @@ class MeshRenderer:
     def _render(self, mesh, poses, thirds, scale=1.0, cull_faces=False) -> RenderBatch:
         poses = np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4)
         dm = self._device_mesh(mesh)
+        before = getattr(dm, "cull", 0)
         dm.set_cull(1 if cull_faces else 0)          # reference :63-66 / :90-93: SKIP_CULL_FACES unless cull_faces
         try:
             rgb, depth = ops.rasterize(dm, torch.from_numpy(poses), scale, self.fx, self.fy, self.cx,
                                        self.cy, self.resolution, self.resolution)
         finally:
-            dm.set_cull(0)
+            dm.set_cull(before)                       # a caller's own ops.Mesh keeps the mode it had
         return RenderBatch(rgb, depth, thirds, (self.fx, self.fy, self.cx, self.cy))
 
     def render(self, mesh, cull_faces=False, scale=1.0):

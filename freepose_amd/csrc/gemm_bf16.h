@@ -56,6 +56,8 @@ struct FpGemmArgs {
     const uint4* ln_cfrag;
     // FP_EPI_LS_RES_STATS: partial row statistics [N/64][M] (sum, sum of squares), N % 64 == 0
     float2* stat_part;
+    int no_split;  // internal: this launch is one part of a row split (gemm_bf16.hip launch_epi)
+    int stat_ld;   // row stride of stat_part (= the whole problem's M; a row-split launch covers only part of it).  0 = M
     int dbg;   // experiment bits (FP_GEMM_DBG; wrong numerics): 2 = LN-folded kernels start from zero accumulators, 8 = persistent kernels skip the epilogue
 };
 

@@ -416,7 +416,40 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     static int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 8 ? (n & ~7) : 256; }();
     const long rounds_big = (tiles_big + ncu - 1) / ncu;
     const bool filled = tiles_big * 4 >= rounds_big * ncu * 3;          // >= 75 % of the big-tile rounds are real work
-    const bool big = tiles_big >= 192 && filled && !(var & 256);        // bit 256 (A/B only): force the 128x128 kernel
+    bool big = tiles_big >= 192 && filled && !(var & 256);              // bit 256 (A/B only): force the 128x128 kernel
+    // ROW SPLIT (round 3): whole rounds of the resident grid on 256x256 tiles, the remaining rows on the finer tiers — for the launch
+    // sizes in between (the video path's ~20-crop batches: 600 qk tiles = 2.34 rounds, 300 proj / fc2 tiles = 1.17) where the big
+    // tile wastes most of a round and the small tile, ~0.56 of a big round per round of 2 tiles per CU at half the work, pays its
+    // lower efficiency on every row.  Rows are independent and every tier produces the same bits (tests/test_gpu_fullsize.py), so
+    // the split is invisible in the results.  Cost model in units of one big round; the split must win by 4 %.  Not for the
+    // transposed-V and patch-embed epilogues (their row -> output mapping is per crop).  Bit 4096 (A/B only): never split.
+    if constexpr (EPI != FP_EPI_VT && EPI != FP_EPI_LN_VT && EPI != FP_EPI_PATCH) {
+        const long tiles_n = cdiv(a.N, 256);
+        const long full = tiles_big / ncu;                               // whole rounds
+        const long rb = full * ncu / tiles_n;                            // 256-row blocks they cover
+        if (!(var & (256 | 4096)) && !a.no_split && full >= 1 && rb * 256 < a.M && tiles_big >= 192) {
+            const double r_small = 0.56;
+            auto small_cost = [&](long rows) { return (double)cdiv(cdiv(rows, 128) * cdiv((long)a.N, 128), 2L * ncu) * r_small; };
+            const double t_big = (double)rounds_big, t_small = small_cost(a.M);
+            const double t_now = big ? t_big : t_small;
+            const double t_split = (double)cdiv(rb * tiles_n, (long)ncu) + small_cost(a.M - rb * 256);
+            if (t_split < 0.96 * t_now) {
+                const size_t m1 = (size_t)rb * 256;
+                FpGemmArgs a1 = a, a2 = a;
+                a1.M = (int)m1; a1.no_split = 1;
+                a2.M = a.M - (int)m1; a2.no_split = 1;
+                a2.X = a.X + m1 * a.ldx;
+                a2.C = a.C + m1 * a.ldc;
+                if (a.resid) a2.resid = a.resid + m1 * a.ldr;
+                if (a.ln_mfrag) a2.ln_mfrag = a.ln_mfrag + m1;
+                if (a.ln_rstd) a2.ln_rstd = a.ln_rstd + m1;
+                if (a.stat_part) a2.stat_part = a.stat_part + m1;
+                const int rc = launch_epi<EPI>(a1, stream);              // whole rounds: takes the 256x256 tier below
+                if (rc != FP_OK) return rc;
+                return launch_epi<EPI>(a2, stream);                      // the remainder picks its own tier (128x128 or 64x64)
+            }
+        }
+    }
     // A launch that cannot even give every CU one 128x128 tile (a single 518^2 crop: 88 tiles for N = 1024) runs one-wave
     // 64x64 tiles instead — 4x the workgroups, all CUs busy (bit 2048, A/B only: keep the 128x128 kernel).
     const long tiles_mid = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
@@ -479,6 +512,7 @@ int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
     FpGemmArgs a = a_in;
     static const int dbg_env = [] { const char* e = getenv("FP_GEMM_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = fp_opt_get(FP_OPT_GEMM_DBG, dbg_env);
+    if (a.stat_ld == 0) a.stat_ld = a.M;
     if (epi == FP_EPI_BIAS_GELU || epi == FP_EPI_LN_GELU) {
         const int rc = fp_gemm_gelu_table(&a.gelu_tab);
         if (rc != FP_OK) return rc;

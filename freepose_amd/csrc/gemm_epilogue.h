@@ -237,7 +237,7 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                             sm += lane_xor<4>(sm); sq += lane_xor<4>(sq);
                             sm += lane_xor<2>(sm); sq += lane_xor<2>(sq);
                             sm += lane_xor<1>(sm); sq += lane_xor<1>(sq);
-                            if (pslot == 0) p.stat_part[(size_t)(nbw >> 6) * p.M + m] = make_float2(sm, sq);
+                            if (pslot == 0) p.stat_part[(size_t)(nbw >> 6) * p.stat_ld + m] = make_float2(sm, sq);
                         }
                     } else if constexpr (EPI == FP_EPI_PATCH) {
                         const int b = m / p.P, pp = m - b * p.P;

@@ -32,7 +32,8 @@ int fp_version(void);
  *                   4 GELU by LDS table (16 KiB at LDS byte 0; the epilogue slabs move into the last K-tile buffer),
  *                   8 16-wave 256x256 tile, 32 persistent tile walk, 64 streaming epilogue I/O,
  *                   128 split DMA issue + MFMA priority, 512 8-tile column strips (A/B only),
- *                   2048 keep the 128x128 kernel for grids smaller than the CU count (A/B only)
+ *                   2048 keep the 128x128 kernel for grids smaller than the CU count (A/B only),
+ *                   4096 never split a launch by rows between the 256x256 and the finer tile tiers (A/B only)
  *                   (default 238 = 2|4|8|32|64|128)
  *   "attn_slots":   LDS ring depth of the attention kernel, 2 (default), 3 or 4
  *   "ln_fused":     1 (default) LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward, 0 the separate kernel (A/B)

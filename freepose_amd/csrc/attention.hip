@@ -92,6 +92,11 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
     const int qb = bid % nqb, bh = bid / nqb;
     const int h = bh % p.H, b = bh / p.H;
     const int q0 = p.q_base + qb * QB + wave * QW;
+    // A wave none of whose 32 queries exists (the last query block of 1374 / 905 tokens holds 94 / 9 queries of 128; q0 is a multiple
+    // of 32 and npad of 16, so "q0 >= npad" is exactly "no row to store") only takes part in each tile's DMA and barrier.
+    // 905 tokens: 718 -> 744 TFLOP/s; 1374: +0.5 % (profiles/r03_ab.md §3).  A half-length body for a last K/V tile whose valid keys
+    // sit in its first 32 (1374 = 21 x 64 + 30) was built too: two bodies updating the O accumulators cost 36 spills — dropped.
+    const bool idle = q0 >= p.npad;
 
     const size_t rowbase = (size_t)b * p.npad;
     const char* gQK = (const char*)p.QK;
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + PF < ntile) stage(slot >= 1 ? slot - 1 : NSLOT - 1, (t + PF) * KVB);   // slot of tile t-1 = (slot+PF) % NSLOT
+        if (idle) return;
         const char* sb = smem + slot * STAGE;
         const int kv0 = t * KVB;
 

@@ -94,8 +94,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
     const int q0 = p.q_base + qb * QB + wave * QW;
     // A wave none of whose 32 queries exists (the last query block of 1374 / 905 tokens holds 94 / 9 queries of 128; q0 is a multiple
     // of 32 and npad of 16, so "q0 >= npad" is exactly "no row to store") only takes part in each tile's DMA and barrier.
-    // 905 tokens: 718 -> 744 TFLOP/s; 1374: +0.5 % (profiles/r03_ab.md §3).  A half-length body for a last K/V tile whose valid keys
-    // sit in its first 32 (1374 = 21 x 64 + 30) was built too: two bodies updating the O accumulators cost 36 spills — dropped.
+    // 905 tokens: 718 -> 744 TFLOP/s; 1374: +0.5 % (profiles/r03_ab.md §3).
     const bool idle = q0 >= p.npad;
 
     const size_t rowbase = (size_t)b * p.npad;
@@ -185,11 +184,17 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
     // "tile t has landed, tile t+1 may still be in flight".  Raw s_barrier (a __syncthreads() would drain vmcnt to 0).
     // The barrier of iteration t also proves every wave finished reading tile t-1, whose slot tile t+2 now reuses.
     const int ntile = (p.n_tok + KVB - 1) / KVB;
+    // VAR bit 4 (chosen by the host when the LAST tile's valid keys all sit in its first 32: 1374 tokens = 21 tiles + 30 keys, 905 =
+    // 14 + 9): that tile goes FIRST — softmax accumulation does not care about the order — through a half-length body (NKS = 1:
+    // half the S^T MFMAs, exponentials and PV MFMAs), then the full tiles follow in the uniform loop.  Being a compile-time prologue
+    // it adds no second body at a join inside the loop (which cost 36 spills when tried).
+    constexpr bool SHORT = (VAR & 4) != 0;
+    auto tile_of = [&](int sq) { return SHORT ? (sq == 0 ? ntile - 1 : sq - 1) : sq; };   // sequence position -> K/V tile
     constexpr int PF = NSLOT - 1;   // tiles in flight
-    stage(0, 0);
+    stage(0, tile_of(0) * KVB);
 #pragma unroll
     for (int i = 1; i < PF; ++i)
-        if (ntile > i) stage(i, i * KVB);
+        if (ntile > i) stage(i, tile_of(i) * KVB);
     // The Q fragments came from ordinary global loads; while a DMA is in flight hipcc would protect their first use in
     // the loop with vmcnt(0) EVERY iteration (draining the ring).  Wait once here and pass them through an empty asm so
     // the compiler sees them as ready registers.
@@ -207,8 +212,13 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
     }
     // one K/V tile; `slot` = its ring slot — a compile-time constant in the 2-slot kernel (the loop below is unrolled by the
     // ring), so every fragment read address is a loop-invariant lane base plus an immediate
-    auto tile_body = [&](int t, auto slot_c) {
+    // `nks_c` = 32-key halves of the tile that are computed: 2, or 1 for a LAST tile whose valid keys all sit in its first half
+    // (1374 tokens = 21 tiles + 30 keys, 905 = 14 tiles + 9): half the S^T MFMAs, exponentials and PV MFMAs of that tile.
+    // A wave whose 32 queries all lie beyond the padded sequence (`idle`: the last query block of 1374 / 905 tokens holds 94 / 9
+    // queries of 128) only takes part in the tile's DMA and barrier.
+    auto tile_body = [&](int t, auto slot_c, auto nks_c) {
         const int slot = slot_c;
+        constexpr int NKS = decltype(nks_c)::value;
         // tiles t+1 .. t+PF-1 may stay in flight (4 DMA instructions per tile per wave); near the end fewer are pending
         const int ahead = min(PF - 1, ntile - 1 - t);
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -216,10 +226,10 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + PF < ntile) stage(slot >= 1 ? slot - 1 : NSLOT - 1, (t + PF) * KVB);   // slot of tile t-1 = (slot+PF) % NSLOT
+        if (t + PF < ntile) stage(slot >= 1 ? slot - 1 : NSLOT - 1, tile_of(t + PF) * KVB);   // slot of step t-1 = (slot+PF) % NSLOT
         if (idle) return;
         const char* sb = smem + slot * STAGE;
-        const int kv0 = t * KVB;
+        const int kv0 = tile_of(t) * KVB;
 
         // ---- S^T = K Q^T -------------------------------------------------------------------------
         // the first d-half starts from the inline constant 0 as the MFMA's C operand: no accumulator zeroing (32 v_mov per tile and
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         for (int kk = 0; kk < 2; ++kk) {
             const int slot = (((kk << 2) | lg) ^ keyK) << 4;
 #pragma unroll
-            for (int fk = 0; fk < 4; ++fk) {
+            for (int fk = 0; fk < 2 * NKS; ++fk) {
                 const bf16x8_t kf = *(const bf16x8_t*)(sb + baseK + (32 * (fk >> 1) + 4 * (fk & 1)) * ROWB + slot);
 #pragma unroll
                 for (int fq = 0; fq < 2; ++fq)
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
         if (kv0 + KVB > p.n_tok) {  // wave-uniform: only the last tile masks
 #pragma unroll
-            for (int fk = 0; fk < 4; ++fk)
+            for (int fk = 0; fk < 2 * NKS; ++fk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (kv0 + 32 * (fk >> 1) + 8 * lg + 4 * (fk & 1) + r >= p.n_tok) {
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         // load makes hipcc protect it against the in-flight LDS DMA with a vmcnt(0), draining the ring every tile.)
         bf16x8_t vf[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             const int sv = (((ks << 2) | lg) ^ keyV) << 4;
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) vf[ks][fd] = *(const bf16x8_t*)(sb + baseV + fd * 4 * ROWB + sv);
@@ -272,6 +282,12 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         bf16x8_t pf[2][2];  // [fq][ks]  B-operand fragments of P^T
         auto softmax_max = [&](int fq) {
             float mx;   // one statement: between separate asm statements hipcc pads every dependent pair with an s_nop
+            if constexpr (NKS == 1)
+                asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+                    : "=&v"(mx)
+                    : "v"(s[0][fq][0]), "v"(s[0][fq][1]), "v"(s[0][fq][2]), "v"(s[0][fq][3]), "v"(s[1][fq][0]), "v"(s[1][fq][1]),
+                      "v"(s[1][fq][2]), "v"(s[1][fq][3]));
+            else
             asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\t"
                 "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
                 : "=&v"(mx)
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
             const f32x2_t mb2 = {nmb[fq], nmb[fq]};
             float pv[4][4];
 #pragma unroll
-            for (int fk = 0; fk < 4; ++fk)
+            for (int fk = 0; fk < 2 * NKS; ++fk)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {
                     // two elements per v_pk_fma_f32 (each lane of it is an ordinary fused multiply-add)
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
                     pv[fk][r + 1] = __builtin_amdgcn_exp2f(e[1]);
                 }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 uint4 w;
                 w.x = pack_bf2(pv[2 * ks][0], pv[2 * ks][1]);
                 w.y = pack_bf2(pv[2 * ks][2], pv[2 * ks][3]);
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         // ---- O^T += V^T P^T (and l += 1^T P^T) for one half ------------------------------------------------------------
         auto pv_half = [&](int fq) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
                 for (int fd = 0; fd < 4; ++fd)
                     o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks][fd], pf[fq][ks], o[fd][fq], 0, 0, 0);
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         softmax_exp(1);
         pv_half(0);
 #pragma unroll
-        for (int g = 0; g < 10; ++g) {
+        for (int g = 0; g < 5 * NKS; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU
         }
@@ -351,15 +367,24 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         pv_half(1);
         if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
     };
-    if constexpr (NSLOT == 2) {
+    using full_c = std::integral_constant<int, 2>;
+    using half_c = std::integral_constant<int, 1>;
+    if constexpr (SHORT) {
+        static_assert(NSLOT == 2, "the short-tail prologue is written for the 2-slot ring");
+        tile_body(0, std::integral_constant<int, 0>{}, half_c{});
+        for (int t = 1; t < ntile; t += 2) {
+            tile_body(t, std::integral_constant<int, 1>{}, full_c{});
+            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 0>{}, full_c{});
+        }
+    } else if constexpr (NSLOT == 2) {
         for (int t = 0; t < ntile; t += 2) {
-            tile_body(t, std::integral_constant<int, 0>{});
-            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 1>{});
+            tile_body(t, std::integral_constant<int, 0>{}, full_c{});
+            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 1>{}, full_c{});
         }
     } else {
         int slot = 0;
         for (int t = 0; t < ntile; ++t) {
-            tile_body(t, slot);
+            tile_body(t, slot, full_c{});
             slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
     }
@@ -404,6 +429,8 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     static int env_var = [] { const char* e = getenv("FP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
     if (nslot == 2 && (env_var & 2)) hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     else if (nslot == 2 && (env_var & 1)) hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    else if (nslot == 2 && !(env_var & 8) && n_tok > KVB && n_tok - (cdiv(n_tok, KVB) - 1) * KVB <= KVB / 2)   // FP_ATTN_VARIANT=8: A/B off
+        hipLaunchKernelGGL((attn_fwd_kernel<2, 4>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     else if (nslot == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     else if (nslot == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(NWAVE * 64), 4 * STAGE, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(NWAVE * 64), 3 * STAGE, stream, a);

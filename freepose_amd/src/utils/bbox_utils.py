@@ -19,7 +19,9 @@ class CropResizePad:
         if isinstance(target_size, int):
             target_size = (target_size, target_size)
         if target_size[0] != target_size[1]:
-            raise NotImplementedError("only square targets are used by the pipeline (and supported by the kernel)")
+            # the reference cannot produce a non-square crop either: its own `assert image.shape[1] == image.shape[2]` after padding
+            # (bbox_utils.py:47-49) fails for every non-square target, so there is no behaviour to reproduce
+            raise NotImplementedError("non-square targets fail the reference's own square-after-padding assertion (bbox_utils.py:47-49)")
         self.target_size = tuple(target_size)
         self.target_h, self.target_w = self.target_size
         self.target_ratio = self.target_w / self.target_h

@@ -3,6 +3,7 @@ the work.  Every function raises if the library is missing or a call fails (no C
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional
 
 import numpy as np
@@ -497,6 +498,11 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 def plan_vit_batches(n: int, n_tok: int, max_batch: int = 192, n_cu: int = 256) -> list:
+    return list(_plan_vit_batches(int(n), int(n_tok), int(max_batch), int(n_cu)))
+
+
+@functools.lru_cache(maxsize=256)
+def _plan_vit_batches(n: int, n_tok: int, max_batch: int, n_cu: int) -> tuple:
     """Split n crops into ViT batches whose GEMM grids fill whole rounds of the resident (one workgroup per CU) grid.
 
     The persistent GEMM walks 256x256 tiles with one workgroup per CU; a batch of b crops has ceil(b*npad/256) tile rows,
@@ -505,7 +511,7 @@ def plan_vit_batches(n: int, n_tok: int, max_batch: int = 192, n_cu: int = 256) 
     then the number of batches.  Host-side policy only — results do not depend on the split.
     """
     if n <= 0:
-        return []
+        return ()
     npad = (n_tok + 15) // 16 * 16
     lo, hi = max(1, max_batch // 2), max_batch + max(1, max_batch // 8)
 
@@ -513,7 +519,7 @@ def plan_vit_batches(n: int, n_tok: int, max_batch: int = 192, n_cu: int = 256) 
         return -(-(-(-b * npad // 256) * 4) // n_cu)
 
     if n <= hi:
-        return [n]
+        return (n,)
     INF = (1 << 60, 1 << 60)
     best = [INF] * (n + 1)
     back = [0] * (n + 1)
@@ -527,12 +533,12 @@ def plan_vit_batches(n: int, n_tok: int, max_batch: int = 192, n_cu: int = 256) 
             if cand < best[m]:
                 best[m], back[m] = cand, b
     if best[n] == INF:            # n below 2*lo: one batch or an even split
-        return [n] if n <= hi else [n // 2, n - n // 2]
+        return (n,) if n <= hi else (n // 2, n - n // 2)
     out, m = [], n
     while m > 0:
         out.append(back[m])
         m -= back[m]
-    return sorted(out, reverse=True)
+    return tuple(sorted(out, reverse=True))
 
 
 class Timer:

@@ -135,11 +135,17 @@ class HotPath:
             with self.clock.stage("hypothesis_top3"):
                 idx_all = torch.arange(self.n_hyp, dtype=torch.int32, device=scores.device)
                 s3, i3 = ops.topk_merge(scores[None], idx_all[None], 3)
-            i3h = i3[0].cpu().numpy().astype(np.int64)
-            e = ext[i3[0].long()].cpu().numpy()
+            # everything the host needs of this proposal in ONE device -> host copy (five separate .cpu() calls were five
+            # synchronisations with the GPU idle in between): indices and fp32 scores are exact in float64
+            k = top_s.shape[1]
+            packed = torch.cat([i3[0].double(), s3[0].double(), ext[i3[0].long(), 4:6].double().reshape(-1), top_s[b].double(),
+                                top_i[b].double()]).cpu().numpy()
+            i3h = packed[0:3].astype(np.int64)
+            s3h = packed[3:6].astype(np.float32)
+            e = packed[6:12].reshape(3, 2)
             ratio = float(scales[b]) / self.render_scale
-            tco = [z_from_extents(bboxes[b], e[j, 4] * ratio, e[j, 5] * ratio, K, self.hyp_poses[i3h[j]]) for j in range(3)]
-            out.append(ProposalResult(top_s[b].cpu().numpy(), top_i[b].cpu().numpy(), i3h, s3[0].cpu().numpy(), tco))
+            tco = [z_from_extents(bboxes[b], e[j, 0] * ratio, e[j, 1] * ratio, K, self.hyp_poses[i3h[j]]) for j in range(3)]
+            out.append(ProposalResult(packed[12:12 + k].astype(np.float32), packed[12 + k:12 + 2 * k].astype(np.int32), i3h, s3h, tco))
         return out
 
 

@@ -196,7 +196,10 @@ def test_row_split_dispatch_is_invisible(M):
     assert torch.isfinite(res["split"]["stat_rows1024"]).all()
 
 
-@pytest.mark.parametrize("B,H,n_tok", [(1, 6, 261), (2, 16, 905), (2, 16, 1374), (1, 16, 64), (1, 2, 17)])
+# 70 / 129 / 261 / 905 / 1374: the last K/V tile's valid keys fit its first half -> the "short tail first" kernel (attention.hip);
+# 97 (33 keys in the tail), 64 and 17 take the plain kernel; 2 tiles (70, 97, 129 -> 3) exercise the shortest loops of both
+@pytest.mark.parametrize("B,H,n_tok", [(1, 6, 261), (2, 16, 905), (2, 16, 1374), (1, 16, 64), (1, 2, 17), (1, 2, 70), (1, 2, 97),
+                                       (2, 3, 129)])
 def test_attention(B, H, n_tok):
     from freepose_amd import ops
     npad = (n_tok + 15) // 16 * 16

@@ -327,9 +327,14 @@ def main():
     vit.profile(False)
     stage_ms = hp.clock.read()
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dt_ranks = [dt]
     if world > 1:
+        parts = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)                                     # every rank's own clock: a straggler shows in the one line
+        dt_ranks = [float(x.item()) for x in parts]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    who = parallel.rank_report()                                       # backend, RCCL version, device + PCI bus id of every rank
     video = video_workload(args, vit, rank, world) if args.video_frames > 0 else None    # outside the timed region
 
     if rank == 0:
@@ -338,7 +343,14 @@ def main():
         gemm_tf = prof["gemm_flops"] / max(prof["ms_gemm"], 1e-9) / 1e9
         out = {
             "metric": "proposals/sec (ViT-L feat + top-k + 576-pose render-compare)",
-            "value": n_prop / dt, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": n_prop / dt, "unit": "proposals/s",
+            # one process per GPU: n_gpus is the number of DISTINCT devices the ranks run on (== world unless FP_ALLOW_SHARED_GPU=1
+            # let ranks share a device on a test box; such a line says shared_devices = true and is not a scaling measurement)
+            "n_gpus": who["devices_distinct"], "n_ranks": world, "shared_devices": who["shared_devices"], "backend": who["backend"],
+            "devices_distinct": who["devices_distinct"], "rccl_version": who["rccl_version"], "ranks": who["ranks"],
+            "ms_per_step_ranks": {"min": min(dt_ranks) / args.steps * 1e3, "median": float(np.median(dt_ranks)) / args.steps * 1e3,
+                                  "max": max(dt_ranks) / args.steps * 1e3, "all": [x / args.steps * 1e3 for x in dt_ranks]},
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"per-proposal hot path: ViT-L/14-reg layer-22 @{args.res}^2 -> FFA -> top-100 over "

@@ -19,17 +19,34 @@ import torch
 import torch.distributed as dist
 
 
+def shared_gpu_allowed() -> bool:
+    """FP_ALLOW_SHARED_GPU=1: several ranks may share one device (flow tests on a single-GPU box).  Without it, more ranks than
+    visible GPUs is an error — a mis-provisioned box must not produce a plausible-looking N-"GPU" line."""
+    return os.environ.get("FP_ALLOW_SHARED_GPU", "0") == "1"
+
+
+def _require_own_devices(world: int) -> None:
+    if torch.cuda.is_available() and world > torch.cuda.device_count() and not shared_gpu_allowed():
+        raise SystemExit(f"freepose_amd: {world} ranks but only {torch.cuda.device_count()} visible GPU(s); one process per GPU is the "
+                         "contract.  Set FP_ALLOW_SHARED_GPU=1 to let ranks share a device (flow tests only: the result is stamped "
+                         "shared_devices = true and n_gpus = the number of distinct devices).")
+
+
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank); initialises the default process group when launched by torch.distributed.run."""
+    """(rank, world, local_rank); initialises the default process group when launched by torch.distributed.run.  Refuses to
+    put several ranks on one GPU unless FP_ALLOW_SHARED_GPU=1 (then the backend defaults to gloo: RCCL rejects shared devices)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    _require_own_devices(world)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:   # RCCL ("nccl") on GPUs; FP_DIST_BACKEND=gloo lets several ranks share one GPU (single-GPU test boxes)
             backend = os.environ.get("FP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
+            if world > torch.cuda.device_count():   # shared devices (allowed above): RCCL rejects them, the flow test runs on gloo
+                backend = os.environ.get("FP_DIST_BACKEND", "gloo")
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
@@ -37,12 +54,57 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def rank_report() -> dict:
+    """Who is running where: backend, RCCL version, and per rank the CUDA device index + PCI bus id, all-gathered so that rank 0
+    can print it.  `devices_distinct` counts distinct (host-local) PCI bus ids; `shared_devices` is true when it is smaller than
+    the world size — a line carrying it is a flow test, not a scaling measurement."""
+    rank, ws = world()
+    me = {"rank": rank, "device": None, "pci_bus_id": None, "name": None}
+    if torch.cuda.is_available():
+        d = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(d)
+        bus = None
+        if all(hasattr(pr, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        elif hasattr(pr, "uuid"):
+            bus = str(pr.uuid)
+        me.update(device=d, pci_bus_id=bus if bus is not None else f"index{d}", name=pr.name)
+    ranks = [me]
+    backend = "none"
+    if ws > 1:
+        backend = dist.get_backend()
+        ranks = [None] * ws
+        dist.all_gather_object(ranks, me)
+    ids = {r["pci_bus_id"] for r in ranks if r["pci_bus_id"] is not None}
+    distinct = len(ids) if ids else (1 if ws == 1 else 0)
+    rccl = None
+    try:
+        v = torch.cuda.nccl.version()
+        rccl = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        pass
+    return {"backend": backend, "world_size": ws, "devices_distinct": distinct, "shared_devices": bool(ids) and distinct < ws,
+            "rccl_version": rccl, "ranks": ranks}
+
+
+def announce(tag: str = "dist") -> dict:
+    """all ranks: gather rank_report(); rank 0 prints it as one `[tag] {json}` line on stderr (the CLIs call this once after
+    init_from_env when world > 1, so a run's log says which backend and which devices produced it)"""
+    import json
+    import sys
+    rep = rank_report()
+    if world()[0] == 0:
+        print(f"[{tag}] " + json.dumps(rep), file=sys.stderr, flush=True)
+    return rep
+
+
 def self_launch(n_ranks: int, target: Sequence[str], argv: Sequence[str]) -> None:
     """`python bench.py --gpus N` / `python -m scripts.dino_inference --gpus N` started WITHOUT a launcher: re-exec the same
     command as N ranks under torch.distributed.run on 127.0.0.1 (one process per GPU, RCCL) and exit with its status.  Returns
     immediately when n_ranks <= 1 or when this process already is a rank (WORLD_SIZE set by a launcher).  `target` is
-    ["bench.py"] or ["-m", "scripts.dino_inference"].  With fewer visible GPUs than ranks (single-GPU test boxes) the ranks
-    share devices, which RCCL refuses — FP_DIST_BACKEND falls back to gloo unless the caller set it."""
+    ["bench.py"] or ["-m", "scripts.dino_inference"].  With fewer visible GPUs than ranks the launch is REFUSED (exit status != 0)
+    unless FP_ALLOW_SHARED_GPU=1 (single-GPU test boxes); then the ranks share devices, which RCCL rejects, so FP_DIST_BACKEND falls
+    back to gloo unless the caller set it."""
     if n_ranks <= 1 or "WORLD_SIZE" in os.environ:
         return
     import socket
@@ -53,8 +115,9 @@ def self_launch(n_ranks: int, target: Sequence[str], argv: Sequence[str]) -> Non
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if "FP_DIST_BACKEND" not in env and torch.cuda.is_available() and torch.cuda.device_count() < n_ranks:
-        env["FP_DIST_BACKEND"] = "gloo"
+    if torch.cuda.is_available() and torch.cuda.device_count() < n_ranks:
+        _require_own_devices(n_ranks)                       # exits non-zero unless FP_ALLOW_SHARED_GPU=1
+        env.setdefault("FP_DIST_BACKEND", "gloo")           # RCCL refuses two ranks on one device
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), *target, *argv]
     raise SystemExit(subprocess.call(cmd, env=env))

@@ -78,6 +78,8 @@ def run(argv=None):
     import sys
     parallel.self_launch(args.gpus, ["-m", "scripts.dino_inference"], sys.argv[1:] if argv is None else list(argv))
     rank, world, _ = parallel.init_from_env()
+    if world > 1:
+        parallel.announce("dist")          # backend, RCCL version, device + PCI bus id of every rank
     task = int(os.getenv("SLURM_ARRAY_TASK_ID", 0))
     res_dir = Path("./data/results").resolve() / args.dataset
     out_dir = res_dir / args.proposals.replace(

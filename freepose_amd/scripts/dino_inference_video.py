@@ -83,6 +83,8 @@ def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, 
 
 def main(args):
     rank, world, _ = parallel.init_from_env()
+    if world > 1:
+        parallel.announce("dist")          # backend, RCCL version, device + PCI bus id of every rank
     video_dir = (Path("data") / "datasets" / "videos" / args.video).resolve()
     frames = sorted(p for p in video_dir.iterdir() if p.suffix.lower() in (".jpg", ".jpeg"))
     results_dir = (Path("data") / "results" / "videos" / args.video).resolve()

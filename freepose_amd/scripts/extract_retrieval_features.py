@@ -55,6 +55,8 @@ def main(argv=None):
     filelist_path = Path("data").resolve() / args.filelist
 
     rank, world, _ = parallel.init_from_env()
+    if world > 1:
+        parallel.announce("dist")          # backend, RCCL version, device + PCI bus id of every rank
     model = DINOv2FeatureExtractor(args.model, allow_random_weights=args.allow_random_weights or None)
     dataset = WebTemplateDataset(shards_path.as_posix(), filelist_path.as_posix(), crop=False, n_views=args.n_views)
 

@@ -128,3 +128,31 @@ def test_missing_checkpoint_fails_closed_and_self_launch_command(tmp_path, monke
     seen.clear()
     parallel.self_launch(4, ["bench.py"], [])
     assert not seen
+
+
+def test_more_ranks_than_gpus_is_refused_unless_overridden(monkeypatch):
+    """A box with fewer GPUs than ranks must not produce a plausible N-"GPU" result: init_from_env / self_launch exit non-zero
+    unless FP_ALLOW_SHARED_GPU=1 (then the launcher falls back to gloo and the result line is stamped shared_devices)."""
+    import subprocess
+    import torch
+    from freepose_amd import parallel
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FP_ALLOW_SHARED_GPU", "FP_DIST_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    called = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: called.update(cmd=cmd, env=env) or 0)
+    with pytest.raises(SystemExit) as e:
+        parallel.self_launch(2, ["bench.py"], ["--gpus", "2"])
+    assert "FP_ALLOW_SHARED_GPU" in str(e.value.code) and not called            # a message = exit status 1, nothing launched
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        parallel.init_from_env("nccl")                                          # a rank under somebody else's launcher: same refusal
+    assert "2 ranks but only 1 visible GPU" in str(e.value.code)
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.setenv("FP_ALLOW_SHARED_GPU", "1")
+    with pytest.raises(SystemExit) as e:
+        parallel.self_launch(2, ["bench.py"], ["--gpus", "2"])
+    assert e.value.code == 0 and called["env"]["FP_DIST_BACKEND"] == "gloo" and "--nproc-per-node=2" in called["cmd"]
+    rep = parallel.rank_report.__doc__
+    assert "shared_devices" in rep

@@ -92,6 +92,10 @@ def _worker(rank, world, port, tmp):
     allr = parallel.all_gather_rows(rows)
     assert allr.shape == (7, 3) and sorted(allr[:, 0].tolist()) == list(range(7))
     assert torch.equal(parallel.all_gather_cat(torch.full((2, 3), float(rank)), dim=1)[:, ::3], torch.tensor([[0., 1.], [0., 1.]]))
+    # ---- the "who ran where" record every N-rank line carries (bench.py, the CLIs) ---------------------------
+    rep = parallel.rank_report()
+    assert rep["backend"] == "gloo" and rep["world_size"] == 2 and [r["rank"] for r in rep["ranks"]] == [0, 1]
+    assert rep["shared_devices"] is False and all(r["device"] is None for r in rep["ranks"])   # CPU ranks: no device to share
     dist.barrier()
     Path(tmp, f"ok{rank}").write_text("ok")
     dist.destroy_process_group()

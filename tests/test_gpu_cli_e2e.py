@@ -32,7 +32,7 @@ def workspace(tmp_path_factory):
 
 
 def _run_ranks(module, argv, cwd, world, port):
-    env = dict(os.environ, FP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", PYTHONPATH=str(ROOT), SLURM_ARRAY_TASK_ID="0")
+    env = dict(os.environ, FP_DIST_BACKEND="gloo", FP_ALLOW_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", PYTHONPATH=str(ROOT), SLURM_ARRAY_TASK_ID="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", module] + argv
     r = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
@@ -129,7 +129,7 @@ def test_image_driver_and_bank_build(workspace, monkeypatch):
     # two ranks: images are dealt round-robin, one CSV per rank; together they hold the same rows
     # the CLI's own launcher: `python -m scripts.dino_inference ... --gpus 2` with no torch.distributed.run around it
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(PYTHONPATH=str(ROOT), SLURM_ARRAY_TASK_ID="0")
+    env.update(PYTHONPATH=str(ROOT), SLURM_ARRAY_TASK_ID="0", FP_ALLOW_SHARED_GPU="1")
     r = subprocess.run([sys.executable, "-m", "scripts.dino_inference", *argv, "--gpus", "2"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])

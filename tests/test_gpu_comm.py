@@ -55,7 +55,7 @@ def test_rccl_two_ranks(tmp_path):
     """2 ranks over the `nccl` backend (RCCL) + the C-ABI communicator.  With >= 2 GPUs each rank has its own device; on a
     single-GPU box both ranks are pointed at GPU 0 — RCCL normally refuses that ("Duplicate GPU detected"), in which case the
     test is skipped with RCCL's own message; any other failure is a failure."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FP_DIST_BACKEND="nccl", FP_COMM_DIR=str(tmp_path), NCCL_DEBUG="WARN")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FP_DIST_BACKEND="nccl", FP_ALLOW_SHARED_GPU="1", FP_COMM_DIR=str(tmp_path), NCCL_DEBUG="WARN")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29581", str(ROOT / "tests" / "_multirank_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

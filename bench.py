@@ -279,8 +279,14 @@ def main():
                     help="frames of the secondary video-tracking measurement (BASELINE config 5; 0 = skip)")
     ap.add_argument("--video-objects", type=int, default=4,
                     help="tracked objects per frame in the multi-object leg of the video measurement (batched per frame)")
+    ap.add_argument("--lab", action="store_true",
+                    help="tools/ only: load libfreepose_hip_lab.so (measurement variants, FP_* toggles); never a reported number")
+    ap.add_argument("--ln-fused", type=int, default=-1, help="fp_ctx_set_option ln_fused (A/B of the LayerNorm fold)")
     args = ap.parse_args()
 
+    if args.lab:
+        from freepose_amd import _lib
+        _lib.use_lab()
     from freepose_amd import ops, parallel
     from freepose_amd.pipeline import HotPath, StageClock, pack_results
     from freepose_amd.retrieval import TemplateBank
@@ -294,6 +300,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local % torch.cuda.device_count())
 
+    if args.ln_fused >= 0:
+        ops.set_option("ln_fused", args.ln_fused)
     vit = ops.ViT("dinov2_vitl14_reg", seed=0)                         # random-init weights of the real architecture
     bank_f32 = synthetic_bank(args.bank, 1024)
     bank = TemplateBank(bank_f32, shard=False)                         # bank replicated, proposals sharded
@@ -353,6 +361,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
+            "library": "libfreepose_hip_lab.so — LAB BUILD, not a reportable number" if args.lab else "libfreepose_hip.so",
             "config": {"workload": f"per-proposal hot path: ViT-L/14-reg layer-22 @{args.res}^2 -> FFA -> top-100 over "
                                    f"{args.bank}x1024 bank -> {args.hyp} hypotheses rasterised ({len(mf)} triangles, 420^2), cropped to "
                                    f"{args.res}^2, ViT + patchwise score -> top-3 pose; all stages per proposal (no feature cache)",
@@ -399,7 +408,7 @@ def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
 
     add("vit_linear_layers", prof["ms_gemm"], "mfma", prof["gemm_flops"], "22 x (qk, v, proj, fc1, fc2) + patch embed")
     add("vit_attention", prof["ms_attn"], "mfma", 22 * 4.0 * n_tok * n_tok * D * crops, "4 n^2 D flops per block per crop")
-    ln_fused = os.environ.get("FP_LN_FUSED", "1") != "0"
+    ln_fused = args.ln_fused != 0   # the product default is on (fp_ctx_set_option "ln_fused"); the library reads no environment variable
     if ln_fused:   # LN1 / LN2 live in the GEMMs: what is left is the block-0 statistics pass, 43 finalisations of 16 partials, final norm, im2col
         other_bytes = (n_tok * D * 2.0 + 43 * n_tok * (128.0 + 20.0) + 2.0 * P * D * 2 + 3.0 * args.res * args.res * 2 + P * 640 * 2.0) * crops
         note = "LayerNorm 1/2 are folded into the GEMMs; this stage = block-0 row statistics, statistics finalisation, final norm + slice, im2col, token init"

@@ -11,8 +11,25 @@ from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libfreepose_hip.so"
+# the lab build (python -m freepose_amd.build --lab): the same sources with -DFP_LAB, i.e. plus the measurement variants and hooks of
+# tools/ (alternative GEMM loops, attention ring depths, FP_* environment toggles).  Never loaded by the product: a tool opts in by
+# calling use_lab() before the first load().
+LAB_LIB_PATH = _HERE / "lib" / "libfreepose_hip_lab.so"
 
 _lib = None
+_use_lab = False
+
+
+def use_lab():
+    """tools/ only: make load() open libfreepose_hip_lab.so (must be called before anything loaded the product library)"""
+    global _use_lab
+    if _lib is not None and not _use_lab:
+        raise RuntimeError("use_lab() after the product library was loaded")
+    _use_lab = True
+
+
+def is_lab() -> bool:
+    return _use_lab
 
 c_void_p, c_int, c_float, c_double, c_size_t, c_char_p = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_char_p
 P = C.POINTER
@@ -27,9 +44,9 @@ class VitArch(C.Structure):
 SIGNATURES = {
     "fp_last_error": (c_char_p, []),
     "fp_version": (c_int, []),
-    "fp_set_option": (c_int, [c_char_p, c_int]),
     "fp_ctx_create": (c_int, [c_int, P(c_void_p)]),
     "fp_ctx_destroy": (c_int, [c_void_p]),
+    "fp_ctx_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "fp_ctx_workspace_bytes": (c_size_t, [c_void_p]),
     "fp_vit_create": (c_int, [c_void_p, P(VitArch), P(c_void_p)]),
     "fp_vit_destroy": (c_int, [c_void_p]),
@@ -72,14 +89,15 @@ SIGNATURES = {
     "fp_allgather_bytes": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fp_allgather_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fp_allgather_poses": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "fp_op_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+    "fp_op_gemm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                            c_int, c_int, c_int, c_void_p]),
-    "fp_op_gemm_vt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+    "fp_op_gemm_vt": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                               c_void_p]),
     "fp_op_ln_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_int,
                                 c_int, c_void_p, c_void_p]),
     "fp_op_gemm_stats": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_float, c_void_p, c_void_p]),
+    "fp_op_gelu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fp_op_attention": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fp_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "fp_timer_create": (c_int, [P(c_void_p)]),
@@ -98,7 +116,7 @@ def load(path: os.PathLike | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else (LAB_LIB_PATH if _use_lab else LIB_PATH)
     if not p.exists():
         raise RuntimeError(
             f"{p} not found: the HIP extension is not built (run `python -m freepose_amd.build`). "
@@ -108,6 +126,9 @@ def load(path: os.PathLike | None = None):
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if hasattr(lib, "fp_lab_set_option"):   # lab build only
+        lib.fp_lab_set_option.restype = c_int
+        lib.fp_lab_set_option.argtypes = [c_char_p, c_int]
     if path is None:
         _lib = lib
     return lib

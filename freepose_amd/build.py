@@ -2,6 +2,8 @@
 
     python -m freepose_amd.build            # build everything that is stale
     python -m freepose_amd.build --force
+    python -m freepose_amd.build --lab      # additionally libfreepose_hip_lab.so: the same sources with -DFP_LAB (measurement
+                                            # variants, hooks and FP_* environment toggles; loaded only by tools/ via _lib.use_lab())
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off: only explicit fmaf() calls become FMAs, so the
 kernels that promise bit-exact agreement with oracle/fp_oracle.c really execute the documented op sequence.
@@ -20,6 +22,7 @@ CSRC = ROOT / "csrc"
 LIBDIR = ROOT / "lib"
 OBJDIR = ROOT / "lib" / "obj"
 LIB = LIBDIR / "libfreepose_hip.so"
+LAB_LIB = LIBDIR / "libfreepose_hip_lab.so"
 REPO = ROOT.parent
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -39,19 +42,23 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = True) -> Path:
+def build_hip(force: bool = False, verbose: bool = True, lab: bool = False) -> Path:
+    """the product library, or with lab=True the lab build (-DFP_LAB) next to it"""
     srcs = sorted(CSRC.glob("*.hip"))
     hdrs = sorted(CSRC.glob("*.h")) + [REPO / "include" / "freepose_hip.h"]
-    OBJDIR.mkdir(parents=True, exist_ok=True)
+    objdir = LIBDIR / "obj_lab" if lab else OBJDIR
+    lib_out = LAB_LIB if lab else LIB
+    extra = ["-DFP_LAB"] if lab else []
+    objdir.mkdir(parents=True, exist_ok=True)
     jobs = []
     for s in srcs:
-        o = OBJDIR / (s.stem + ".o")
+        o = objdir / (s.stem + ".o")
         if force or _stale(o, [s] + hdrs):
             jobs.append((s, o))
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC, *HIP_FLAGS, "-c", str(s), "-o", str(o)]
+        cmd = [HIPCC, *HIP_FLAGS, *extra, "-c", str(s), "-o", str(o)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s.name}:\n{r.stderr[-4000:]}")
@@ -62,15 +69,15 @@ def build_hip(force: bool = False, verbose: bool = True) -> Path:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
-    objs = [OBJDIR / (s.stem + ".o") for s in srcs]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950:sramecc+", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    objs = [objdir / (s.stem + ".o") for s in srcs]
+    if force or jobs or _stale(lib_out, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950:sramecc+", "-shared", "-fPIC", "-o", str(lib_out), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
         if verbose:
-            print(f"[build] linked {LIB.relative_to(REPO)}", flush=True)
-    return LIB
+            print(f"[build] linked {lib_out.relative_to(REPO)}", flush=True)
+    return lib_out
 
 
 def build_oracle(force: bool = False, verbose: bool = True) -> Path:
@@ -92,6 +99,8 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     force = "--force" in argv
     build_hip(force)
+    if "--lab" in argv:
+        build_hip(force, lab=True)
     build_oracle(force)
 
 

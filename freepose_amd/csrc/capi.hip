@@ -20,16 +20,28 @@ void fp_set_error(const char* fmt, ...) {
 extern "C" const char* fp_last_error(void) { return g_err; }
 extern "C" int fp_version(void) { return 100; }
 
+#ifdef FP_LAB
+// lab build only: process-global experiment toggles (tools/ A/B runs)
 static int g_opts[FP_OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
 int fp_opt_get(int key, int dflt) { return (key >= 0 && key < FP_OPT_COUNT && g_opts[key] >= 0) ? g_opts[key] : dflt; }
-extern "C" int fp_set_option(const char* name, int value) {
-    FP_REQUIRE(name, "set_option: null name");
+extern "C" int fp_lab_set_option(const char* name, int value) {
+    FP_REQUIRE(name, "lab_set_option: null name");
     if (!strcmp(name, "gemm_variant")) g_opts[FP_OPT_GEMM_VARIANT] = value;
     else if (!strcmp(name, "attn_slots")) g_opts[FP_OPT_ATTN_SLOTS] = value;
-    else if (!strcmp(name, "raster_tiled")) g_opts[FP_OPT_RASTER_TILED] = value;
-    else if (!strcmp(name, "ln_fused")) g_opts[FP_OPT_LN_FUSED] = value;
-    else if (!strcmp(name, "gemm_dbg")) g_opts[FP_OPT_GEMM_DBG] = value;   // measurement hooks (FP_GEMM_DBG bits), for in-process A/B
-    else { fp_set_error("set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
+    else if (!strcmp(name, "gemm_dbg")) g_opts[FP_OPT_GEMM_DBG] = value;   // measurement hooks with wrong numerics
+    else if (!strcmp(name, "attn_variant")) g_opts[FP_OPT_ATTN_VARIANT] = value;
+    else if (!strcmp(name, "topk_select")) g_opts[FP_OPT_TOPK_SELECT] = value;
+    else { fp_set_error("lab_set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
+    return FP_OK;
+}
+#endif
+
+extern "C" int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value) {
+    FP_REQUIRE(ctx && name, "ctx_set_option: null argument");
+    if (!strcmp(name, "ln_fused")) ctx->opt_ln_fused = value;
+    else if (!strcmp(name, "raster_tiled")) ctx->opt_raster_tiled = value;
+    else if (!strcmp(name, "gemm_row_split")) ctx->opt_row_split = value;
+    else { fp_set_error("ctx_set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
     return FP_OK;
 }
 
@@ -105,7 +117,9 @@ struct fp_vit {
     // (colsum(W'), b') pairs, built on the device the first time a forward runs after the weights changed
     struct VitFold { bf16_t *qkvw = nullptr, *fc1w = nullptr; uint4 *qkv_cb = nullptr, *fc1_cb = nullptr; };
     std::vector<VitFold> fold;
-    bool folded = false;
+    int folded_upto = 0;             // blocks [0, folded_upto) carry valid folded weights (a forward folds only the blocks it runs)
+    hipEvent_t fold_ev = nullptr;    // recorded behind the last fold; forwards on OTHER streams wait for it
+    hipStream_t fold_stream = nullptr;
     // pos-embed cache per (gh,gw)
     std::map<std::pair<int, int>, bf16_t*> pos_cache;
     // profiling
@@ -153,6 +167,7 @@ extern "C" int fp_vit_destroy(fp_vit* v) {
         if (f.fc1_cb) (void)hipFree(f.fc1_cb);
     }
     for (auto& p : v->ev_pool) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (v->fold_ev) (void)hipEventDestroy(v->fold_ev);
     delete v;
     return FP_OK;
 }
@@ -162,7 +177,7 @@ extern "C" int fp_vit_set_weight(fp_vit* v, const char* name, const void* d, siz
     const fp_vit_arch& a = v->a;
     const bf16_t* p = (const bf16_t*)d;
     const size_t D = a.dim;
-    v->folded = false;   // any new tensor invalidates the folded LayerNorm weights
+    v->folded_upto = 0;   // any new tensor invalidates the folded LayerNorm weights (in-place updates of a registered tensor: re-register it)
     auto need = [&](size_t n) -> bool {
         if (numel != n) { fp_set_error("vit_set_weight: %s has %zu elements, expected %zu", name, numel, n); return false; }
         return true;
@@ -225,10 +240,10 @@ static int vit_pos(fp_vit* v, int gh, int gw, hipStream_t s, const bf16_t** out)
 }
 
 // W' = W diag(gamma_ln), (colsum, b') for the qkv and fc1 layers of the first L blocks (device kernels on `s`, once per weight load)
-static int vit_fold(fp_vit* v, int L, hipStream_t s) {
+static int vit_fold(fp_vit* v, int first, int L, hipStream_t s) {
     const fp_vit_arch& a = v->a;
     const size_t D = a.dim, Mm = a.mlp_dim;
-    for (int i = 0; i < L; ++i) {
+    for (int i = first; i < L; ++i) {
         const VitBlockW& w = v->blk[i];
         fp_vit::VitFold& f = v->fold[i];
         if (!f.qkvw) FP_HIP(hipMalloc((void**)&f.qkvw, 3 * D * D * 2));
@@ -299,16 +314,23 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
 
     bf16_t *A0, *X, *Y, *QK, *Vt, *AO, *H1;
     int rc;
-    // LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs (default; fp_set_option("ln_fused", 0) runs the separate kernel for A/B)
-    static const int ln_env = [] { const char* e = getenv("FP_LN_FUSED"); return e ? atoi(e) : 1; }();
-    const bool lnf = fp_opt_get(FP_OPT_LN_FUSED, ln_env) != 0 && D % 64 == 0;
+    const int nosplit = v->ctx->opt_row_split == 0;   // fp_ctx_set_option(ctx, "gemm_row_split", 0)
+    // LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs (default; fp_ctx_set_option(ctx, "ln_fused", 0) runs the separate kernel)
+    const bool lnf = v->ctx->opt_ln_fused != 0 && D % 64 == 0;
     uint4* stat = nullptr;     // per-row init-MFMA records (sigma, -mean splits)
     float2* part = nullptr;
     float* rstd = nullptr;
     if (lnf) {
-        if (!v->folded) {
-            if ((rc = vit_fold(v, a.depth, s))) return rc;
-            v->folded = true;
+        // only the blocks this call runs (their weights were checked above): a caller that registered 22 of 24 blocks never
+        // touches the other two.  The fold is enqueued on `s`; a later forward on another stream waits for it through the event.
+        if (v->folded_upto < L) {
+            if ((rc = vit_fold(v, v->folded_upto, L, s))) return rc;
+            if (!v->fold_ev) FP_HIP(hipEventCreateWithFlags(&v->fold_ev, hipEventDisableTiming));
+            FP_HIP(hipEventRecord(v->fold_ev, s));
+            v->fold_stream = s;
+            v->folded_upto = L;
+        } else if (v->fold_ev && s != v->fold_stream) {
+            FP_HIP(hipStreamWaitEvent(s, v->fold_ev, 0));
         }
         if ((rc = v->ctx->get("vit.ln_stat", M * sizeof(uint4), (void**)&stat))) return rc;
         if ((rc = v->ctx->get("vit.ln_rstd", M * sizeof(float), (void**)&rstd))) return rc;
@@ -333,7 +355,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
     }
     {
         ProfScope ps(v, s, &v->ms_gemm);
-        FpGemmArgs g{};
+        FpGemmArgs g{}; g.no_split = nosplit;
         g.X = A0; g.ldx = v->KP; g.W = v->pe_w; g.ldw = v->KP; g.C = X; g.ldc = D; g.bias = v->pe_b;
         g.M = B * P; g.N = D; g.K = v->KP; g.pos = pos_patch; g.P = P; g.npad = npad; g.tok_off = 1 + a.n_reg;
         if ((rc = fp_gemm_bf16(g, FP_EPI_PATCH, s))) return rc;
@@ -353,11 +375,11 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
-            FpGemmArgs g{};
+            FpGemmArgs g{}; g.no_split = nosplit;
             g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.qkvw : w.qkvw; g.ldw = D; g.C = QK; g.ldc = 2 * D; g.bias = w.qkvb;
             g.M = Mi; g.N = 2 * D; g.K = D; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = f.qkv_cb;
             if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_BIAS : FP_EPI_BIAS, s))) return rc;
-            FpGemmArgs gv{};
+            FpGemmArgs gv{}; gv.no_split = nosplit;
             gv.X = lnf ? X : Y; gv.ldx = D; gv.W = (lnf ? f.qkvw : w.qkvw) + (size_t)2 * D * D; gv.ldw = D; gv.C = Vt; gv.ldc = 8;
             gv.bias = w.qkvb + 2 * D; gv.M = Mi; gv.N = D; gv.K = D; gv.npad = npad; gv.heads = a.heads;
             gv.ln_mfrag = stat; gv.ln_rstd = rstd; gv.ln_cfrag = lnf ? f.qkv_cb + 2 * D : nullptr;
@@ -370,7 +392,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
-            FpGemmArgs g{};
+            FpGemmArgs g{}; g.no_split = nosplit;
             g.X = AO; g.ldx = D; g.W = w.projw; g.ldw = D; g.C = X; g.ldc = D; g.bias = w.projb;
             g.gamma = w.ls1 ? w.ls1 : v->ones; g.resid = X; g.ldr = D; g.M = Mi; g.N = D; g.K = D; g.stat_part = part;
             if ((rc = fp_gemm_bf16(g, stats_out ? FP_EPI_LS_RES_STATS : FP_EPI_BIAS_LS_RES, s))) return rc;
@@ -383,11 +405,11 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
-            FpGemmArgs g{};
+            FpGemmArgs g{}; g.no_split = nosplit;
             g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.fc1w : w.fc1w; g.ldw = D; g.C = H1; g.ldc = a.mlp_dim; g.bias = w.fc1b;
             g.M = Mi; g.N = a.mlp_dim; g.K = D; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = f.fc1_cb;
             if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_GELU : FP_EPI_BIAS_GELU, s))) return rc;
-            FpGemmArgs g2{};
+            FpGemmArgs g2{}; g2.no_split = nosplit;
             g2.X = H1; g2.ldx = a.mlp_dim; g2.W = w.fc2w; g2.ldw = a.mlp_dim; g2.C = X; g2.ldc = D; g2.bias = w.fc2b;
             g2.gamma = w.ls2 ? w.ls2 : v->ones; g2.resid = X; g2.ldr = D; g2.M = Mi; g2.N = D; g2.K = a.mlp_dim; g2.stat_part = part;
             if ((rc = fp_gemm_bf16(g2, (stats_out && i + 1 < L) ? FP_EPI_LS_RES_STATS : FP_EPI_BIAS_LS_RES, s))) return rc;
@@ -524,19 +546,19 @@ extern "C" int fp_template_score_normed(fp_ctx* ctx, const void* d_tmpl_normed, 
 
 // ---------------------------------------------------------------------------------------------
 // kernel-level entry points
-extern "C" int fp_op_gemm(const void* X, int ldx, const void* W, int ldw, void* Cc, int ldc, const void* bias,
+extern "C" int fp_op_gemm(fp_ctx* ctx, const void* X, int ldx, const void* W, int ldw, void* Cc, int ldc, const void* bias,
                           const void* gamma, const void* resid, int ldr, int M, int N, int K, int epi, void* stream) {
-    FP_REQUIRE(X && W && Cc && bias, "op_gemm: null argument");
+    FP_REQUIRE(ctx && X && W && Cc && bias, "op_gemm: null argument");
     FP_REQUIRE(epi >= 0 && epi <= 2, "op_gemm: epi %d (0..2)", epi);
     FpGemmArgs g{};
     g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Cc; g.ldc = ldc;
     g.bias = (const bf16_t*)bias; g.gamma = (const bf16_t*)gamma; g.resid = (const bf16_t*)resid; g.ldr = ldr;
-    g.M = M; g.N = N; g.K = K;
+    g.M = M; g.N = N; g.K = K; g.no_split = ctx->opt_row_split == 0;
     return fp_gemm_bf16(g, epi, (hipStream_t)stream);
 }
-extern "C" int fp_op_gemm_vt(const void* X, int ldx, const void* W, int ldw, void* Vt, const void* bias, int M, int N,
+extern "C" int fp_op_gemm_vt(fp_ctx* ctx, const void* X, int ldx, const void* W, int ldw, void* Vt, const void* bias, int M, int N,
                              int K, int npad, int heads, void* stream) {
-    FP_REQUIRE(X && W && Vt, "op_gemm_vt: null argument");
+    FP_REQUIRE(ctx && X && W && Vt, "op_gemm_vt: null argument");
     FpGemmArgs g{};
     g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Vt; g.ldc = 8;
     g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads;
@@ -562,6 +584,7 @@ extern "C" int fp_op_ln_linear(fp_ctx* ctx, const void* X, int M, int K, const v
     FpGemmArgs g{};
     g.X = (const bf16_t*)X; g.ldx = K; g.W = Wf; g.ldw = K; g.C = (bf16_t*)out; g.ldc = mode == 2 ? 8 : N;
     g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = cb;
+    g.no_split = ctx->opt_row_split == 0;
     return fp_gemm_bf16(g, mode == 0 ? FP_EPI_LN_BIAS : (mode == 1 ? FP_EPI_LN_GELU : FP_EPI_LN_VT), s);
 }
 // LayerScale + residual GEMM that also emits the row statistics of its OUTPUT (what the next LN-folded GEMM consumes):
@@ -580,7 +603,7 @@ extern "C" int fp_op_gemm_stats(fp_ctx* ctx, const void* X, int ldx, const void*
     FpGemmArgs g{};
     g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Cc; g.ldc = ldc;
     g.bias = (const bf16_t*)bias; g.gamma = (const bf16_t*)gamma; g.resid = (const bf16_t*)resid; g.ldr = ldr;
-    g.M = M; g.N = N; g.K = K; g.stat_part = part;
+    g.M = M; g.N = N; g.K = K; g.stat_part = part; g.no_split = ctx->opt_row_split == 0;
     if ((rc = fp_gemm_bf16(g, FP_EPI_LS_RES_STATS, (hipStream_t)stream))) return rc;
     if ((rc = fp_stats_finalize(part, ms, rstd, M, N, eps, (hipStream_t)stream))) return rc;
     // d_stat [M,6] = the row record's 4 words {sh|sl, sh|-mh, -ml|-mh, 0} reinterpreted as floats are NOT meaningful: hand back the raw
@@ -588,6 +611,12 @@ extern "C" int fp_op_gemm_stats(fp_ctx* ctx, const void* X, int ldx, const void*
     FP_HIP(hipMemcpy2DAsync(d_stat, 24, ms, 16, 16, M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     FP_HIP(hipMemcpy2DAsync(d_stat + 4, 24, rstd, 4, 4, M, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return FP_OK;
+}
+// y = bf16(gelu_erf(x)) elementwise with the direct fp32 expression — the DEFINITION the fc1 epilogue's table is filled from; the
+// tests compare the table-GELU GEMM against it on all 65 536 bf16 inputs
+extern "C" int fp_op_gelu(const void* x, void* y, size_t n, void* stream) {
+    FP_REQUIRE(x && y, "op_gelu: null argument");
+    return fp_gemm_gelu_direct((const bf16_t*)x, (bf16_t*)y, n, (hipStream_t)stream);
 }
 extern "C" int fp_op_attention(const void* QK, int ldqk, const void* Vt, void* O, int ldo, int B, int H, int n_tok,
                                int npad, void* stream) {

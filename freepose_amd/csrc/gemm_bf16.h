@@ -56,10 +56,19 @@ struct FpGemmArgs {
     const uint4* ln_cfrag;
     // FP_EPI_LS_RES_STATS: partial row statistics [N/64][M] (sum, sum of squares), N % 64 == 0
     float2* stat_part;
-    int no_split;  // internal: this launch is one part of a row split (gemm_bf16.hip launch_epi)
+    int no_split;  // 1: never split this launch by rows between the tile tiers (set on the parts of a split; callers may set it too)
     int stat_ld;   // row stride of stat_part (= the whole problem's M; a row-split launch covers only part of it).  0 = M
-    int dbg;   // experiment bits (FP_GEMM_DBG; wrong numerics): 2 = LN-folded kernels start from zero accumulators, 8 = persistent kernels skip the epilogue
+#ifdef FP_LAB
+    int dbg;   // LAB BUILD ONLY (libfreepose_hip_lab.so, tools/): measurement bits with wrong numerics — 2 = LN-folded kernels start from
+               // zero accumulators, 8 = persistent kernels skip the epilogue, 16 = epilogue without its stores, 32 = staggered start
+#endif
 };
+// measurement hooks exist only in the lab build; in the product they are the constant 0 and the guarded code is not compiled in
+#ifdef FP_LAB
+#define FP_GEMM_DBG_BIT(p, bit) ((p).dbg & (bit))
+#else
+#define FP_GEMM_DBG_BIT(p, bit) 0
+#endif
 
 // Tile order shared by the GEMM kernels.  blockIdx -> logical id (XCD-contiguous, bijective) -> (tile_m, tile_n) in
 // column STRIPS of 4 n-tiles swept m-major: the 32 tiles an XCD runs concurrently then cover 8 X row-panels x 4 W
@@ -87,5 +96,7 @@ __device__ __forceinline__ void fp_gemm_tile(int block, int nblocks, int tiles_m
 int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream);
 // builds (once per device) and returns the bf16 -> bf16 GELU table the fc1 epilogue gathers from
 int fp_gemm_gelu_table(const uint16_t** out);
+// y[i] = bf16(gelu_erf(x[i])): the direct expression, elementwise (test entry fp_op_gelu)
+int fp_gemm_gelu_direct(const bf16_t* x, bf16_t* y, size_t n, hipStream_t stream);
 // name of the kernel variant used for (epi) — for profiles / bench bookkeeping
 const char* fp_gemm_kernel_name(int epi);

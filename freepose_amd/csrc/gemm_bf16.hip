@@ -18,13 +18,18 @@
 #include "gemm_bf16.h"
 #include "gemm_epilogue.h"
 
-#include <stdlib.h>
-
 #include <mutex>
 
-#ifndef FP_GEMM_DEFAULT_VARIANT
-#define FP_GEMM_DEFAULT_VARIANT 238   // 2|4|8|32|64|128 (profiles/r02_ab.md: +4..6 % over 110 on every ViT shape)
+// The PRODUCT build (libfreepose_hip.so) instantiates exactly one kernel per (epilogue, tile tier) — the variants below that the
+// rounds' A/B runs selected — reads no environment variable and has no measurement hooks.  The LAB build (-DFP_LAB,
+// libfreepose_hip_lab.so, loaded only by tools/) additionally compiles the alternative main loops / tile shapes and selects them
+// through fp_lab_set_option("gemm_variant" / "gemm_dbg") or FP_GEMM_VARIANT / FP_GEMM_DBG.
+#ifdef FP_LAB
+#include <stdlib.h>
 #endif
+#define FP_GEMM_DEFAULT_VARIANT 238   // 2|4|8|32|64|128 (profiles/r02_ab.md: +4..6 % over 110 on every ViT shape)
+#define FP_GEMM_VAR_BIG (4 | 32 | 64 | 128)   // 16-wave 256x256: table GELU, persistent walk, streaming epilogue I/O, split DMA issue
+#define FP_GEMM_VAR_SMALL 6                   // 128x128 (4 waves) and 64x64 (1 wave): pipelined fragment reads, table GELU
 
 namespace {
 
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     if constexpr ((VAR & 32) != 0) {
         // experiment (FP_GEMM_DBG=32): stagger the resident workgroups over one tile period so that the chip's 256 epilogues (each a
         // 128 KiB store burst) do not all hit the memory system at the same moment
-        if (p.dbg & 32) {
+        if (FP_GEMM_DBG_BIT(p, 32)) {
             const int phase = (blockIdx.x >> 3) & 7;
             const int n = phase * (p.K / BK) * 6;      // ~ phase/8 of a tile: a K step is ~3 000 cycles = 48 x s_sleep(1)
             for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
             for (int f = 0; f < TC; ++f) fc0[f] = onef;
         }
         if constexpr (LNF || !TRANS) {
-            if (LNF && (p.dbg & 2)) {
+            if (LNF && FP_GEMM_DBG_BIT(p, 2)) {
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
                     __builtin_amdgcn_s_setprio(0);
                 }
             }
-            if (p.dbg & 8) {   // measurement only (FP_GEMM_DBG=8): the main loop without its epilogue — one store keeps the accumulators live
+            if (FP_GEMM_DBG_BIT(p, 8)) {   // lab build only (gemm_dbg = 8): the main loop without its epilogue — one store keeps the accumulators live
                 if (acc[0][0][0] == 123456.789f) p.C[0] = 0;
             } else {
             if constexpr (RELOC) epi_stage = reloc_stage((g - 1) & 1);
@@ -379,6 +384,11 @@ __global__ void gelu_table_kernel(uint16_t* tab) {
     tab[i] = (uint16_t)(__float_as_uint(rbf(fp_gemm::gelu_erf(x))) >> 16);
 }
 
+__global__ void gelu_direct_kernel(const bf16_t* x, bf16_t* y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (bf16_t)(__float_as_uint(rbf(fp_gemm::gelu_erf(__uint_as_float((uint32_t)x[i] << 16)))) >> 16);
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
@@ -401,14 +411,17 @@ template <int EPI>
 int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // big tile once the grid can fill the chip with it, else the 128x128 tile
     const long tiles_big = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
-    // kernel variant bits: 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads (8-wave kernels),
-    // 4 = table GELU in the fc1 epilogue (gemm_epilogue.h; 0 = direct erff expression), 8 = 16-wave big tile, 32 = persistent tile walk,
-    // 64 = streaming epilogue I/O: non-temporal output stores and residual loads (the last two with the 16-wave big tile),
-    // 128 = split DMA issue (X pieces behind the first fragment reads, W pieces behind the first MFMA block) + MFMA priority
-    // (persistent 16-wave kernel).  FP_GEMM_VARIANT / fp_set_option override
-    // the default (A/B probing only).
+    // kernel variant bits (template parameter VAR): 1 = s_setprio around MFMA blocks, 2 = software-pipelined fragment reads (8-wave
+    // and smaller kernels), 4 = table GELU in the fc1 epilogue (gemm_epilogue.h; 0 = direct erff expression), 8 = 16-wave big tile,
+    // 32 = persistent tile walk, 64 = streaming epilogue I/O: non-temporal output stores and residual loads (the last two with the
+    // 16-wave big tile), 128 = split DMA issue (X pieces behind the first fragment reads, W pieces behind the first MFMA block) +
+    // MFMA priority (persistent 16-wave kernel).  The product always runs FP_GEMM_DEFAULT_VARIANT; only the lab build can change it.
+#ifdef FP_LAB
     static int env_var = [] { const char* e = getenv("FP_GEMM_VARIANT"); return e ? atoi(e) : FP_GEMM_DEFAULT_VARIANT; }();
     const int var = fp_opt_get(FP_OPT_GEMM_VARIANT, env_var);
+#else
+    constexpr int var = FP_GEMM_DEFAULT_VARIANT;
+#endif
     // The 256x256 kernels run one resident workgroup per CU, so their time goes in whole rounds of `ncu` tiles.  When the last
     // round would be mostly empty (e.g. 300 tiles on 256 CUs: the ~20-crop batches of the video path) the 128x128 kernel —
     // ~15-20 % less efficient per flop but 8x finer grained — is faster: measured 0.053 vs 0.068 ms (proj), 0.157 vs 0.192
@@ -454,36 +467,37 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // 64x64 tiles instead — 4x the workgroups, all CUs busy (bit 2048, A/B only: keep the 128x128 kernel).
     const long tiles_mid = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const bool tiny = !big && tiles_mid < ncu && !(var & 2048);
-    if constexpr (EPI >= FP_EPI_LN_BIAS) {   // LN-folded / stats epilogues: the default variant of each tile tier only
-        return big ? launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128>(a, stream)
-             : tiny ? launch_cfg<64, 64, 1, 1, EPI, 6>(a, stream)
-                    : launch_cfg<128, 128, 2, 2, EPI, 6>(a, stream);
-    } else {
+#ifdef FP_LAB
+    if constexpr (EPI < FP_EPI_LN_BIAS) {   // lab build: the alternative kernels of the plain epilogues (A/B runs)
+        if (var != FP_GEMM_DEFAULT_VARIANT) {
 #define FP_GEMM_CASE(V)                                                          \
     case V: return big ? launch_cfg<256, 256, 2, 4, EPI, V>(a, stream)          \
                : tiny ? launch_cfg<64, 64, 1, 1, EPI, V>(a, stream)             \
                       : launch_cfg<128, 128, 2, 2, EPI, V>(a, stream);
-    if (big && (var & 8)) {   // experimental: 16-wave workgroup (4 waves/SIMD), 64x64 per wave, non-pipelined reads
-        {
-            switch (var & (32 | 64)) {   // 32: persistent tile walk, 64: streaming (non-temporal) output stores
-                case 32: return launch_cfg<256, 256, 4, 4, EPI, 4 | 32>(a, stream);
-                case 64: return launch_cfg<256, 256, 4, 4, EPI, 4 | 64>(a, stream);
-                case 96:
-                    if ((var & 128) && (var & 512)) return launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128 | 512>(a, stream);
-                    return (var & 128) ? launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128>(a, stream)
-                                       : launch_cfg<256, 256, 4, 4, EPI, 4 | 96>(a, stream);
-                default: return launch_cfg<256, 256, 4, 4, EPI, 4>(a, stream);
+            if (big && (var & 8)) {   // 16-wave workgroup (4 waves/SIMD), 64x64 per wave
+                switch (var & (32 | 64)) {   // 32: persistent tile walk, 64: streaming (non-temporal) output stores
+                    case 32: return launch_cfg<256, 256, 4, 4, EPI, 4 | 32>(a, stream);
+                    case 64: return launch_cfg<256, 256, 4, 4, EPI, 4 | 64>(a, stream);
+                    case 96:
+                        if ((var & 128) && (var & 512)) return launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128 | 512>(a, stream);
+                        return (var & 128) ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
+                                           : launch_cfg<256, 256, 4, 4, EPI, 4 | 96>(a, stream);
+                    default: return launch_cfg<256, 256, 4, 4, EPI, 4>(a, stream);
+                }
             }
+            switch (var & 7) {   // measured on MI355X (profiles/): 6 is the fastest; 0 is kept as the plain baseline for A/B runs
+                FP_GEMM_CASE(0)
+                default:
+                FP_GEMM_CASE(6)
+            }
+#undef FP_GEMM_CASE
         }
     }
-    switch (var & 7) {   // measured on MI355X (profiles/): 6 is the fastest; 0 is kept as the plain baseline for A/B runs
-        FP_GEMM_CASE(0)
-        default:
-        FP_GEMM_CASE(6)
-    }
-#undef FP_GEMM_CASE
-    return FP_ERR_INVALID;
-    }
+#endif
+    // one kernel per (epilogue, tile tier)
+    return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
+         : tiny ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream)
+                : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);
 }
 
 }  // namespace
@@ -510,8 +524,10 @@ int fp_gemm_gelu_table(const uint16_t** out) {
 
 int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
     FpGemmArgs a = a_in;
+#ifdef FP_LAB
     static const int dbg_env = [] { const char* e = getenv("FP_GEMM_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = fp_opt_get(FP_OPT_GEMM_DBG, dbg_env);
+#endif
     if (a.stat_ld == 0) a.stat_ld = a.M;
     if (epi == FP_EPI_BIAS_GELU || epi == FP_EPI_LN_GELU) {
         const int rc = fp_gemm_gelu_table(&a.gelu_tab);
@@ -550,6 +566,13 @@ int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
             return launch_epi<FP_EPI_LS_RES_STATS>(a, stream);
         default: fp_set_error("gemm: unknown epilogue %d", epi); return FP_ERR_INVALID;
     }
+}
+
+int fp_gemm_gelu_direct(const bf16_t* x, bf16_t* y, size_t n, hipStream_t stream) {
+    if (n == 0) return FP_OK;
+    hipLaunchKernelGGL(gelu_direct_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, n);
+    FP_LAUNCH_CHECK();
+    return FP_OK;
 }
 
 const char* fp_gemm_kernel_name(int epi) {

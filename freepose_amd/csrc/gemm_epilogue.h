@@ -251,7 +251,7 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                             ow[e] = pack_bf2(lo_bf(tw[e]) + lo_bf(qw[e]), hi_bf(tw[e]) + hi_bf(qw[e]));
                         o = u32x4_t{ow[0], ow[1], ow[2], ow[3]};
                     }
-                    if ((p.dbg & 16) && o.x != 0x12345678u) continue;   // measurement only (FP_GEMM_DBG=16): everything but the stores
+                    if (FP_GEMM_DBG_BIT(p, 16) && o.x != 0x12345678u) continue;   // lab build only (gemm_dbg = 16): everything but the stores
                     if constexpr ((VAR & 64) != 0) __builtin_nontemporal_store(o, (u32x4_t*)(p.C + orow * p.ldc + nb2));
                     else *(u32x4_t*)(p.C + orow * p.ldc + nb2) = o;
                 }

@@ -17,6 +17,10 @@ struct fp_ctx {
     // optional RCCL communicator (comm.hip: fp_comm_init); null = single rank
     void* comm = nullptr;
     int comm_rank = 0, comm_size = 1;
+    // run-time options of THIS context (fp_ctx_set_option); -1 = built-in default
+    int opt_ln_fused = -1;       // 1 (default): LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward; 0: separate kernel
+    int opt_raster_tiled = -1;   // default: by triangle count / image size; 1 / 0 force the LDS-tiled / global-buffer strategy
+    int opt_row_split = -1;      // 1 (default): GEMM launches between the tile tiers are split by rows; 0: never
     size_t total() const;
     void release();
 };

@@ -771,11 +771,10 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
     // tile edge: 64 px up to 512-px images, else the smallest multiple of 8 that covers the image with 8 x 8 tiles
     const int side = W > Hh ? W : Hh;
     const int T = side <= 512 ? 64 : (cdiv(side, 8) + 7) / 8 * 8;
-    static int env_tiled = [] { const char* e = getenv("FP_RASTER_TILED"); return e ? atoi(e) : 2; }();
     // measured crossover (576 views, 420^2, profiles/r01_ab.md): tiled 1.7-2.2 ms vs 2.4-2.8 up to 20 k triangles, 2.8 vs 2.3 at
     // 82 k, 7.6 vs 2.9 at 328 k — with ~1-pixel triangles set-up dominates and the tiled path does it twice (bin + tile).
-    // option: -1/unset = choose by triangle count, 0 = global visibility buffer, 1 = tiled
-    const int mode = fp_opt_get(FP_OPT_RASTER_TILED, env_tiled);
+    // fp_ctx_set_option(ctx, "raster_tiled", v): -1 / unset = choose by triangle count, 0 = global visibility buffer, 1 = tiled
+    const int mode = ctx->opt_raster_tiled;
     const bool tiled = T <= 88 && (mode == 1 || (mode != 0 && F <= 32768));
     if (tiled) {
         const int ntx = cdiv(W, T), nty = cdiv(Hh, T), nchunk = cdiv(F, BIN_CHUNK);

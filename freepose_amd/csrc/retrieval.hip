@@ -798,8 +798,13 @@ int fp_topk_select(const uint16_t* keys, int ldk, int N, int Q, int k, int idx_o
     FP_REQUIRE(k > 0 && k <= KMAX && k <= N, "topk: k=%d out of range (N=%d, max %d)", k, N, KMAX);
     FP_REQUIRE(ldk >= N && ldk % 8 == 0, "topk: key row stride %d must be >= N and a multiple of 8", ldk);
     const size_t key_bytes = (size_t)ldk * 2;
+#ifdef FP_LAB
     static int env_sel = [] { const char* e = getenv("FP_TOPK_SELECT"); return e ? atoi(e) : 1; }();   // 0: histogram kernels (A/B)
-    if (env_sel && N <= SEL_CAP) {   // counting select on register-resident keys (no LDS atomics)
+    const bool use_sel = fp_opt_get(FP_OPT_TOPK_SELECT, env_sel) != 0;
+#else
+    constexpr bool use_sel = true;
+#endif
+    if (use_sel && N <= SEL_CAP) {   // counting select on register-resident keys (no LDS atomics)
         const size_t lds = (size_t)SEL_CAP * 2;
         FP_DYN_LDS_ONCE(topk_select_reg_kernel, 128 * 1024);
         hipLaunchKernelGGL(topk_select_reg_kernel, dim3(Q), dim3(SEL_T), lds, s, keys, ldk, N, k, idx_offset, out_scores, out_idx);

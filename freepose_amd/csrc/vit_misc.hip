@@ -410,7 +410,8 @@ int fp_stats_finalize(const float2* part, uint4* ms, float* rstd, int rows, int 
 
 int fp_ln_fold(const bf16_t* W, const bf16_t* gamma, const bf16_t* beta, const bf16_t* bias, bf16_t* Wf, uint4* cb, int N, int K,
                hipStream_t s) {
-    FP_REQUIRE(K % 8 == 0, "ln_fold: K=%d must be a multiple of 8", K);
+    FP_REQUIRE(W && gamma && beta && bias && Wf && cb, "ln_fold: null argument (W / LayerNorm gamma, beta / bias / outputs)");
+    FP_REQUIRE(N > 0 && K % 8 == 0, "ln_fold: N=%d, K=%d (K must be a multiple of 8)", N, K);
     hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, gamma, beta, bias, Wf, cb, N, K);
     FP_LAUNCH_CHECK();
     return FP_OK;

@@ -28,9 +28,20 @@ def context(device: Optional[int] = None):
     return h
 
 
-def set_option(name: str, value: int):
-    """experiment toggle (A/B measurements): 'gemm_variant', 'attn_slots', 'raster_tiled', 'ln_fused'; value < 0 restores the default"""
-    check(_lib.load().fp_set_option(name.encode(), int(value)), "fp_set_option")
+CTX_OPTIONS = ("ln_fused", "raster_tiled", "gemm_row_split")
+
+
+def set_option(name: str, value: int, device: Optional[int] = None):
+    """Run-time option of this process's context on `device` (fp_ctx_set_option): 'ln_fused', 'raster_tiled', 'gemm_row_split';
+    value < 0 restores the default.  Any other name is a measurement toggle of the LAB build ('gemm_variant', 'gemm_dbg',
+    'attn_slots', 'attn_variant', 'topk_select': tools/ call _lib.use_lab() first) and raises on the product library."""
+    lib = _lib.load()
+    if name in CTX_OPTIONS:
+        check(lib.fp_ctx_set_option(context(device), name.encode(), int(value)), "fp_ctx_set_option")
+    elif hasattr(lib, "fp_lab_set_option"):
+        check(lib.fp_lab_set_option(name.encode(), int(value)), "fp_lab_set_option")
+    else:
+        raise RuntimeError(f"option '{name}' exists only in the lab build (python -m freepose_amd.build --lab; _lib.use_lab())")
 
 
 def _dev(t: torch.Tensor, dtype=None) -> torch.Tensor:
@@ -425,9 +436,17 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epi: int = 0, gam
     r = _dev(resid, torch.bfloat16) if resid is not None else None
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    check(lib.fp_op_gemm(ptr(x), K, ptr(w), K, ptr(out), N, ptr(bias), ptr(g), ptr(r), N, M, N, K, epi, current_stream()),
+    check(lib.fp_op_gemm(context(), ptr(x), K, ptr(w), K, ptr(out), N, ptr(bias), ptr(g), ptr(r), N, M, N, K, epi, current_stream()),
           "fp_op_gemm")
     return out
+
+
+def gelu_direct(x: torch.Tensor) -> torch.Tensor:
+    """bf16(0.5 x (1 + erf(x / sqrt 2))) elementwise, the direct fp32 expression the fc1 epilogue's GELU table is filled from"""
+    x = _dev(x, torch.bfloat16)
+    y = torch.empty_like(x)
+    check(_lib.load().fp_op_gelu(ptr(x), ptr(y), x.numel(), current_stream()), "fp_op_gelu")
+    return y
 
 
 def gemm_vt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, npad: int, heads: int,
@@ -438,7 +457,7 @@ def gemm_vt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, npad: int, hea
     N = w.shape[0]
     B = M // npad
     vt = out if out is not None else torch.zeros((B, heads, 64, npad), dtype=torch.bfloat16, device=x.device)
-    check(lib.fp_op_gemm_vt(ptr(x), K, ptr(w), K, ptr(vt), ptr(bias), M, N, K, npad, heads, current_stream()), "fp_op_gemm_vt")
+    check(lib.fp_op_gemm_vt(context(), ptr(x), K, ptr(w), K, ptr(vt), ptr(bias), M, N, K, npad, heads, current_stream()), "fp_op_gemm_vt")
     return vt
 
 

@@ -27,21 +27,19 @@ typedef struct fp_mesh fp_mesh; /* device copy of a triangle mesh for the raster
 
 const char* fp_last_error(void);
 int fp_version(void);
-/* experiment toggles for A/B measurements; value < 0 restores the default.
- *   "gemm_variant": bit 1 s_setprio around MFMA blocks (8-wave kernels), 2 pipelined fragment reads (8-wave kernels),
- *                   4 GELU by LDS table (16 KiB at LDS byte 0; the epilogue slabs move into the last K-tile buffer),
- *                   8 16-wave 256x256 tile, 32 persistent tile walk, 64 streaming epilogue I/O,
- *                   128 split DMA issue + MFMA priority, 512 8-tile column strips (A/B only),
- *                   2048 keep the 128x128 kernel for grids smaller than the CU count (A/B only),
- *                   4096 never split a launch by rows between the 256x256 and the finer tile tiers (A/B only)
- *                   (default 238 = 2|4|8|32|64|128)
- *   "attn_slots":   LDS ring depth of the attention kernel, 2 (default), 3 or 4
- *   "ln_fused":     1 (default) LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward, 0 the separate kernel (A/B)
- *   "raster_tiled": unset = LDS-tiled rasteriser for meshes up to 32 768 triangles and images up to 704 px, global
- *                   visibility-buffer path otherwise; 1 / 0 force one of them (both bit-identical) */
-int fp_set_option(const char* name, int value);
 int fp_ctx_create(int device, fp_ctx** out);
 int fp_ctx_destroy(fp_ctx* ctx);
+/* Run-time options of ONE context (no process-global state, no environment variables: the library never calls getenv).
+ * value < 0 restores the default.
+ *   "ln_fused":       1 (default) LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward on a ViT of this context,
+ *                     0 the separate LayerNorm kernel (same reference rounding points; used by the parity tests)
+ *   "raster_tiled":   unset = LDS-tiled rasteriser for meshes up to 32 768 triangles and images up to 704 px, global
+ *                     visibility-buffer strategy otherwise; 1 / 0 force one of them (both bit-identical)
+ *   "gemm_row_split": 1 (default) a GEMM launch between the tile tiers runs whole rounds of the resident grid on 256x256 tiles and
+ *                     the remaining rows on the finer tiers; 0 never splits (bit-identical; tests/test_gpu_kernels.py)
+ * The measurement variants of earlier rounds (alternative GEMM main loops, attention ring depths, ...) are not in this library:
+ * they are compiled only into the lab build (python -m freepose_amd.build --lab -> libfreepose_hip_lab.so, used by tools/). */
+int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value);
 /* bytes currently held in the context's workspaces (diagnostics) */
 size_t fp_ctx_workspace_bytes(const fp_ctx* ctx);
 
@@ -206,10 +204,10 @@ int fp_allgather_poses(fp_ctx* ctx, const double* d_rows, int n_rows, int row_le
 /* ---- kernel-level entry points (unit parity tests, microbenchmarks; the ViT forward is built from these) */
 /* C[M,N] = epi(X[M,K] W[N,K]^T + bias): epi 0 = bias, 1 = bias+GELU(erf), 2 = resid + gamma*(.) ; bf16, ld* in
  * elements (multiples of 8), K % 64 == 0, N % 16 == 0. */
-int fp_op_gemm(const void* d_X, int ldx, const void* d_W, int ldw, void* d_C, int ldc, const void* d_bias,
+int fp_op_gemm(fp_ctx* ctx, const void* d_X, int ldx, const void* d_W, int ldw, void* d_C, int ldc, const void* d_bias,
                const void* d_gamma, const void* d_resid, int ldr, int M, int N, int K, int epi, void* stream);
 /* V part of qkv stored transposed per head: Vt[b,h,d,t] for rows m = b*npad + t, n = h*64 + d */
-int fp_op_gemm_vt(const void* d_X, int ldx, const void* d_W, int ldw, void* d_Vt, const void* d_bias, int M, int N,
+int fp_op_gemm_vt(fp_ctx* ctx, const void* d_X, int ldx, const void* d_W, int ldw, void* d_Vt, const void* d_bias, int M, int N,
                   int K, int npad, int heads, void* stream);
 /* LayerNorm folded into the consuming linear layer, the way fp_vit_forward runs LN1 -> qkv and LN2 -> fc1 (hub DINOv2 block:
  * x + ls1 * attn(norm1(x)); x + ls2 * mlp(norm2(x)) — the nn.LayerNorm + nn.Linear pairs behind src/pipeline/retrieval/dino.py:18-19):
@@ -224,6 +222,10 @@ int fp_op_ln_linear(fp_ctx* ctx, const void* d_X, int M, int K, const void* d_g_
  * -mean as two-piece bf16 splits —, word 4 rstd = 1 / sigma (f32), word 5 unused. */
 int fp_op_gemm_stats(fp_ctx* ctx, const void* d_X, int ldx, const void* d_W, int ldw, void* d_C, int ldc, const void* d_bias,
                      const void* d_gamma, const void* d_resid, int ldr, int M, int N, int K, float eps, float* d_stat, void* stream);
+/* d_y[i] = bf16(0.5 x (1 + erf(x / sqrt 2))) elementwise on bf16 values in fp32: the direct expression the fc1 epilogue's GELU table
+ * is filled from (hub DINOv2 Mlp act_layer = nn.GELU behind src/pipeline/retrieval/dino.py:18-19); the table-GELU GEMM is tested
+ * against it on all 65 536 bf16 inputs */
+int fp_op_gelu(const void* d_x, void* d_y, size_t n, void* stream);
 /* flash attention forward on QK [B*npad, 2*H*64] (ldqk elements) + Vt [B,H,64,npad] -> O [B*npad, H*64] */
 int fp_op_attention(const void* d_QK, int ldqk, const void* d_Vt, void* d_O, int ldo, int B, int H, int n_tok,
                     int npad, void* stream);

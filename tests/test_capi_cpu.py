@@ -28,6 +28,39 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in freepose_hip.h but not exported"
 
 
+def test_product_library_carries_no_lab():
+    """The shipped library reads no environment variable and has no process-global option: every FP_* measurement toggle, the
+    alternative GEMM / attention kernels and the wrong-numerics hooks exist only in the lab build (-DFP_LAB).  One GEMM kernel per
+    (epilogue, tile tier): 9 epilogues x 3 tiers + the two GELU helper kernels."""
+    from freepose_amd import _lib, build
+    build.build_hip(verbose=False)
+    blob = _lib.LIB_PATH.read_bytes()
+    for needle in (b"FP_GEMM", b"FP_ATTN", b"FP_LN_FUSED", b"FP_TOPK_SELECT", b"FP_RASTER_TILED", b"gemm_dbg", b"gemm_variant"):
+        assert needle not in blob, needle
+    nm = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in nm, "the product library must not read the environment"
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    assert not hasattr(lib, "fp_set_option") and not hasattr(lib, "fp_lab_set_option") and hasattr(lib, "fp_ctx_set_option")
+    obj = ROOT / "freepose_amd" / "lib" / "obj" / "gemm_bf16.o"
+    stubs = [ln for ln in subprocess.run(["nm", str(obj)], capture_output=True, text=True, check=True).stdout.splitlines()
+             if "__device_stub__" in ln]
+    assert 0 < len(stubs) <= 30, len(stubs)
+    for src in (ROOT / "freepose_amd" / "csrc").glob("*"):
+        text = src.read_text()
+        depth, bad = 0, []
+        for i, ln in enumerate(text.splitlines(), 1):     # every getenv / fp_opt_get sits inside an #ifdef FP_LAB block
+            t = ln.strip()
+            if t.startswith("#ifdef FP_LAB"):
+                depth += 1
+            elif depth and t.startswith(("#if ", "#ifdef ", "#ifndef ")):
+                depth += 1
+            elif depth and t.startswith("#endif"):
+                depth -= 1
+            elif depth == 0 and re.search(r"\bgetenv\s*\(|\bfp_opt_get\s*\(", ln) and not t.startswith("//"):
+                bad.append((src.name, i))
+        assert not bad, bad
+
+
 def test_ctypes_table_mirrors_header():
     from freepose_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()

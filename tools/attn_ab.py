@@ -5,6 +5,10 @@ import sys
 import torch
 
 sys.path.insert(0, '.')
+from freepose_amd import _lib
+import os
+if os.environ.get('FP_ATTN_VARIANT') or os.environ.get('FP_LAB_LIB'):
+    _lib.use_lab()   # FP_ATTN_VARIANT exists only in the lab build
 from freepose_amd import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64

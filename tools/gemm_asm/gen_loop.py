@@ -107,11 +107,14 @@ def interleave(mfmas, fillers, rate, start=0):
     return out
 
 
+ABLATE = set()   # measurement only (wrong numerics): "dma" drops the steady-state DMA loads, "read" the steady-state fragment reads
+
+
 def step(buf, first, rate0, rate1, fold_next_tile):
     lines = []
     # ---- phase 0: set A, reads of (g, k-half 1) -> set B ------------------------------------------------------------------
     m0 = [mfma(i, j, V_SETA_X, V_SETA_W, first) for i in range(8) for j in range(8)]
-    lines += interleave(m0, frag_reads(buf, 1, V_SETB_X, V_SETB_W), rate0)
+    lines += interleave(m0, [] if "read" in ABLATE else frag_reads(buf, 1, V_SETB_X, V_SETB_W), rate0)
     lines += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
     if fold_next_tile:   # the table entry requested at the top of the tile has landed (lgkmcnt(0) above): add the wave's row offset
         lines += [f"s_add_u32 {s('nx')}, {s('nx')}, {s('waveoff')}", f"s_add_u32 {s('nw')}, {s('nw')}, {s('waveoff')}"]
@@ -121,8 +124,9 @@ def step(buf, first, rate0, rate1, fold_next_tile):
     reads = frag_reads(buf ^ 1, 0, V_SETA_X, V_SETA_W)
     fill = []
     for q in range(16):
-        fill += groups[q]
-        fill.append(reads[q])
+        fill += [g for g in groups[q] if not ("dma" in ABLATE and g.startswith("buffer_load"))]
+        if "read" not in ABLATE:
+            fill.append(reads[q])
     fill += adv
     lines += interleave(m1, fill, rate1)
     lines += ["s_waitcnt lgkmcnt(0)"]
@@ -217,7 +221,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rate0", type=float, default=1.0)
     ap.add_argument("--rate1", type=float, default=2.0)
+    ap.add_argument("--ablate", default="", help="comma list of dma, read (measurement only, wrong numerics)")
     a = ap.parse_args()
+    ABLATE.update(x for x in a.ablate.split(",") if x)
     L = program(a.rate0, a.rate1)
     print(f"// generated by tools/gemm_asm/gen_loop.py --rate0 {a.rate0} --rate1 {a.rate1}: {len(L)} lines; do not edit")
     print("#define FP_ASM_LOOP_TEXT \\")

@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/gdbg
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
-BENCH="python $REPO/bench.py --no-cpu-baseline --video-frames 0 --steps 1 --warmup 1"
+BENCH="python $REPO/bench.py --lab --no-cpu-baseline --video-frames 0 --steps 1 --warmup 1"   # FP_GEMM_DBG exists in the lab build only
 for d in ${DBGS:-0 1 2 4 7}; do
   FP_GEMM_DBG=$d timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s$d -o b -- $BENCH > $OUT/stdout$d.log 2>&1
   f=$(find $OUT/s$d -name "*kernel_stats*.csv" | head -1)

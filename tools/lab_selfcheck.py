@@ -1,0 +1,71 @@
+"""Self-check of the LAB build (libfreepose_hip_lab.so, `python -m freepose_amd.build --lab`): the measurement variants the A/B
+tools switch between still compute what the product computes.  Run by tests/test_gpu_lab.py in its own process (the product and the
+lab library are never loaded together).  python tools/lab_selfcheck.py"""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from freepose_amd import _lib  # noqa: E402
+_lib.use_lab()
+from freepose_amd import ops  # noqa: E402
+
+
+def main():
+    assert _lib.is_lab() and hasattr(_lib.load(), "fp_lab_set_option")
+    g = torch.Generator().manual_seed(5)
+    # 1. table GELU == direct formula through every GEMM main-loop variant (0: plain loops + direct erff, 6: pipelined 8-wave /
+    #    128x128 kernels with the table, default 238: the product's kernels), all 65 536 bf16 inputs, 128x128 and 256x256 tiers
+    pats = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+    for M_rep, N in ((1, 64), (4, 256)):
+        x = torch.zeros((65536 * M_rep, 64), dtype=torch.bfloat16)
+        x[:, 0] = pats.repeat(M_rep)
+        w = torch.zeros((N, 64), dtype=torch.bfloat16)
+        w[:, 0] = 1.0
+        bias = torch.zeros((N,), dtype=torch.bfloat16)
+        outs = {}
+        for var in (-1, 6, 0, 14, 110):
+            ops.set_option("gemm_variant", var)
+            outs[var] = ops.gemm(x, w, bias, 1).cpu().view(torch.int16)
+        ops.set_option("gemm_variant", -1)
+        finite = ~torch.isnan(pats.float()).repeat(M_rep)
+        for var, o in outs.items():
+            assert torch.equal(o[finite], outs[-1][finite]), f"gemm_variant {var} differs (N={N})"
+    # 2. every variant of the plain / LayerScale+residual GEMM gives the product's bits on a ragged shape
+    M, N, K = 4000, 1024, 1024
+    x = (torch.randn((M, K), generator=g)).to(torch.bfloat16)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16)
+    bias, gamma = torch.randn((N,), generator=g).to(torch.bfloat16), torch.randn((N,), generator=g).to(torch.bfloat16)
+    resid = torch.randn((M, N), generator=g).to(torch.bfloat16)
+    ref0, ref2 = ops.gemm(x, w, bias, 0).cpu(), ops.gemm(x, w, bias, 2, gamma=gamma, resid=resid).cpu()
+    for var in (0, 6, 14, 46, 110, 238 | 256, 238 | 2048, 238 | 512):
+        ops.set_option("gemm_variant", var)
+        assert torch.equal(ops.gemm(x, w, bias, 0).cpu(), ref0), var
+        assert torch.equal(ops.gemm(x, w, bias, 2, gamma=gamma, resid=resid).cpu(), ref2), var
+    ops.set_option("gemm_variant", -1)
+    # 3. attention: ring depths and the short-tail-off flavour agree to rounding (the exponent reference differs by tile order only)
+    B, H, n_tok = 3, 16, 905
+    npad = (n_tok + 15) // 16 * 16
+    qk = (torch.randn((B * npad, 2 * H * 64), generator=g) * 0.5).to(torch.bfloat16)
+    vt = torch.randn((B, H, 64, npad), generator=g).to(torch.bfloat16)
+    base = ops.attention(qk, vt, n_tok).float().cpu()
+    for name, val in (("attn_slots", 3), ("attn_slots", 4), ("attn_variant", 8)):
+        ops.set_option(name, val)
+        o = ops.attention(qk, vt, n_tok).float().cpu()
+        ops.set_option(name, -1)
+        assert (o - base).abs().max().item() <= 2e-2, (name, val)
+    # 4. measurement hooks are reachable here (and only here): loop-only GEMM runs without writing its output
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    big = x.repeat(20, 1)
+    outb = torch.full((big.shape[0], N), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.set_option("gemm_dbg", 8)
+    ops.gemm(big, w, bias, 0, out=outb)
+    ops.set_option("gemm_dbg", -1)
+    torch.cuda.synchronize()
+    assert (outb == 7.0).all(), "gemm_dbg = 8 (no epilogue) still wrote the output"
+    print("LAB_SELFCHECK_OK")
+
+
+if __name__ == "__main__":
+    main()

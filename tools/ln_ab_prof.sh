@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
 BENCH="python $REPO/bench.py --no-cpu-baseline --video-frames 0 --steps 1 --warmup 1"
 for f in 0 1; do
-  FP_LN_FUSED=$f timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s$f -o b -- $BENCH > $OUT/stdout$f.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s$f -o b -- $BENCH --ln-fused $f > $OUT/stdout$f.log 2>&1
   find $OUT/s$f -name "*kernel_stats*.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_lnf$f.csv
   rm -rf $OUT/s$f
 done

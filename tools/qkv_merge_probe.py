@@ -7,6 +7,8 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from freepose_amd import _lib  # noqa: E402
+_lib.use_lab()   # measurement variants / hooks live in libfreepose_hip_lab.so only (python -m freepose_amd.build --lab)
 from freepose_amd import ops  # noqa: E402
 
 B, npad, K = 214, 1376, 1024

@@ -45,7 +45,7 @@ def _stale(target: Path, deps) -> bool:
 def build_hip(force: bool = False, verbose: bool = True, lab: bool = False) -> Path:
     """the product library, or with lab=True the lab build (-DFP_LAB) next to it"""
     srcs = sorted(CSRC.glob("*.hip"))
-    hdrs = sorted(CSRC.glob("*.h")) + [REPO / "include" / "freepose_hip.h"]
+    hdrs = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + [REPO / "include" / "freepose_hip.h"]
     objdir = LIBDIR / "obj_lab" if lab else OBJDIR
     lib_out = LAB_LIB if lab else LIB
     extra = ["-DFP_LAB"] if lab else []

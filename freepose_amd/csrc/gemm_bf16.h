@@ -96,6 +96,9 @@ __device__ __forceinline__ void fp_gemm_tile(int block, int nblocks, int tiles_m
 int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream);
 // builds (once per device) and returns the bf16 -> bf16 GELU table the fc1 epilogue gathers from
 int fp_gemm_gelu_table(const uint16_t** out);
+// the hand-scheduled 256x256 kernel (gemm_asm.hip): the big-tile tier of the row-major epilogues
+bool fp_gemm_asm_supported(const FpGemmArgs& a, int epi);
+int fp_gemm_asm(const FpGemmArgs& a, int epi, hipStream_t stream);
 // y[i] = bf16(gelu_erf(x[i])): the direct expression, elementwise (test entry fp_op_gelu)
 int fp_gemm_gelu_direct(const bf16_t* x, bf16_t* y, size_t n, hipStream_t stream);
 // name of the kernel variant used for (epi) — for profiles / bench bookkeeping

@@ -1,6 +1,8 @@
 // Fused GEMM epilogues shared by the GEMM kernels (same accumulator layout: acc[TC][TR], R operand = permuted rows in the
 // MFMA A slot, so a lane owns 4*TR consecutive R indices for each of its TC C-operand rows).
 #pragma once
+#include <type_traits>
+
 #include "gemm_bf16.h"
 
 namespace fp_gemm {
@@ -91,6 +93,47 @@ constexpr int EPI_STAGE_BYTES = 2048;
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the accumulator accessors need constant indices)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Accumulator accessors.  The epilogues consume a wave's accumulators in 16-token x 64-feature blocks: for row block I and
+// 64-feature group G the lane's 16 values are acc[I][4 G + j][r], j = 0..3, r = 0..3 (feature 64 G + 16 lg + 4 j + r of token 16 I + li).
+//   RegAcc : the compiler-managed f32x4 array of the HIP main loops (gemm_bf16.hip)
+//   AgprAcc: the accumulator file of the hand-scheduled main loop (gemm_asm.hip): fragment f = I TR + jj lives in a[4 f .. 4 f + 3],
+//            so a block is the 16 CONSECUTIVE registers a[4 (I TR + 4 G) ..]; read with v_accvgpr_read (constant indices)
+template <int TC, int TR>
+struct RegAcc {
+    f32x4_t (&a)[TC][TR];
+    template <int I, int G>
+    __device__ __forceinline__ void load16(float (&v)[16]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = a[I][G * 4 + j][r];
+    }
+};
+template <int TR>
+struct AgprAcc {
+    template <int I, int G>
+    __device__ __forceinline__ void load16(float (&v)[16]) const {
+        constexpr int B = 4 * (I * TR + 4 * G);
+        asm volatile("v_accvgpr_read_b32 %0, a[%c8]\n\tv_accvgpr_read_b32 %1, a[%c9]\n\tv_accvgpr_read_b32 %2, a[%c10]\n\tv_accvgpr_read_b32 %3, a[%c11]\n\t"
+                     "v_accvgpr_read_b32 %4, a[%c12]\n\tv_accvgpr_read_b32 %5, a[%c13]\n\tv_accvgpr_read_b32 %6, a[%c14]\n\tv_accvgpr_read_b32 %7, a[%c15]"
+                     : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7])
+                     : "n"(B), "n"(B + 1), "n"(B + 2), "n"(B + 3), "n"(B + 4), "n"(B + 5), "n"(B + 6), "n"(B + 7));
+        asm volatile("v_accvgpr_read_b32 %0, a[%c8]\n\tv_accvgpr_read_b32 %1, a[%c9]\n\tv_accvgpr_read_b32 %2, a[%c10]\n\tv_accvgpr_read_b32 %3, a[%c11]\n\t"
+                     "v_accvgpr_read_b32 %4, a[%c12]\n\tv_accvgpr_read_b32 %5, a[%c13]\n\tv_accvgpr_read_b32 %6, a[%c14]\n\tv_accvgpr_read_b32 %7, a[%c15]"
+                     : "=v"(v[8]), "=v"(v[9]), "=v"(v[10]), "=v"(v[11]), "=v"(v[12]), "=v"(v[13]), "=v"(v[14]), "=v"(v[15])
+                     : "n"(B + 8), "n"(B + 9), "n"(B + 10), "n"(B + 11), "n"(B + 12), "n"(B + 13), "n"(B + 14), "n"(B + 15));
+    }
+};
+
 // `stg`: this wave's private EPI_STAGE_BYTES slab of LDS (unused by the transposed epilogue).
 //
 // Non-transposed epilogues run in two phases per 16-token x 64-feature block of the wave tile:
@@ -114,9 +157,9 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 // FP_EPI_LS_RES_STATS (producer side): phase 2 additionally reduces (sum, sum of squares) of each bf16 OUTPUT row over the wave's
 // 64 columns — v_dot2c_f32_bf16 on the packed pairs, xor-butterfly over the row's 8 lanes, fixed order — and writes them to
 // stat_part[n/64][m].  The partials are per 64-column block whatever the tile shape, so every tile tier produces the same bits.
-template <int BM, int BN, int WM, int WN, int EPI, int VAR, int TC, int TR>
-__device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC][TR], int m0, int n0, int wm, int wn,
-                                         int li, int lg, char* stg, const char* gelu_tab = nullptr) {
+template <int BM, int BN, int WM, int WN, int EPI, int VAR, int TC, int TR, class Acc>
+__device__ __forceinline__ void epilogue_acc(const FpGemmArgs& p, const Acc& accs, int m0, int n0, int wm, int wn,
+                                             int li, int lg, char* stg, const char* gelu_tab = nullptr) {
     // Everything below that depends only on the lane (slab addresses, row / chunk roles, output offsets) is re-derived per tile from
     // these two laundered values: left to itself hipcc hoists it out of the persistent tile loop, keeps it live through the K loop
     // of a 128-VGPR kernel and spills it — and a scratch reload inside the epilogue waits (vmcnt is in-order) for every output
@@ -137,8 +180,8 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
         char* wr = stg + li * 128;
         const int wkey = (li >> 1) & 7;
         const int mbase = m0 + wm * (16 * TM);
-#pragma unroll
-        for (int grp = 0; grp < NG; ++grp) {
+        static_for<0, NG>([&](auto grp_c) {
+            constexpr int grp = decltype(grp_c)::value;
             const int nbw = n0 + wn * (16 * TN) + grp * 64;     // the wave's 64-feature group
             const int nb1 = nbw + lg * 16;                      // phase-1 features of this lane
             const int nb2 = nbw + pslot * 8;                    // phase-2 features of this lane
@@ -169,17 +212,14 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
 #pragma unroll
                 for (int i = 0; i < TM; ++i) rs[i] = p.ln_rstd[min(mbase + 16 * i + li, p.M - 1)];
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            static_for<0, TM>([&](auto i_c) {
+                constexpr int i = decltype(i_c)::value;
                 if constexpr (LSRES) {
                     if (i + 1 < TM) load_res(i + 1, res[(i + 1) & 1]);
                 }
                 // ---- phase 1 ----------------------------------------------------------------------------------------
                 float v[16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][grp * 4 + j][r];
+                accs.template load16<i, grp>(v);
                 if constexpr (LNF) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] *= rs[i];
@@ -255,9 +295,10 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
                     if constexpr ((VAR & 64) != 0) __builtin_nontemporal_store(o, (u32x4_t*)(p.C + orow * p.ldc + nb2));
                     else *(u32x4_t*)(p.C + orow * p.ldc + nb2) = o;
                 }
-            }
-        }
+            });
+        });
     } else if constexpr (TM == 4) {
+        auto& acc = accs.a;   // transposed stores: compiler-managed accumulators only
         // transposed V store, staged like the row-major epilogues with the roles swapped: a block is 16 FEATURES (rows,
         // lane li) x 64 TOKENS (lane lg owns 16 consecutive ones); phase 2 writes one full 128-B line of Vt[b,h,d,:]
         // (64 tokens of one feature) per 8 lanes.  Blocks never straddle a crop: npad and the tile origin are
@@ -313,6 +354,7 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
             }
         }
     } else {
+        auto& acc = accs.a;
         // transposed V store (direct form, wave tiles taller than 64 tokens): lane owns, for each of its TN features, 4*TM consecutive tokens
         static_assert(!LNF, "the LN-folded V store exists for 64-token wave tiles only");
         constexpr int RUN = 4 * TM;
@@ -344,6 +386,13 @@ __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC]
             }
         }
     }
+}
+
+// the HIP main loops' entry: accumulators in a compiler-managed register array
+template <int BM, int BN, int WM, int WN, int EPI, int VAR, int TC, int TR>
+__device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC][TR], int m0, int n0, int wm, int wn,
+                                         int li, int lg, char* stg, const char* gelu_tab = nullptr) {
+    epilogue_acc<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, RegAcc<TC, TR>{acc}, m0, n0, wm, wn, li, lg, stg, gelu_tab);
 }
 
 }  // namespace fp_gemm

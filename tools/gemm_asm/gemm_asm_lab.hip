@@ -34,21 +34,24 @@ struct Args {
     uint32_t recX, recW;
 };
 
-__global__ __launch_bounds__(256, 1) void gemm_asm_kernel(Args p) {
+constexpr int NWN = FP_ASM_NWN, NWAVE = 2 * NWN, TRF = 16 / NWN, NFRAG = 8 * TRF;   // waves along N, waves, W fragments per wave, accumulator fragments
+constexpr size_t DUMP_WAVE = (size_t)NFRAG * 1024, DUMP_TILE = DUMP_WAVE * NWAVE;
+
+__global__ __launch_bounds__(NWAVE * 64) void gemm_asm_kernel(Args p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 stages x 64 KiB at LDS address 0 (the asm uses absolute addresses)
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wm = wave >> 1, wn = wave & 1;
+    const uint32_t wm = wave / NWN, wn = wave % NWN;
     const uint32_t li = lane & 15, lg = lane >> 4;
     const uint32_t K2 = (uint32_t)p.K * 2u;
     const uint32_t vdma = (uint32_t)(lane >> 3) * K2 + ((((uint32_t)lane & 7u) ^ ((uint32_t)lane >> 3)) << 4);
     const uint32_t sw = (lg ^ (li & 7u)) << 4;
     const uint32_t vax = (wm * 128u + li) * 128u + sw;
-    const uint32_t vaw = 32768u + (wn * 128u + li) * 128u + sw;
-    const uint32_t vout = (uint32_t)lane * 16u + wave * 65536u;
+    const uint32_t vaw = 32768u + (wn * (256u / NWN) + li) * 128u + sw;
+    const uint32_t vout = (uint32_t)lane * 16u + wave * (uint32_t)DUMP_WAVE;
     const uint64_t xa = (uint64_t)p.X, wa = (uint64_t)p.W;
     const uint64_t ta = (uint64_t)(p.table + (size_t)blockIdx.x * p.tab_stride);
-    const uint64_t oa = (uint64_t)p.out + (size_t)blockIdx.x * (size_t)(p.tab_stride - 1) * 4u * 65536u;
+    const uint64_t oa = (uint64_t)p.out + (size_t)blockIdx.x * (size_t)(p.tab_stride - 1) * DUMP_TILE;
     const uint32_t nt = (uint32_t)p.ntiles_wg[blockIdx.x];
     if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
     if (nt == 0) return;
@@ -137,13 +140,13 @@ static void free_problem(Problem& p) { hipFree(p.X); hipFree(p.W); hipFree(p.tab
 
 static void launch(const Problem& p, float* out, int store) {
     Args a{p.X, p.W, p.table, out, p.ntw, p.K, p.tps + 1, store, 0xffffffffu, 0xffffffffu};
-    hipLaunchKernelGGL(gemm_asm_kernel, dim3(p.grid), dim3(256), 131072, 0, a);
+    hipLaunchKernelGGL(gemm_asm_kernel, dim3(p.grid), dim3(NWAVE * 64), 131072, 0, a);
 }
 
 static bool check(int M, int N, int K, int ncu, int force_grid) {
     Problem p = make_problem(M, N, K, ncu, force_grid, false);
     float *out, *ref;
-    const size_t out_bytes = (size_t)p.grid * p.tps * 4 * 65536;
+    const size_t out_bytes = (size_t)p.grid * p.tps * DUMP_TILE;
     CK(hipMalloc(&out, out_bytes)); CK(hipMemset(out, 0xff, out_bytes));
     CK(hipMalloc(&ref, (size_t)p.Mpad * N * 4));
     hipLaunchKernelGGL(ref_kernel, dim3((N + 255) / 256, p.Mpad), dim3(256), 0, 0, p.X, p.W, p.Mpad, N, K, ref);
@@ -158,13 +161,13 @@ static bool check(int M, int N, int K, int ncu, int force_grid) {
         for (int sq = 0; sq < p.tps; ++sq) {
             const auto mn = p.tile_mn[(size_t)b * p.tps + sq];
             if (mn[0] < 0) continue;
-            for (int w = 0; w < 4; ++w)
-                for (int f = 0; f < 64; ++f)
+            for (int w = 0; w < NWAVE; ++w)
+                for (int f = 0; f < NFRAG; ++f)
                     for (int l = 0; l < 64; ++l)
                         for (int r = 0; r < 4; ++r) {
-                            const int i = f >> 3, j = f & 7;
-                            const int m = mn[0] + (w >> 1) * 128 + 16 * i + (l >> 4) * 4 + r, n = mn[1] + (w & 1) * 128 + 16 * j + (l & 15);
-                            const float got = ho[((((size_t)b * p.tps + sq) * 4 + w) * 64 + f) * 256 + l * 4 + r];
+                            const int i = f / TRF, j = f % TRF;
+                            const int m = mn[0] + (w / NWN) * 128 + 16 * i + (l >> 4) * 4 + r, n = mn[1] + (w % NWN) * (256 / NWN) + 16 * j + (l & 15);
+                            const float got = ho[((((size_t)b * p.tps + sq) * NWAVE + w) * NFRAG + f) * 256 + l * 4 + r];
                             const float want = hr[(size_t)m * N + n];
                             const double e = fabs((double)got - want);
                             if (!(e <= 1e-3 + 1e-3 * fabs(want))) ++bad;

@@ -33,11 +33,31 @@ S = dict(
     ldsX0=57, ldsW0=58, ldsX1=59, ldsW1=60,
     waveoff=61, tmp=62,
 )
-V_SETA_X, V_SETA_W, V_SETB_X, V_SETB_W = 64, 96, 128, 160
-V_DMA = 192
-V_AX = {(0, 0): 193, (0, 1): 194, (1, 0): 195, (1, 1): 196}   # (buffer, k-half) -> LDS read base of the X fragments
-V_AW = {(0, 0): 197, (0, 1): 198, (1, 0): 199, (1, 1): 200}
-V_OUT = 201
+# geometry: 2 x NWN waves; a wave owns 128 rows of X (TC = 8 fragments) and 256 / NWN rows of W (TR fragments)
+NWN = 2
+TC, TR, NW, PCS = 8, 8, 4, 8           # PCS = DMA pieces per operand, wave and stage (32 / NW)
+V0 = 64                                # first fixed VGPR
+V_SETA_X = V_SETA_W = V_SETB_X = V_SETB_W = V_DMA = V_OUT = 0
+V_AX, V_AW = {}, {}
+
+
+def set_geometry(nwn):
+    global NWN, TR, NW, PCS, V0, V_SETA_X, V_SETA_W, V_SETB_X, V_SETB_W, V_DMA, V_OUT
+    NWN = nwn
+    TR = 16 // nwn
+    NW = 2 * nwn
+    PCS = 32 // NW
+    V0 = 64 if nwn == 2 else 16        # two waves per SIMD: everything (accumulators included) must fit 256 registers
+    V_SETA_X = V0
+    V_SETA_W = V_SETA_X + 4 * TC
+    V_SETB_X = V_SETA_W + 4 * TR
+    V_SETB_W = V_SETB_X + 4 * TC
+    V_DMA = V_SETB_W + 4 * TR
+    base = V_DMA + 1
+    for n, key in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        V_AX[key] = base + n            # (buffer, k-half) -> LDS read base of the X fragments
+        V_AW[key] = base + 4 + n
+    V_OUT = base + 8
 
 
 def s(name, off=0):
@@ -53,7 +73,7 @@ def vr(base, n=4):
 
 
 def mfma(i, j, xs, ws, first):
-    f = i * 8 + j
+    f = i * TR + j
     acc = f"a[{4 * f}:{4 * f + 3}]"
     c = "0" if first else acc
     return f"v_mfma_f32_16x16x32_bf16 {acc}, {vr(xs + 4 * i)}, {vr(ws + 4 * j)}, {c}"
@@ -62,9 +82,9 @@ def mfma(i, j, xs, ws, first):
 def frag_reads(buf, kh, xs, ws):
     """W fragments first, then X0..X7: the next phase's MFMA order (i outer, j inner) needs W0-7 + X0 first, X7 last"""
     out = []
-    for j in range(8):
+    for j in range(TR):
         out.append(f"ds_read_b128 {vr(ws + 4 * j)}, v{V_AW[(buf, kh)]} offset:{j * 2048}")
-    for i in range(8):
+    for i in range(TC):
         out.append(f"ds_read_b128 {vr(xs + 4 * i)}, v{V_AX[(buf, kh)]} offset:{i * 2048}")
     return out
 
@@ -72,13 +92,13 @@ def frag_reads(buf, kh, xs, ws):
 def dma_pieces(buf):
     """16 pieces of the stage at the DMA cursor into buffer `buf`, then the cursor advance; each piece = [m0, soffset, load]"""
     groups = []
-    for q in range(8):
+    for q in range(PCS):
         g = []
         g.append(f"s_mov_b32 m0, {s('ldsX0' if buf == 0 else 'ldsX1')}" if q == 0 else "s_add_u32 m0, m0, 0x400")
         g.append(f"s_add_u32 {s('t')}, {s('dx')}, {s('dk')}" if q == 0 else f"s_add_u32 {s('t')}, {s('t')}, {s('stride8')}")
         g.append(f"buffer_load_dwordx4 v{V_DMA}, {srange('rsX', 4)}, {s('t')} offen lds")
         groups.append(g)
-    for q in range(8):
+    for q in range(PCS):
         g = []
         g.append(f"s_mov_b32 m0, {s('ldsW0' if buf == 0 else 'ldsW1')}" if q == 0 else "s_add_u32 m0, m0, 0x400")
         g.append(f"s_add_u32 {s('t')}, {s('dw')}, {s('dk')}" if q == 0 else f"s_add_u32 {s('t')}, {s('t')}, {s('stride8')}")
@@ -110,31 +130,61 @@ def interleave(mfmas, fillers, rate, start=0):
 ABLATE = set()   # measurement only (wrong numerics): "dma" drops the steady-state DMA loads, "read" the steady-state fragment reads
 
 
-def step(buf, first, rate0, rate1, fold_next_tile):
+STAGGER = "none"   # "comb": wave w issues its DMA piece q behind MFMA 4q + w of phase 1; "block": behind MFMAs 16w .. 16w + 15
+
+
+def place(mfmas, slots):
+    """slots: {mfma index: [instructions issued right behind it]}"""
+    out = []
+    for m, ins in enumerate(mfmas):
+        out.append(ins)
+        out.extend(slots.get(m, []))
+    return out
+
+
+def step(buf, first, rate0, rate1, fold_next_tile, wave=0):
     lines = []
     # ---- phase 0: set A, reads of (g, k-half 1) -> set B ------------------------------------------------------------------
-    m0 = [mfma(i, j, V_SETA_X, V_SETA_W, first) for i in range(8) for j in range(8)]
+    m0 = [mfma(i, j, V_SETA_X, V_SETA_W, first) for i in range(TC) for j in range(TR)]
     lines += interleave(m0, [] if "read" in ABLATE else frag_reads(buf, 1, V_SETB_X, V_SETB_W), rate0)
     lines += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
     if fold_next_tile:   # the table entry requested at the top of the tile has landed (lgkmcnt(0) above): add the wave's row offset
         lines += [f"s_add_u32 {s('nx')}, {s('nx')}, {s('waveoff')}", f"s_add_u32 {s('nw')}, {s('nw')}, {s('waveoff')}"]
     # ---- phase 1: set B, DMA of stage g+2 -> this buffer, reads of (g+1, k-half 0) from the other buffer -> set A -----------
-    m1 = [mfma(i, j, V_SETB_X, V_SETB_W, False) for i in range(8) for j in range(8)]
+    m1 = [mfma(i, j, V_SETB_X, V_SETB_W, False) for i in range(TC) for j in range(TR)]
     groups, adv = dma_pieces(buf)
     reads = frag_reads(buf ^ 1, 0, V_SETA_X, V_SETA_W)
     fill = []
-    for q in range(16):
+    nrd = len(reads)
+    for q in range(2 * PCS):
         fill += [g for g in groups[q] if not ("dma" in ABLATE and g.startswith("buffer_load"))]
         if "read" not in ABLATE:
-            fill.append(reads[q])
+            fill += reads[q * nrd // (2 * PCS):(q + 1) * nrd // (2 * PCS)]
     fill += adv
-    lines += interleave(m1, fill, rate1)
+    if STAGGER == "none":
+        lines += interleave(m1, fill, rate1)
+    else:
+        slots = {}
+        for q in range(16):
+            m = (4 * q + wave) if STAGGER == "comb" else (16 * wave + q)
+            slots.setdefault(m, []).extend(g for g in groups[q] if not ("dma" in ABLATE and g.startswith("buffer_load")))
+            if "read" not in ABLATE:
+                mr = (4 * q + (wave + 2) % 4) if STAGGER == "comb" else ((16 * wave + 32 + q) % 64 if q < 8 or True else 0)
+                slots.setdefault(mr % 64, []).append(reads[q])
+        slots.setdefault(63, []).extend(adv)
+        if STAGGER == "block":   # reads in ascending issue order: re-place them at 4 q + 2 (they must issue W0..7, X0..7 in order)
+            for m in list(slots):
+                slots[m] = [x for x in slots[m] if not x.startswith("ds_read")]
+            if "read" not in ABLATE:
+                for q in range(16):
+                    slots.setdefault(4 * q + 2, []).append(reads[q])
+        lines += place(m1, slots)
     lines += ["s_waitcnt lgkmcnt(0)"]
     return lines
 
 
-def body(first, rate0, rate1):
-    return step(0, first, rate0, rate1, first) + step(1, False, rate0, rate1, False)
+def body(first, rate0, rate1, wave=0):
+    return step(0, first, rate0, rate1, first, wave) + step(1, False, rate0, rate1, False, wave)
 
 
 def prologue():
@@ -149,8 +199,9 @@ def prologue():
     a(f"s_lshr_b32 {s('nkh')}, %9, 1"); a(f"s_sub_u32 {s('nkh')}, {s('nkh')}, 1")
     a(f"s_mov_b32 {s('ntile')}, %10"); a(f"s_mov_b32 {s('store')}, %13")
     # wave-dependent: row offset of the wave's pieces (wave * 64 rows), LDS destinations of its pieces
-    a(f"s_lshl_b32 {s('tmp')}, %14, 6"); a(f"s_mul_i32 {s('waveoff')}, {s('tmp')}, %8")
-    a(f"s_lshl_b32 {s('ldsX0')}, %14, 13"); a(f"s_add_u32 {s('ldsW0')}, {s('ldsX0')}, 0x8000")
+    sh_rows, sh_lds = (6, 13) if NWN == 2 else (5, 12)   # rows of X / W a wave moves per stage: 64 or 32; its LDS bytes: 8 or 4 KiB
+    a(f"s_lshl_b32 {s('tmp')}, %14, {sh_rows}"); a(f"s_mul_i32 {s('waveoff')}, {s('tmp')}, %8")
+    a(f"s_lshl_b32 {s('ldsX0')}, %14, {sh_lds}"); a(f"s_add_u32 {s('ldsW0')}, {s('ldsX0')}, 0x8000")
     a(f"s_add_u32 {s('ldsX1')}, {s('ldsX0')}, 0x10000"); a(f"s_add_u32 {s('ldsW1')}, {s('ldsW0')}, 0x10000")
     a(f"v_mov_b32 v{V_DMA}, %15")
     a(f"v_mov_b32 v{V_AX[(0, 0)]}, %16"); a(f"v_xor_b32 v{V_AX[(0, 1)]}, 64, v{V_AX[(0, 0)]}")
@@ -170,7 +221,7 @@ def prologue():
         for g in groups:
             L.extend(g)
         L.extend(adv)
-    a("s_waitcnt vmcnt(16)"); a("s_barrier")
+    a(f"s_waitcnt vmcnt({2 * PCS})"); a("s_barrier")
     L.extend(frag_reads(0, 0, V_SETA_X, V_SETA_W))
     a("s_waitcnt lgkmcnt(0)")
     return L
@@ -178,42 +229,57 @@ def prologue():
 
 def epilogue():
     L = ["s_nop 15", "s_nop 15"]
-    for f in range(64):
+    for f in range(TC * TR):
         L.append(f"global_store_dwordx4 v{V_OUT}, a[{4 * f}:{4 * f + 3}], {srange('out', 2)}")
         L.append(f"v_add_u32 v{V_OUT}, 0x400, v{V_OUT}")
-    L.append(f"v_add_u32 v{V_OUT}, 0x30000, v{V_OUT}")
+    L.append(f"v_add_u32 v{V_OUT}, {hex((NW - 1) * TC * TR * 1024)}, v{V_OUT}")
     L += ["s_nop 7"]
     return L
 
 
 def program(rate0, rate1):
     L = prologue()
-    L.append("L_tile_%=:")
+    if STAGGER == "none":
+        return L + wave_program(rate0, rate1, 0, "")
+    for w in (1, 2, 3):
+        L.append(f"s_cmp_eq_u32 %14, {w}")
+        L.append(f"s_cbranch_scc1 L_wave{w}_%=")
+    for w in (0, 1, 2, 3):
+        L.append(f"L_wave{w}_%=:")
+        L += wave_program(rate0, rate1, w, f"w{w}")
+        L.append("s_branch L_end_%=")
+    L.append("L_end_%=:")
+    return L
+
+
+def wave_program(rate0, rate1, wave, tag):
+    L = []
+    L.append(f"L_tile{tag}_%=:")
     L.append(f"s_load_dwordx2 {srange('nx', 2)}, {srange('tab', 2)}, {s('seq8')}")
     L.append(f"s_add_u32 {s('seq8')}, {s('seq8')}, 8")
-    L += body(True, rate0, rate1)
+    L += body(True, rate0, rate1, wave)
     L.append(f"s_mov_b32 {s('cnt')}, {s('nkh')}")
     L.append(f"s_cmp_eq_u32 {s('cnt')}, 0")
-    L.append("s_cbranch_scc1 L_kdone_%=")
-    L.append("L_k_%=:")
-    L += body(False, rate0, rate1)
+    L.append(f"s_cbranch_scc1 L_kdone{tag}_%=")
+    L.append(f"L_k{tag}_%=:")
+    L += body(False, rate0, rate1, wave)
     L.append(f"s_sub_u32 {s('cnt')}, {s('cnt')}, 1")
     L.append(f"s_cmp_lg_u32 {s('cnt')}, 0")
-    L.append("s_cbranch_scc1 L_k_%=")
-    L.append("L_kdone_%=:")
+    L.append(f"s_cbranch_scc1 L_k{tag}_%=")
+    L.append(f"L_kdone{tag}_%=:")
     L.append(f"s_cmp_eq_u32 {s('store')}, 0")
-    L.append("s_cbranch_scc1 L_nostore_%=")
+    L.append(f"s_cbranch_scc1 L_nostore{tag}_%=")
     L += epilogue()
-    L.append("L_nostore_%=:")
+    L.append(f"L_nostore{tag}_%=:")
     L.append(f"s_sub_u32 {s('ntile')}, {s('ntile')}, 1")
     L.append(f"s_cmp_lg_u32 {s('ntile')}, 0")
-    L.append("s_cbranch_scc1 L_tile_%=")
+    L.append(f"s_cbranch_scc1 L_tile{tag}_%=")
     L.append("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return L
 
 
 def clobbers():
-    c = [f"v{i}" for i in range(64, 208)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(32, 64)]
+    c = [f"v{i}" for i in range(V0, V_OUT + 1)] + [f"a{i}" for i in range(4 * TC * TR)] + [f"s{i}" for i in range(32, 64)]
     return c + ["memory", "scc", "vcc"]
 
 
@@ -221,11 +287,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rate0", type=float, default=1.0)
     ap.add_argument("--rate1", type=float, default=2.0)
+    ap.add_argument("--nwn", type=int, default=2, choices=[2, 4], help="waves along N: 2 = 4 waves of 128x128, 4 = 8 waves of 128x64")
+    ap.add_argument("--stagger", default="none", choices=["none", "comb", "block"])
     ap.add_argument("--ablate", default="", help="comma list of dma, read (measurement only, wrong numerics)")
     a = ap.parse_args()
     ABLATE.update(x for x in a.ablate.split(",") if x)
+    global STAGGER
+    STAGGER = a.stagger
+    set_geometry(a.nwn)
     L = program(a.rate0, a.rate1)
     print(f"// generated by tools/gemm_asm/gen_loop.py --rate0 {a.rate0} --rate1 {a.rate1}: {len(L)} lines; do not edit")
+    print(f"#define FP_ASM_NWN {NWN}")
     print("#define FP_ASM_LOOP_TEXT \\")
     for ln in L:
         print(f'    "{ln}\\n\\t" \\')

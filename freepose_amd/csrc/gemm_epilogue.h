@@ -388,6 +388,136 @@ __device__ __forceinline__ void epilogue_acc(const FpGemmArgs& p, const Acc& acc
     }
 }
 
+
+// ---- software-pipelined row-major epilogue for ONE wave per SIMD (gemm_asm.hip) -------------------------------------------------
+// Same arithmetic, rounding points and slab layout as epilogue_acc above — outputs are bit-identical — but scheduled for a lone in-order
+// wave, which has nobody to hide an LDS round trip or a residual load behind: the wave owns TWO slabs; the slab reads of block b are
+// issued, then phase 1 of block b+1 (accumulator reads, rstd / GELU, bf16 rounding, slab writes) runs while they are in flight, then
+// block b is finished and stored; residual rows are requested two blocks ahead.  Rows past M and columns past N are handled by the
+// buffer descriptors of the stores / residual loads (an out-of-range offset is dropped / reads zero), so there is no branch in the loop.
+// Blocks are enumerated b = grp * TM + i (64-feature group, 16-row block).  Epilogues: BIAS, BIAS_GELU, BIAS_LS_RES, LN_BIAS, LN_GELU,
+// LS_RES_STATS.
+template <int BM, int BN, int WM, int WN, int EPI, int TC, int TR, class Acc>
+__device__ __forceinline__ void epilogue_pipe(const FpGemmArgs& p, const Acc& accs, int m0, int n0, int wm, int wn, int li, int lg,
+                                              char* stg2, const char* gelu_tab) {
+    asm volatile("" : "+v"(li), "+v"(lg));
+    constexpr bool LNF = FpEpiTraits<EPI>::LN;
+    constexpr bool EGELU = FpEpiTraits<EPI>::GELU;
+    constexpr bool LSRES = FpEpiTraits<EPI>::LSRES;
+    constexpr bool STATS = FpEpiTraits<EPI>::STATS;
+    static_assert(!FpEpiTraits<EPI>::TRANS && EPI != FP_EPI_PATCH, "row-major epilogues without the patch scatter");
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16, NG = TN / 4, NB = TM * NG;
+    static_assert(TN % 4 == 0 && TM == TC && TN == TR, "wave tile");
+    const int lane = lg * 16 + li;
+    const int prow = lane >> 3, pslot = lane & 7;
+    const int wkey = (li >> 1) & 7;
+    const int mbase = m0 + wm * (16 * TM), nw0 = n0 + wn * (16 * TN);
+    const int rows_left = max(p.M - mbase, 0);
+    auto records = [&](int ld) { const unsigned long long b = (unsigned long long)rows_left * (unsigned)ld * 2ull; return (int)(b > 0x7fffffffull ? 0x7fffffffull : b); };
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (size_t)min(mbase, p.M) * p.ldc), 0, records(p.ldc), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsR = rsC;
+    if constexpr (LSRES) rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid + (size_t)min(mbase, p.M) * p.ldr), 0, records(p.ldr), 0x00020000);
+    // per 64-feature group: this lane's phase-2 column (8 features), its byte offset in an output / residual row, LayerScale
+    int colC[NG], colR[NG];
+    uint32_t gamw[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int nb2 = nw0 + g * 64 + pslot * 8;
+        const bool ok = nb2 < p.N;
+        colC[g] = ok ? nb2 * 2 : 0x7fffffff;      // an offset past num_records: the store is dropped
+        colR[g] = colC[g];
+        if constexpr (LSRES) {
+            const uint4 g0 = *(const uint4*)(p.gamma + min(nb2, p.N - 8));
+            gamw[g][0] = g0.x; gamw[g][1] = g0.y; gamw[g][2] = g0.z; gamw[g][3] = g0.w;
+        }
+    }
+    float rs[LNF ? TM : 1];
+    if constexpr (LNF) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rs[i] = p.ln_rstd[min(mbase + 16 * i + li, p.M - 1)];
+    }
+    const int ldc2 = p.ldc * 2, ldr2 = p.ldr * 2;
+    u32x4_t res[3][2];
+    auto load_res = [&](auto bc) {
+        constexpr int b = decltype(bc)::value, g = b / TM, i = b % TM;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 16 * i + 8 * h + prow;
+            res[b % 3][h] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (colR[g] == 0x7fffffff) ? 0x7fffffff : r * ldr2 + colR[g], 0, 2);   // read once: streaming
+        }
+    };
+    auto phase1 = [&](auto bc) {
+        constexpr int b = decltype(bc)::value, g = b / TM, i = b % TM;
+        float v[16];
+        accs.template load16<i, g>(v);
+        if constexpr (LNF) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] *= rs[i];
+        }
+        u32x4_t w0, w1;
+        if constexpr (EGELU) {
+            uint32_t q[8];
+            gelu_tab16(v, q, gelu_tab);
+            w0 = u32x4_t{q[0], q[1], q[2], q[3]};
+            w1 = u32x4_t{q[4], q[5], q[6], q[7]};
+        } else {
+            w0.x = pack_bf2(v[0], v[1]);   w0.y = pack_bf2(v[2], v[3]);
+            w0.z = pack_bf2(v[4], v[5]);   w0.w = pack_bf2(v[6], v[7]);
+            w1.x = pack_bf2(v[8], v[9]);   w1.y = pack_bf2(v[10], v[11]);
+            w1.z = pack_bf2(v[12], v[13]); w1.w = pack_bf2(v[14], v[15]);
+        }
+        char* wr = stg2 + (b & 1) * EPI_STAGE_BYTES + li * 128;
+        *(bf16x8_t*)(wr + (((2 * lg) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w0);
+        *(bf16x8_t*)(wr + (((2 * lg + 1) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w1);
+    };
+    if constexpr (LSRES) { load_res(std::integral_constant<int, 0>{}); if constexpr (NB > 1) load_res(std::integral_constant<int, 1>{}); }
+    phase1(std::integral_constant<int, 0>{});
+    static_for<0, NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value, g = b / TM, i = b % TM;
+        u32x4_t t[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = h * 8 + prow;
+            t[h] = __builtin_bit_cast(u32x4_t, *(const bf16x8_t*)(stg2 + (b & 1) * EPI_STAGE_BYTES + r * 128 + ((pslot ^ ((r >> 1) & 7)) << 4)));
+        }
+        if constexpr (b + 1 < NB) phase1(std::integral_constant<int, b + 1>{});
+        if constexpr (LSRES && b + 2 < NB) load_res(std::integral_constant<int, b + 2>{});
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 16 * i + 8 * h + prow;
+            u32x4_t o = t[h];
+            if constexpr (LSRES) {
+                const u32x4_t rr = res[b % 3][h];
+                const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+                const uint32_t tw[4] = {t[h].x, t[h].y, t[h].z, t[h].w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)   // reference rounding points: linear -> bf16, *gamma -> bf16, +resid -> bf16
+                    ow[e] = pack_bf2(lo_bf(rw[e]) + rbf(lo_bf(gamw[g][e]) * lo_bf(tw[e])),
+                                     hi_bf(rw[e]) + rbf(hi_bf(gamw[g][e]) * hi_bf(tw[e])));
+                o = u32x4_t{ow[0], ow[1], ow[2], ow[3]};
+                if constexpr (STATS) {
+                    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+                    float sm = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2_hw pr = __builtin_bit_cast(bf16x2_hw, ow[e]);
+                        sm = __builtin_amdgcn_fdot2_f32_bf16(pr, __builtin_bit_cast(bf16x2_hw, 0x3f803f80u), sm, false);
+                        sq = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, sq, false);
+                    }
+                    sm += lane_xor<4>(sm); sq += lane_xor<4>(sq);
+                    sm += lane_xor<2>(sm); sq += lane_xor<2>(sq);
+                    sm += lane_xor<1>(sm); sq += lane_xor<1>(sq);
+                    const int m = mbase + r;
+                    if (pslot == 0 && m < p.M && nw0 + g * 64 < p.N) p.stat_part[(size_t)((nw0 + g * 64) >> 6) * p.stat_ld + m] = make_float2(sm, sq);
+                }
+            }
+            if (FP_GEMM_DBG_BIT(p, 16) && o.x != 0x12345678u) continue;   // lab build only (gemm_dbg = 16): everything but the stores
+            __builtin_amdgcn_raw_buffer_store_b128(o, rsC, (colC[g] == 0x7fffffff) ? 0x7fffffff : r * ldc2 + colC[g], 0, 2);   // streaming full-line stores
+        }
+    });
+}
+
 // the HIP main loops' entry: accumulators in a compiler-managed register array
 template <int BM, int BN, int WM, int WN, int EPI, int VAR, int TC, int TR>
 __device__ __forceinline__ void epilogue(const FpGemmArgs& p, f32x4_t (&acc)[TC][TR], int m0, int n0, int wm, int wn,

@@ -189,3 +189,15 @@ def test_more_ranks_than_gpus_is_refused_unless_overridden(monkeypatch):
     assert e.value.code == 0 and called["env"]["FP_DIST_BACKEND"] == "gloo" and "--nproc-per-node=2" in called["cmd"]
     rep = parallel.rank_report.__doc__
     assert "shared_devices" in rep
+
+
+def test_reference_import_paths_resolve_in_both_forms():
+    """`import src.pipeline.X as m` and `from src.pipeline.X import name` for every reference module on the path"""
+    code = (
+        "import src.utils.bbox_utils as a, src.pipeline.utils as b, src.pipeline.retrieval.dino as c, src.pipeline.retrieval.renderer as d\n"
+        "import src.pipeline.estimators.pose_estimator as e, src.pipeline.estimators.online_pose_estimator as f\n"
+        "import src.pipeline.estimators.tracking_refiner as g, src.pipeline.refiner_utils as h, src.dataloader.template as i, src.dataloader.bop as j\n"
+        "from src.pipeline.estimators.tracking_refiner import TrackingRefiner\n"
+        "from src.pipeline.refiner_utils import crop_image, update_K_with_crop\n"
+        "assert all(m.__name__.startswith('freepose_amd.src.') for m in (a, b, c, d, e, f, g, h, i, j))\n")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)

@@ -58,7 +58,8 @@ def test_gelu_table_is_the_direct_formula_on_every_bf16_input(M_rep, N):
     w[:, 0] = 1.0
     bias = torch.zeros((N,), dtype=torch.bfloat16)
     tab = ops.gemm(x, w, bias, 1).cpu()
-    direct = ops.gelu_direct(pats.repeat(M_rep)).cpu()[:, None].expand(-1, N).contiguous()
+    pre = ops.gemm(x, w, bias, 0)                        # the bf16 pre-activation the epilogue sees (x * 1 + 0: -0 becomes +0)
+    direct = ops.gelu_direct(pre).cpu()
     a, b = tab.view(torch.int16), direct.view(torch.int16)
     finite = ~torch.isnan(pats.float()).repeat(M_rep)
     assert torch.equal(a[finite], b[finite]), "table GELU differs from the direct formula"

@@ -152,14 +152,18 @@ def init_stmt():
 
 def tile_stmt():
     # operands: 0-5 THIS tile's X lo, hi, records, W lo, hi, records | 6-11 the NEXT tile's | 12 strideX8 13 strideW8 14 lds_base
-    #           15 wave 16 K/128 - 1 (body iterations before the last) | 17 vX0 18 vW0 19 vAX 20 vAW
+    #           15 wave 16 K/128 - 1 (body iterations before the last) | 17 vX0 18 vW0 19 vAX 20 vAW | 21 drain (s)
+    # Entry wait: stages 0, 1 of this tile are the OLDEST vector-memory operations in flight; behind them sit the previous tile's
+    # epilogue (32 output stores per wave, always issued: rows / columns past the end are clipped by the store's descriptor, not
+    # branched around) and the next record loads.  vmcnt retires in order, so vmcnt(32) = "the stages have landed" without waiting
+    # for the store burst to drain.  The workgroup's first tile has no epilogue behind its stages: operand 21 != 0 -> vmcnt(0).
     L = ["s_nop 4"]
     L += descriptors("%0", "%1", "%2", "%3", "%4", "%5") + setup_pieces("%17", "%18", "%12", "%13") + setup_lds("%14", "%15")
     L += [f"v_mov_b32 v{V_AX[(0, 0)]}, %19", f"v_xor_b32 v{V_AX[(0, 1)]}, 64, v{V_AX[(0, 0)]}",
           f"v_add_u32 v{V_AX[(1, 0)]}, 0x10000, v{V_AX[(0, 0)]}", f"v_add_u32 v{V_AX[(1, 1)]}, 0x10000, v{V_AX[(0, 1)]}",
           f"v_mov_b32 v{V_AW[(0, 0)]}, %20", f"v_xor_b32 v{V_AW[(0, 1)]}, 64, v{V_AW[(0, 0)]}",
           f"v_add_u32 v{V_AW[(1, 0)]}, 0x10000, v{V_AW[(0, 0)]}", f"v_add_u32 v{V_AW[(1, 1)]}, 0x10000, v{V_AW[(0, 1)]}"]
-    L += ["s_waitcnt vmcnt(0)", "s_barrier"]
+    L += ["s_cmp_eq_u32 %21, 0", "s_cbranch_scc1 L_nodrain_%=", "s_waitcnt vmcnt(0)", "L_nodrain_%=:", "s_waitcnt vmcnt(32)", "s_barrier"]
     L += frag_reads(0, 0, V_SETA_X, V_SETA_W)
     L += ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{S_DK}, 0x100", f"s_mov_b32 s{S_CNT}, %16"]
     L += ["L_k_%=:"] + step(0) + step(1)

@@ -88,6 +88,62 @@ __device__ __forceinline__ void gelu_tab16(const float (&v)[16], uint32_t (&out)
     }
 }
 
+// The same table GELU in two halves for a software-pipelined epilogue (epilogue_pipe): `issue` packs the 16 values, checks the window
+// and sends the 16 LDS gathers WITHOUT waiting; `finish` — at least one block of other work later — waits and combines.  hipcc does not
+// see the gathers (inline asm): between the two calls the caller must not let a compiler-counted LDS wait depend on them (see there).
+struct GeluPending {
+    uint32_t w[8];       // packed bf16 inputs (fallback path)
+    uint32_t r[8], q[8]; // gather destinations: low / high element of each pair
+    bool inside;         // wave-uniform: every element of the wave's block is inside the table window
+};
+__device__ __forceinline__ void gelu_tab16_issue(const float (&v)[16], GeluPending& st) {
+    uint32_t amin = 0x7fff7fffu, amax = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        st.w[k] = pack_bf2(v[2 * k], v[2 * k + 1]);
+        const uint32_t a2 = st.w[k] & 0x7fff7fffu;
+        amin = pk_min_u16(amin, a2);
+        amax = pk_max_u16(amax, a2);
+    }
+    const uint32_t lo = min(amin & 0xffffu, amin >> 16), hi = max(amax & 0xffffu, amax >> 16);
+    const bool in = lo >= GELU_WIN_LO && hi < GELU_WIN_HI;
+    st.inside = __builtin_amdgcn_ballot_w64(!in) == 0ull;
+    if (st.inside) {
+        uint32_t alo[8], ahi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t u = (((st.w[k] >> 3) & 0x10001000u) | (st.w[k] & 0x0fff0fffu)) << 1;   // two byte offsets (table at LDS byte 0)
+            alo[k] = u & 0xffffu;
+            ahi[k] = u >> 16;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            asm volatile(
+                "ds_read_u16 %0, %8\n\tds_read_u16 %1, %9\n\tds_read_u16 %2, %10\n\tds_read_u16 %3, %11\n\t"
+                "ds_read_u16_d16_hi %4, %12\n\tds_read_u16_d16_hi %5, %13\n\tds_read_u16_d16_hi %6, %14\n\tds_read_u16_d16_hi %7, %15"
+                : "=&v"(st.r[4 * h]), "=&v"(st.r[4 * h + 1]), "=&v"(st.r[4 * h + 2]), "=&v"(st.r[4 * h + 3]),
+                  "=&v"(st.q[4 * h]), "=&v"(st.q[4 * h + 1]), "=&v"(st.q[4 * h + 2]), "=&v"(st.q[4 * h + 3])
+                : "v"(alo[4 * h]), "v"(alo[4 * h + 1]), "v"(alo[4 * h + 2]), "v"(alo[4 * h + 3]),
+                  "v"(ahi[4 * h]), "v"(ahi[4 * h + 1]), "v"(ahi[4 * h + 2]), "v"(ahi[4 * h + 3])
+                : "memory");
+    }
+}
+__device__ __forceinline__ void gelu_tab16_finish(GeluPending& st, uint32_t (&out)[8], const char* tab) {
+    if (st.inside) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(st.r[0]), "+v"(st.r[1]), "+v"(st.r[2]), "+v"(st.r[3]), "+v"(st.r[4]), "+v"(st.r[5]), "+v"(st.r[6]), "+v"(st.r[7]),
+                       "+v"(st.q[0]), "+v"(st.q[1]), "+v"(st.q[2]), "+v"(st.q[3]), "+v"(st.q[4]), "+v"(st.q[5]), "+v"(st.q[6]), "+v"(st.q[7])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = st.r[k] | st.q[k];
+    } else {
+        const uint16_t* t16 = (const uint16_t*)tab;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = gelu_tab_any(st.w[k] & 0xffffu, t16) | (gelu_tab_any(st.w[k] >> 16, t16) << 16);
+    }
+}
+
 // bytes of LDS each wave needs for the row-coalescing stage of the non-transposed epilogues (16 rows x 128 B)
 constexpr int EPI_STAGE_BYTES = 2048;
 
@@ -446,7 +502,11 @@ __device__ __forceinline__ void epilogue_pipe(const FpGemmArgs& p, const Acc& ac
             res[b % 3][h] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (colR[g] == 0x7fffffff) ? 0x7fffffff : r * ldr2 + colR[g], 0, 2);   // read once: streaming
         }
     };
-    auto phase1 = [&](auto bc) {
+    // phase 1 of block b in two halves: `p1_front` reads the accumulators, applies rstd, rounds to bf16 (or, for the table GELU, packs the
+    // inputs and SENDS the 16 table gathers); `p1_back` (table GELU: waits for the gathers sent one block earlier) writes the slab.
+    u32x4_t pw[3][2];
+    GeluPending gp[EGELU ? 3 : 1];
+    auto p1_front = [&](auto bc, bool send) {
         constexpr int b = decltype(bc)::value, g = b / TM, i = b % TM;
         float v[16];
         accs.template load16<i, g>(v);
@@ -454,33 +514,51 @@ __device__ __forceinline__ void epilogue_pipe(const FpGemmArgs& p, const Acc& ac
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] *= rs[i];
         }
-        u32x4_t w0, w1;
         if constexpr (EGELU) {
-            uint32_t q[8];
-            gelu_tab16(v, q, gelu_tab);
-            w0 = u32x4_t{q[0], q[1], q[2], q[3]};
-            w1 = u32x4_t{q[4], q[5], q[6], q[7]};
+            (void)send;
+            gelu_tab16_issue(v, gp[b % 3]);
         } else {
+            u32x4_t w0, w1;
             w0.x = pack_bf2(v[0], v[1]);   w0.y = pack_bf2(v[2], v[3]);
             w0.z = pack_bf2(v[4], v[5]);   w0.w = pack_bf2(v[6], v[7]);
             w1.x = pack_bf2(v[8], v[9]);   w1.y = pack_bf2(v[10], v[11]);
             w1.z = pack_bf2(v[12], v[13]); w1.w = pack_bf2(v[14], v[15]);
+            pw[b % 3][0] = w0; pw[b % 3][1] = w1;
+        }
+    };
+    auto p1_back = [&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (EGELU) {
+            uint32_t q[8];
+            gelu_tab16_finish(gp[b % 3], q, gelu_tab);
+            pw[b % 3][0] = u32x4_t{q[0], q[1], q[2], q[3]};
+            pw[b % 3][1] = u32x4_t{q[4], q[5], q[6], q[7]};
         }
         char* wr = stg2 + (b & 1) * EPI_STAGE_BYTES + li * 128;
-        *(bf16x8_t*)(wr + (((2 * lg) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w0);
-        *(bf16x8_t*)(wr + (((2 * lg + 1) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, w1);
+        *(bf16x8_t*)(wr + (((2 * lg) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, pw[b % 3][0]);
+        *(bf16x8_t*)(wr + (((2 * lg + 1) ^ wkey) << 4)) = __builtin_bit_cast(bf16x8_t, pw[b % 3][1]);
     };
     if constexpr (LSRES) { load_res(std::integral_constant<int, 0>{}); if constexpr (NB > 1) load_res(std::integral_constant<int, 1>{}); }
-    phase1(std::integral_constant<int, 0>{});
+    // pipeline per block b:  back(b+1) -> slab reads of b -> front(b+2) (covers the reads; table GELU: its gathers fly until the next
+    // block's back) -> finish and store b.  Slab b+1 was last read by block b-1, whose reads were consumed before its stores.
+    p1_front(std::integral_constant<int, 0>{}, true);
+    p1_back(std::integral_constant<int, 0>{});
+    if constexpr (NB > 1) p1_front(std::integral_constant<int, 1>{}, true);
     static_for<0, NB>([&](auto bc) {
         constexpr int b = decltype(bc)::value, g = b / TM, i = b % TM;
+        if constexpr (b + 1 < NB) p1_back(std::integral_constant<int, b + 1>{});
         u32x4_t t[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = h * 8 + prow;
             t[h] = __builtin_bit_cast(u32x4_t, *(const bf16x8_t*)(stg2 + (b & 1) * EPI_STAGE_BYTES + r * 128 + ((pslot ^ ((r >> 1) & 7)) << 4)));
         }
-        if constexpr (b + 1 < NB) phase1(std::integral_constant<int, b + 1>{});
+        if constexpr (EGELU) {
+            // the slab reads must have landed BEFORE the next gathers are sent: hipcc counts only its own LDS operations, so a wait it
+            // places behind the (invisible) gathers would wait for them too
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]) : : "memory");
+        }
+        if constexpr (b + 2 < NB) p1_front(std::integral_constant<int, b + 2>{}, true);
         if constexpr (LSRES && b + 2 < NB) load_res(std::integral_constant<int, b + 2>{});
 #pragma unroll
         for (int h = 0; h < 2; ++h) {

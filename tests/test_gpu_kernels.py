@@ -42,8 +42,8 @@ def test_gemm_epilogues(M, N, K, epi):
     assert (diff <= tol).all(), f"max diff {diff.max().item()}"
 
 
-@pytest.mark.parametrize("M_rep,N", [(1, 64), (1, 256), (4, 256)])   # 128x128 kernel; 256x256 16-wave kernel (>= 192 big tiles), 1 and 4 tiles per CU
-def test_gelu_table_is_the_direct_formula_on_every_bf16_input(M_rep, N):
+@pytest.mark.parametrize("M_rep,N,K", [(1, 64, 64), (1, 256, 64), (4, 256, 64), (4, 256, 256)])   # 128x128 kernel; 256x256 16-wave kernel (>= 192 big tiles; K = 64 is not a shape of the asm loop), 1 and 4 tiles per CU; hand-scheduled 256x256 kernel (K % 128 == 0) with the pipelined epilogue
+def test_gelu_table_is_the_direct_formula_on_every_bf16_input(M_rep, N, K):
     """fc1 epilogue: the table GELU against the direct fp32 expression 0.5 x (1 + erf(x / sqrt 2)) (fp_op_gelu: the expression the
     table is filled from, evaluated elementwise) on ALL 65 536 bf16 inputs, in every tile tier — one-hot weights make the
     pre-activation equal the chosen pattern exactly (NaN/Inf and both zeros included); bit-identical.  Against torch's CPU GELU of
@@ -51,7 +51,6 @@ def test_gelu_table_is_the_direct_formula_on_every_bf16_input(M_rep, N):
     (The alternative main loops of earlier rounds carry the same table; they live in the lab build: tools/lab_selfcheck.py.)"""
     from freepose_amd import ops
     pats = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)          # every bf16 pattern
-    K = 64
     x = torch.zeros((65536 * M_rep, K), dtype=torch.bfloat16)
     x[:, 0] = pats.repeat(M_rep)
     w = torch.zeros((N, K), dtype=torch.bfloat16)

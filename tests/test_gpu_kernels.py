@@ -190,6 +190,33 @@ def test_row_split_dispatch_is_invisible(M):
     assert torch.isfinite(res["split"]["stat_rows1024"]).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(49152 + 37, 1024, 4096), (50000, 1152, 2048)])
+def test_hand_scheduled_tier_gives_the_bits_of_the_small_tiers(M, N, K):
+    """Long-K launches that fill the chip run the hand-scheduled one-wave-per-SIMD kernel (gemm_asm.hip: accumulators in the AGPR file,
+    pipelined epilogue, descriptor-clipped ragged rows / columns).  Same K order, same init MFMA, same rounding points as every other
+    tier, so its outputs — plain, GELU, LayerScale + residual, row statistics, LayerNorm-folded — must equal, bit for bit, the same
+    rows computed in 4096-row slices (which take the 128x128 kernel); plus a float64 reference check of the plain product."""
+    from freepose_amd import ops
+    x = _rand((M, K), 71, 1.0)
+    w, bias = _rand((N, K), 72, 0.03), _rand((N,), 73, 0.5)
+    gamma, resid = _rand((N,), 74, 1.0), _rand((M, N), 75, 2.0)
+    g_ln, b_ln = _rand((K,), 76, 1.0), _rand((K,), 77, 0.3)
+
+    def run(xs, rs):
+        o = {"bias": ops.gemm(xs, w, bias, 0), "gelu": ops.gemm(xs, w, bias, 1), "lsres": ops.gemm(xs, w, bias, 2, gamma=gamma, resid=rs),
+             "ln": ops.ln_linear(xs, g_ln, b_ln, w, bias, mode=0), "ln_gelu": ops.ln_linear(xs, g_ln, b_ln, w, bias, mode=1)}
+        o["stats"], o["stat_rows"] = ops.gemm_stats(xs, w, bias, gamma, rs)
+        return o
+    whole = run(x, resid)
+    parts = [run(x[i:i + 4096], resid[i:i + 4096]) for i in range(0, M, 4096)]
+    torch.cuda.synchronize()
+    for k in whole:
+        assert torch.equal(whole[k], torch.cat([p_[k] for p_ in parts])), k
+    rows = torch.arange(0, M, 997)
+    ref = x[rows].double() @ w.double().t() + bias.double()
+    assert _rel(whole["bias"][rows.cuda()], ref) < 6e-3
+
+
 # 70 / 129 / 261 / 905 / 1374: the last K/V tile's valid keys fit its first half -> the "short tail first" kernel (attention.hip);
 # 97 (33 keys in the tail), 64 and 17 take the plain kernel; 2 tiles (70, 97, 129 -> 3) exercise the shortest loops of both
 @pytest.mark.parametrize("B,H,n_tok", [(1, 6, 261), (2, 16, 905), (2, 16, 1374), (1, 16, 64), (1, 2, 17), (1, 2, 70), (1, 2, 97),

@@ -33,13 +33,13 @@ def main():
         for var, o in outs.items():
             assert torch.equal(o[finite], outs[-1][finite]), f"gemm_variant {var} differs (N={N})"
     # 2. every variant of the plain / LayerScale+residual GEMM gives the product's bits on a ragged shape
-    M, N, K = 4000, 1024, 1024
+    M, N, K = 50000, 1024, 1024          # fills the chip with 256x256 tiles, ragged last row tile
     x = (torch.randn((M, K), generator=g)).to(torch.bfloat16)
     w = (torch.randn((N, K), generator=g) * 0.05).to(torch.bfloat16)
     bias, gamma = torch.randn((N,), generator=g).to(torch.bfloat16), torch.randn((N,), generator=g).to(torch.bfloat16)
     resid = torch.randn((M, N), generator=g).to(torch.bfloat16)
     ref0, ref2 = ops.gemm(x, w, bias, 0).cpu(), ops.gemm(x, w, bias, 2, gamma=gamma, resid=resid).cpu()
-    for var in (0, 6, 14, 46, 110, 238 | 256, 238 | 2048, 238 | 512):
+    for var in (0, 6, 14, 46, 110, 238 | 256, 238 | 2048, 238 | 512, 238 | 8192, 238 | 16384):
         ops.set_option("gemm_variant", var)
         assert torch.equal(ops.gemm(x, w, bias, 0).cpu(), ref0), var
         assert torch.equal(ops.gemm(x, w, bias, 2, gamma=gamma, resid=resid).cpu(), ref2), var

@@ -263,6 +263,163 @@ def video_workload(args, vit, rank, world):
             "config": "1280x720 frames, ViT-L/14-reg @420^2, 600 coarse + 20000 fine hypotheses, 15 deg neighbourhood, 5120-triangle mesh"}
 
 
+def _timed(fn, iters=3, warmup=1):
+    """median HIP-event time (ms) of fn() on the current stream"""
+    from freepose_amd import ops
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(iters):
+        t = ops.Timer()
+        t.start()
+        fn()
+        t.stop()
+        ts.append(t.elapsed_ms())
+    return float(np.median(ts))
+
+
+def config_legs(args, vit, bank):
+    """BASELINE configs 2 and 3 as secondary measurements (rank 0, one GPU, outside the timed region).
+
+    config2 — scripts/extract_retrieval_features.py:36-70 (bank building): ViT-L layer-22 patch features -> per-view FFA (fp32 rows)
+    -> per-object mean (scripts/merge_features.py:19-35).  Two shapes: B = 256 crops @518^2 in one batch (BASELINE's statement of the
+    config: 6 objects x 42 views + 4), and the reference's own loop shape, 600 views @420^2 in batches of 256 / 256 / 88 with one
+    device->host copy per mesh.
+    config3 — scripts/dino_inference.py:108-111 -> src/pipeline/estimators/pose_estimator.py:55-60,84-92 with the template features
+    CACHED (the reference's steady state): the 5 proposals of one image share ONE ViT call and ONE bank pass
+    (scripts/extract_proposals_ground.py:136-140), then per proposal: normalised-query patchwise score against the resident
+    600 x 900 x 1024 store of its mesh (5 different stores), top-3, depth extents -> pose."""
+    from freepose_amd import ops
+    from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
+    from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+    out = {}
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(10)
+
+    def masks_for(B, res, seed):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        yy, xx = np.mgrid[0:res, 0:res]
+        return torch.from_numpy(np.stack([(((yy - res * rng.uniform(.4, .6)) / (res * rng.uniform(.25, .45))) ** 2 +
+                                           ((xx - res * rng.uniform(.4, .6)) / (res * rng.uniform(.25, .45))) ** 2) <= 1 for _ in range(B)])).to(dev)
+
+    # ---------------- config 2 (a): one batch of 256 crops @518^2 -------------------------------------------------------------
+    B, res, views = 256, 518, 42
+    crops = torch.rand((B, 3, res, res), generator=g).to(torch.bfloat16).to(dev)
+    masks = masks_for(B, res, 11)
+    gg = res // 14
+    st = {}
+
+    def c2a():
+        t0, t1 = ops.Timer(), ops.Timer()
+        t0.start()
+        feats = vit(crops, layer=22, feature_type="patch")
+        t0.stop()
+        t1.start()
+        desc = ops.ffa(feats, masks[:, : gg * 14, : gg * 14], cell=14, out_f32=True)                       # [B, 1024] fp32 per-view rows
+        objs = torch.stack([desc[o:o + views].mean(dim=0) for o in range(0, B - views + 1, views)])   # merge_features.py: mean over an object's views
+        t1.stop()
+        st["vit"], st["ffa"], st["objs"] = t0, t1, objs
+        return objs
+    ms = _timed(c2a)
+    fl = vit.flops(B, res, res, 22)
+    out["config2_batch256_518"] = {
+        "metric": "crops/s (extract_retrieval_features: ViT-L/14 layer-22 + FFA + per-object mean, one batch of 256 @518^2)",
+        "value": B / ms * 1e3, "unit": "crops/s", "ms": ms, "vit_ms": st["vit"].elapsed_ms(), "ffa_mean_ms": st["ffa"].elapsed_ms(),
+        "roofline": {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS},
+        "objects": int(st["objs"].shape[0])}
+    del crops, masks
+
+    # ---------------- config 2 (b): the reference's loop: 600 views @420^2, batches 256 / 256 / 88, one host copy per mesh ----
+    T, res = 600, 420
+    tmpl = torch.rand((T, 3, res, res), generator=g).to(torch.bfloat16).to(dev)
+    tmask = masks_for(T, res, 12)
+
+    def c2b():
+        feats = torch.cat([vit(tmpl[i:i + 256], layer=22, feature_type="patch") for i in range(0, T, 256)], dim=0)
+        desc = ops.ffa(feats, tmask, cell=14, out_f32=True).cpu().numpy()                                  # the mesh's .npy rows
+        return desc[~np.isnan(desc).any(axis=1)]
+    c2b()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        c2b()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / 3
+    fl = vit.flops(T, res, res, 22)
+    out["config2_mesh600_420"] = {
+        "metric": "crops/s (extract_retrieval_features per mesh: 600 views @420^2 in batches 256/256/88, FFA, host copy of the rows)",
+        "value": T / sec, "unit": "crops/s", "ms_per_mesh": sec * 1e3, "meshes_per_s": 1.0 / sec,
+        "roofline": {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS}}
+
+    # ---------------- config 3: cached per-proposal path, the proposals of one image batched ------------------------------------
+    n_prop, P, D = 5, 900, 1024
+    fe = DINOv2FeatureExtractor.__new__(DINOv2FeatureExtractor)      # share the already-resident ViT-L
+    torch.nn.Module.__init__(fe)
+    fe.model_name, fe.model, fe.num_register_tokens = "dinov2_vitl14_reg", vit, vit.n_reg
+    est = DinoPoseEstimator(n_poses=T, cache_size=n_prop, cache_dir="/tmp/fp_bench_cache_c3", feature_extractor=fe)
+    depth = torch.zeros((T, res, res), dtype=torch.float32, device=dev)
+    depth[:, 120:300, 140:290] = 1.1                                   # a plausible silhouette per view (extents only need the support)
+    tdicts = []
+    for m in range(n_prop):
+        f = torch.randn((T, P, D), generator=g, dtype=torch.float32).to(torch.bfloat16).to(dev)
+        est._cache_features(f"mesh{m}", f)                            # enters the device store normalised in place (1.1 GB each)
+        tdicts.append({"model_name": f"mesh{m}", "templates": tmpl, "depths": depth, "intrinsic": torch.tensor([[600, 0, 210], [0, 600, 210], [0, 0, 1]])})
+    pcrops, pmasks, K, boxes, scales = synthetic_proposals(n_prop, res, seed=20)
+    pcrops, pmasks = pcrops.to(dev), pmasks.to(dev)
+    stages = {}
+
+    def span(name):
+        t = ops.Timer()
+        stages.setdefault(name, []).append(t)
+        return t
+
+    def c3():
+        stages.clear()
+        t = span("vit_query_batch"); t.start()
+        feats = vit(pcrops, layer=22, feature_type="patch")                                     # ONE call for the image's proposals
+        t.stop()
+        t = span("ffa"); t.start()
+        desc = ops.ffa(feats, pmasks, cell=14, normalize=True)
+        t.stop()
+        t = span("bank_scan_topk"); t.start()
+        s_, i_ = bank.topk(desc, 100)                                                           # ONE bank pass for all of them
+        t.stop()
+        res_ = []
+        for pidx in range(n_prop):
+            t = span("estimator_forward_cached"); t.start()
+            res_.append(est.forward(pcrops[pidx], tdicts[pidx], K, boxes[pidx], float(scales[pidx]), query_feat=feats[pidx:pidx + 1]))
+            t.stop()
+        return res_, s_, i_
+    c3()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 5
+    for _ in range(iters):
+        c3()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / iters
+    st_ms = {k: sum(t.elapsed_ms() for t in v) for k, v in stages.items()}
+    q = ops.l2_normalize(torch.randn((P, D), generator=g).to(torch.bfloat16).to(dev))
+    ts_ms = _timed(lambda: ops.template_score(est.feature_cache["mesh0"], q, normalized=True), iters=5)
+    vfl = vit.flops(n_prop, res, res, 22)
+    passes = -(-n_prop // ops.BANK_QUERIES_PER_PASS) if hasattr(ops, "BANK_QUERIES_PER_PASS") else -(-n_prop // 4)
+    out["config3_cached_proposals"] = {
+        "metric": "proposals/s (dino_inference steady state: template features cached; 5 proposals of an image share one ViT call and one bank pass)",
+        "value": n_prop / sec, "unit": "proposals/s", "ms_per_image": sec * 1e3, "proposals_per_image": n_prop,
+        "stages_ms_per_image": st_ms,
+        "roofline": {
+            "vit_query_batch": {"bound": "mfma", "achieved": vfl / max(st_ms.get("vit_query_batch", 1e9), 1e-9) / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": vfl / max(st_ms.get("vit_query_batch", 1e9), 1e-9) / 1e9 / MFMA_BF16_PEAK_TFLOPS},
+            "bank_scan_topk": {"bound": "hbm", "achieved": passes * args.bank * D * 2.0 / max(st_ms.get("bank_scan_topk", 1e9), 1e-9) / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": passes * args.bank * D * 2.0 / max(st_ms.get("bank_scan_topk", 1e9), 1e-9) / 1e6 / HBM_PEAK_GBS, "bank_passes": passes},
+            "template_score_normed": {"bound": "hbm", "achieved": T * P * D * 2.0 / ts_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": T * P * D * 2.0 / ts_ms / 1e6 / HBM_PEAK_GBS, "ms": ts_ms, "bytes": T * P * D * 2.0}},
+        "note": "estimator_forward_cached = DinoPoseEstimator.forward with the caller's query features: normalise query, streaming score over the "
+                "1.1 GB pre-normalised store, top-3, depth extents of the 3 winners, host pose formula (one sync per proposal)"}
+    est.feature_cache.clear()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,6 +436,7 @@ def main():
                     help="frames of the secondary video-tracking measurement (BASELINE config 5; 0 = skip)")
     ap.add_argument("--video-objects", type=int, default=4,
                     help="tracked objects per frame in the multi-object leg of the video measurement (batched per frame)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the secondary BASELINE config 2 / 3 measurements")
     ap.add_argument("--lab", action="store_true",
                     help="tools/ only: load libfreepose_hip_lab.so (measurement variants, FP_* toggles); never a reported number")
     ap.add_argument("--ln-fused", type=int, default=-1, help="fp_ctx_set_option ln_fused (A/B of the LayerNorm fold)")
@@ -344,6 +502,7 @@ def main():
     dt = float(tt.item())
     who = parallel.rank_report()                                       # backend, RCCL version, device + PCI bus id of every rank
     video = video_workload(args, vit, rank, world) if args.video_frames > 0 else None    # outside the timed region
+    legs = config_legs(args, vit, bank) if (world == 1 and not args.no_config_legs) else None   # BASELINE configs 2 and 3 (secondary)
 
     if rank == 0:
         n_prop = world * B * args.steps
@@ -378,6 +537,7 @@ def main():
             "stages_rank0": stage_table(args, prof, stage_ms, n_tri=len(mf), n_vert=len(mv), n_prop=B * args.steps),
         }
         out["video_workload"] = video
+        out["configs"] = legs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, (mv, mf, mc), bank_f32)
         else:

@@ -466,7 +466,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // A launch that cannot even give every CU one 128x128 tile (a single 518^2 crop: 88 tiles for N = 1024) runs one-wave
     // 64x64 tiles instead — 4x the workgroups, all CUs busy (bit 2048, A/B only: keep the 128x128 kernel).
     const long tiles_mid = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-    const bool tiny = !big && tiles_mid < ncu && !(var & 2048);
+    const bool tiny = !big && ((tiles_mid < ncu && !(var & 2048)) || (var & 32768));   // bit 32768 (lab A/B only): one-wave tiles whenever not big
 #ifdef FP_LAB
     if constexpr (EPI < FP_EPI_LN_BIAS) {   // lab build: the alternative kernels of the plain epilogues (A/B runs)
         if (var != FP_GEMM_DEFAULT_VARIANT) {

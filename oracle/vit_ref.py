@@ -92,6 +92,68 @@ def vit_forward(sd: dict, images: torch.Tensor, layer: int = 22, feature_type: s
     return x[:, 1 + n_reg:]
 
 
+def vit_forward_video_regime(sd: dict, images: torch.Tensor, layer: int = 22, feature_type: str = "patch", eps: float = 1e-6) -> torch.Tensor:
+    """The VIDEO script's precision regime, restated op by op: a bf16 model (online_pose_estimator.py:19) fed fp16 images
+    (`.half()`, online_pose_estimator.py:51,66) under `torch.autocast(device_type='cuda', dtype=torch.bfloat16)`
+    (scripts/dino_inference_video.py:151).  CUDA autocast semantics [torch/csrc/autocast_mode.cpp; public knowledge]:
+      * conv / linear / matmul / scaled-dot-product attention cast their floating inputs to bf16 and return bf16;
+      * layer_norm and softmax run in fp32 and RETURN fp32 (so the final norm's features are fp32, not bf16);
+      * elementwise ops (Normalize's sub / div, GELU, LayerScale mul, residual add) run in their input dtype with ordinary
+        type promotion (bf16 op fp32 -> fp32).
+    images: float32 tensor holding the values of the fp16 input (any float input is rounded to fp16 first).  Returns fp32 features."""
+    bf, h = torch.bfloat16, torch.float16
+    sd = {k: v.to(bf) for k, v in sd.items()}
+    mean = torch.as_tensor(IMAGENET_MEAN, dtype=h).view(1, 3, 1, 1)
+    std = torch.as_tensor(IMAGENET_STD, dtype=h).view(1, 3, 1, 1)
+    x = (images.to(h) - mean) / std                                        # T.Normalize on the fp16 tensor (fp16 arithmetic)
+    D = sd["cls_token"].shape[-1]
+    heads = D // 64
+    n_reg = sd["register_tokens"].shape[1] if "register_tokens" in sd else 0
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    B, _, H, W = x.shape
+    gh, gw = H // 14, W // 14
+    x = F.conv2d(x.to(bf), sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=14)     # autocast: conv in bf16
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([sd["cls_token"].expand(B, -1, -1), x], dim=1)
+    x = x + interpolate_pos_encoding(sd["pos_embed"], gh, gw)
+    if n_reg:
+        x = torch.cat([x[:, :1], sd["register_tokens"].expand(B, -1, -1), x[:, 1:]], dim=1)
+
+    def ln(t, w, b):                                                        # autocast: fp32 in, fp32 out
+        return F.layer_norm(t.float(), (D,), w.float(), b.float(), eps)
+
+    def lin(t, w, b):                                                       # autocast: bf16 in, bf16 out
+        return F.linear(t.to(bf), w, b)
+
+    for i in range(depth):
+        p = f"blocks.{i}."
+        y = ln(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+        qkv = lin(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(B, -1, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, -1, D)
+        y = lin(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        x = x + (y * sd[p + "ls1.gamma"] if p + "ls1.gamma" in sd else y)
+        y = ln(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+        y = lin(F.gelu(lin(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        x = x + (y * sd[p + "ls2.gamma"] if p + "ls2.gamma" in sd else y)
+        if i + 1 == layer:
+            break
+    x = ln(x, sd["norm.weight"], sd["norm.bias"])                           # fp32 features leave the extractor
+    if feature_type == "cls":
+        return x[:, 0]
+    if feature_type == "reg":
+        return x[:, 1:1 + n_reg]
+    return x[:, 1 + n_reg:]
+
+
+def score_video_regime(query_feat_f32: torch.Tensor, template_feats_f32: torch.Tensor) -> torch.Tensor:
+    """online_pose_estimator.py:52,76 under the same autocast: F.normalize on the fp32 features (fp32), einsum -> bmm in bf16 (inputs
+    rounded to bf16, fp32 accumulation, bf16 result), .mean(-1) on the bf16 dots.  query [P,D], templates [T,P,D] -> [T] (bf16 values)."""
+    q = F.normalize(query_feat_f32, dim=-1).to(torch.bfloat16)
+    t = F.normalize(template_feats_f32, dim=-1).to(torch.bfloat16)
+    dots = (t.float() * q.float()[None]).sum(-1).to(torch.bfloat16)        # 'b n d, b n d -> b n' as a batched matmul in bf16
+    return dots.float().mean(-1).to(torch.bfloat16).float()
+
+
 def to_hf_state_dict(sd: dict) -> dict:
     """hub DINOv2 names -> transformers Dinov2WithRegistersModel names (SURVEY.md App. B key map)."""
     D = sd["cls_token"].shape[-1]

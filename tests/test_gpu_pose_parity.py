@@ -21,6 +21,7 @@ Stated tolerance:
   * every HIP score is within SCORE_ULP bf16 ulps of the oracle's score for the same hypothesis.
 re / te are restated from bop_toolkit_lib/pose_error.py:288-315 and printed for every query together with the agreement rate."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -78,7 +79,13 @@ def test_pose_parity_vit_in_the_loop(capsys):
     v, f, uv = textured_cube()
     v = v * np.array([1.0, 0.7, 0.45], np.float32)             # a box with three different extents: poses are distinguishable
     tex = checker_gradient_texture(256)
-    sd = ops.random_state_dict("dinov2_vitl14_reg", seed=3)
+    ck = os.environ.get("FP_PARITY_STATE_DICT")        # tools/real_weights_parity.py: the same test on the trained checkpoint
+    if ck:
+        sd = torch.load(ck, map_location="cpu")
+        sd = sd["model"] if isinstance(sd, dict) and "model" in sd and "pos_embed" not in sd else sd
+        sd = {k: v.to(torch.bfloat16) for k, v in sd.items() if k != "mask_token"}
+    else:
+        sd = ops.random_state_dict("dinov2_vitl14_reg", seed=3)
     vit = ops.ViT("dinov2_vitl14_reg", sd)
     bank = TemplateBank(bench.synthetic_bank(200, 1024, seed=5))
     hp = HotPath(vit, bank, ops.Mesh(v, f, uv=uv, texture=tex), n_hyp=N_HYP, crop_res=RES, render_res=420, k=10, layer=LAYER, vit_batch=32)

@@ -1,0 +1,32 @@
+"""Small-batch ViT-L forwards (B = 1 .. 8) under the GEMM tile tiers (lab build): default dispatch, 128x128 kept for small grids
+(bit 2048), one-wave 64x64 tiles for everything below the big tier (bit 32768).  python tools/small_batch_ab.py [res]"""
+import statistics
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from freepose_amd import _lib  # noqa: E402
+_lib.use_lab()
+from freepose_amd import ops  # noqa: E402
+
+res = int(sys.argv[1]) if len(sys.argv) > 1 else 518
+vit = ops.ViT("dinov2_vitl14_reg", seed=0)
+for B in (1, 2, 3, 4, 5, 6, 8, 12, 16, 21):
+    x = torch.rand((B, 3, res, res), device="cuda").to(torch.bfloat16)
+    row = []
+    for name, var in (("default", -1), ("mid", 238 | 2048), ("tiny", 238 | 32768)):
+        ops.set_option("gemm_variant", var)
+        for _ in range(2):
+            vit(x, layer=22, feature_type="patch")
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t = ops.Timer(); t.start()
+            vit(x, layer=22, feature_type="patch")
+            t.stop(); ts.append(t.elapsed_ms())
+        ms = statistics.median(ts)
+        row.append(f"{name} {ms:.3f} ms ({vit.flops(B, res, res, 22) / ms / 1e9:.0f} TF)")
+    ops.set_option("gemm_variant", -1)
+    print(f"B={B} @{res}: " + " | ".join(row), flush=True)

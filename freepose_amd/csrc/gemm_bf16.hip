@@ -463,6 +463,36 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
             }
         }
     }
+    // ROW SPLIT below the big tier (round 4): the 128x128 kernel keeps two workgroups per CU resident, so its time also goes in whole
+    // rounds (2 x ncu tiles) — 6 crops @518^2 give the N = 1024 layers 520 tiles = one round + 8 tiles, i.e. TWO rounds (the B = 5 -> 6
+    // step of a ViT-L forward was 6.1 -> 8.7 ms).  Whole rounds run on 128x128 tiles, the remaining rows pick their own tier (a
+    // remainder below one tile per CU takes the one-wave 64x64 tiles, whose round is ~half the cost).  Same bits from every tier.
+    if constexpr (EPI != FP_EPI_VT && EPI != FP_EPI_LN_VT && EPI != FP_EPI_PATCH) {
+        const long tn = cdiv(a.N, 128), slots = 2L * ncu, tiles_mid_all = (long)cdiv(a.M, 128) * tn;
+        const long fullm = tiles_mid_all / slots;
+        const long rbm = fullm * slots / tn;                              // 128-row blocks the whole rounds cover
+        if (!big && !(var & (256 | 4096)) && !a.no_split && fullm >= 1 && rbm * 128 < a.M) {
+            const long rem_rows = a.M - rbm * 128, rem_mid = cdiv(rem_rows, 128L) * tn;
+            const double t_now = (double)cdiv(tiles_mid_all, slots);
+            const double t_rem = rem_mid < ncu ? 0.5 * (double)cdiv(cdiv(rem_rows, 64L) * cdiv((long)a.N, 64L), 4L * ncu) : (double)cdiv(rem_mid, slots);
+            const double t_split = (double)cdiv(rbm * tn, slots) + t_rem;
+            if (t_split < 0.9 * t_now) {
+                const size_t m1 = (size_t)rbm * 128;
+                FpGemmArgs a1 = a, a2 = a;
+                a1.M = (int)m1; a1.no_split = 1;
+                a2.M = a.M - (int)m1; a2.no_split = 1;
+                a2.X = a.X + m1 * a.ldx;
+                a2.C = a.C + m1 * a.ldc;
+                if (a.resid) a2.resid = a.resid + m1 * a.ldr;
+                if (a.ln_mfrag) a2.ln_mfrag = a.ln_mfrag + m1;
+                if (a.ln_rstd) a2.ln_rstd = a.ln_rstd + m1;
+                if (a.stat_part) a2.stat_part = a.stat_part + m1;
+                const int rc = launch_epi<EPI>(a1, stream);
+                if (rc != FP_OK) return rc;
+                return launch_epi<EPI>(a2, stream);
+            }
+        }
+    }
     // A launch that cannot even give every CU one 128x128 tile (a single 518^2 crop: 88 tiles for N = 1024) runs one-wave
     // 64x64 tiles instead — 4x the workgroups, all CUs busy (bit 2048, A/B only: keep the 128x128 kernel).
     const long tiles_mid = (long)cdiv(a.M, 128) * cdiv(a.N, 128);

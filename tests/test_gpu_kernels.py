@@ -157,7 +157,7 @@ def test_gemm_emits_row_statistics(M, N, K):
     assert torch.equal(out2, out[:m2]) and torch.equal(stat2, stat[:m2])
 
 
-@pytest.mark.parametrize("M", [19152, 21 * 912 + 37, 16384 + 128])
+@pytest.mark.parametrize("M", [19152, 21 * 912 + 37, 16384 + 128, 6 * 1376, 5 * 912, 8192 + 64])   # the last three: 128x128 rounds + a one-wave-tile remainder
 def test_row_split_dispatch_is_invisible(M):
     """launch sizes between the tile tiers (the video path's ~20-crop batches) run whole rounds of the resident grid on 256x256
     tiles and the remaining rows on the finer tiers (gemm_bf16.hip launch_epi).  Rows are independent and every tier produces the

@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT
-timeout 1400 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-python tools/scan_perf.py 2>&1 | grep "Q="
-python bench.py --no-cpu-baseline --video-frames 0 --steps 2 --warmup 1 > gpurun_out/r04/bench_legs.json 2> gpurun_out/r04/bench_legs.err; tail -c 3500 gpurun_out/r04/bench_legs.json; tail -5 gpurun_out/r04/bench_legs.err
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for cfg in "6 518" "21 420" "12 420"; do set -- $cfg
+ for S in 1 0; do B=$1 RES=$2 SPLIT=$S python $R/tools/vit_batch_prof.py 2>&1 | grep "^B="; done
+ for S in 1 0; do B=$1 RES=$2 SPLIT=$S python $R/tools/vit_batch_prof.py 2>&1 | grep "^B="; done
+done

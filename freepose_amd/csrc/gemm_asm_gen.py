@@ -28,19 +28,40 @@ Fillers follow the MFMAs at a fixed rate (one per two MFMAs in phase 0, one per 
 """
 from __future__ import annotations
 
-TC, TR = 8, 8
-PCS = 8                      # DMA pieces per operand, wave and stage
-NACC = 4 * TC * TR
-
-# ---- fixed registers (clobbered by the statements that use them) ---------------------------------------------------------------
+# Two geometries are generated (macros FP_GASM4_* and FP_GASM8_*):
+#   4 waves (2 x 2, one per SIMD):   wave tile 128 x 128, 256 accumulator registers, fragments / addresses in v[64:215]
+#   8 waves (2 x 4, two per SIMD):   wave tile 128 x 64,  128 accumulator registers, everything else in v[16:127] (256 registers per
+#                                    wave in total); the loop is 1-2 % slower (1.5x the fragment reads per flop) but two waves share
+#                                    each SIMD's vector ALU in the epilogue
+TC = 8
+TR = PCS = NACC = NW = LDS_SHIFT = STORES = 0
 S_RSX, S_RSW = 36, 40        # buffer descriptors of the tile being LOADED
 S_DK, S_CNT, S_LX0, S_LW0, S_LX1, S_LW1 = 44, 45, 46, 47, 48, 49
 S_LAST = 49
-V_SETA_X, V_SETA_W, V_SETB_X, V_SETB_W = 64, 96, 128, 160
-V_XP, V_WP = 192, 200        # per-piece source offsets
-V_AX = {(0, 0): 208, (0, 1): 209, (1, 0): 210, (1, 1): 211}
-V_AW = {(0, 0): 212, (0, 1): 213, (1, 0): 214, (1, 1): 215}
-V_LAST = 215
+V_SETA_X = V_SETA_W = V_SETB_X = V_SETB_W = V_XP = V_WP = V_LAST = 0
+V_AX, V_AW = {}, {}
+
+
+def set_geometry(nw):
+    global TR, PCS, NACC, NW, LDS_SHIFT, STORES, V_SETA_X, V_SETA_W, V_SETB_X, V_SETB_W, V_XP, V_WP, V_LAST
+    NW = nw
+    TR = 8 if nw == 4 else 4
+    PCS = 32 // nw                      # DMA pieces per operand, wave and stage
+    NACC = 4 * TC * TR
+    LDS_SHIFT = 13 if nw == 4 else 12   # log2 of a wave's bytes per operand and stage
+    STORES = 2 * TC * (TR // 4)         # output stores per wave and tile (two per 16 x 64 block): the entry wait's count
+    v0 = 64 if nw == 4 else 16
+    V_SETA_X = v0
+    V_SETA_W = V_SETA_X + 4 * TC
+    V_SETB_X = V_SETA_W + 4 * TR
+    V_SETB_W = V_SETB_X + 4 * TC
+    V_XP = V_SETB_W + 4 * TR
+    V_WP = V_XP + PCS
+    base = V_WP + PCS
+    for n, key in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        V_AX[key] = base + n
+        V_AW[key] = base + 4 + n
+    V_LAST = base + 7
 
 
 def vr(b):
@@ -89,18 +110,18 @@ def interleave(mfmas, fillers, rate):
 def step(buf, preload_next=True):
     L = []
     m0 = [mfma(i, jj, V_SETA_X, V_SETA_W) for i in range(TC) for jj in range(TR)]
-    L += interleave(m0, frag_reads(buf, 1, V_SETB_X, V_SETB_W), 0.5)
+    L += interleave(m0, frag_reads(buf, 1, V_SETB_X, V_SETB_W), 0.5 if NW == 4 else 0.4)
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
     m1 = [mfma(i, jj, V_SETB_X, V_SETB_W) for i in range(TC) for jj in range(TR)]
     groups = dma_groups(buf)
     reads = frag_reads(buf ^ 1, 0, V_SETA_X, V_SETA_W) if preload_next else []
     fill = []
+    nrd = len(reads)
     for q in range(2 * PCS):
         fill += groups[q]
-        if reads:
-            fill.append(reads[q])
+        fill += reads[q * nrd // (2 * PCS):(q + 1) * nrd // (2 * PCS)]
     fill.append(f"s_add_u32 s{S_DK}, s{S_DK}, 0x80")
-    L += interleave(m1, fill, 1.0 if preload_next else 0.6)
+    L += interleave(m1, fill, (1.0 if preload_next else 0.6) * (1.0 if NW == 4 else 1.2))
     L += ["s_waitcnt lgkmcnt(0)"]
     return L
 
@@ -119,7 +140,7 @@ def setup_pieces(vx0, vw0, sx8, sw8):
 
 
 def setup_lds(lds_base, wave):
-    return [f"s_lshl_b32 s{S_LX0}, {wave}, 13", f"s_add_u32 s{S_LX0}, s{S_LX0}, {lds_base}", f"s_add_u32 s{S_LW0}, s{S_LX0}, 0x8000",
+    return [f"s_lshl_b32 s{S_LX0}, {wave}, {LDS_SHIFT}", f"s_add_u32 s{S_LX0}, s{S_LX0}, {lds_base}", f"s_add_u32 s{S_LW0}, s{S_LX0}, 0x8000",
             f"s_add_u32 s{S_LX1}, s{S_LX0}, 0x10000", f"s_add_u32 s{S_LW1}, s{S_LW0}, 0x10000"]
 
 
@@ -141,12 +162,12 @@ def prologue_stmt():
 
 
 def init_stmt():
-    # operands: 0..7 the W-side records (A operand, fragment jj), 8..15 the X-side records (fragment i)
+    # operands: 0..TR-1 the W-side records (A operand, fragment jj), TR..TR+7 the X-side records (fragment i)
     L = ["s_nop 1"]
     for i in range(TC):
         for jj in range(TR):
             f = i * TR + jj
-            L.append(f"v_mfma_f32_16x16x32_bf16 a[{4 * f}:{4 * f + 3}], %{jj}, %{8 + i}, 0")
+            L.append(f"v_mfma_f32_16x16x32_bf16 a[{4 * f}:{4 * f + 3}], %{jj}, %{TR + i}, 0")
     return L
 
 
@@ -154,8 +175,8 @@ def tile_stmt():
     # operands: 0-5 THIS tile's X lo, hi, records, W lo, hi, records | 6-11 the NEXT tile's | 12 strideX8 13 strideW8 14 lds_base
     #           15 wave 16 K/128 - 1 (body iterations before the last) | 17 vX0 18 vW0 19 vAX 20 vAW | 21 drain (s)
     # Entry wait: stages 0, 1 of this tile are the OLDEST vector-memory operations in flight; behind them sit the previous tile's
-    # epilogue (32 output stores per wave, always issued: rows / columns past the end are clipped by the store's descriptor, not
-    # branched around) and the next record loads.  vmcnt retires in order, so vmcnt(32) = "the stages have landed" without waiting
+    # epilogue (STORES = 32 / 16 output stores per wave in the 4- / 8-wave geometry, always issued: rows / columns past the end are clipped by the store's descriptor, not
+    # branched around) and the next record loads.  vmcnt retires in order, so vmcnt(STORES) = "the stages have landed" without waiting
     # for the store burst to drain.  The workgroup's first tile has no epilogue behind its stages: operand 21 != 0 -> vmcnt(0).
     L = ["s_nop 4"]
     L += descriptors("%0", "%1", "%2", "%3", "%4", "%5") + setup_pieces("%17", "%18", "%12", "%13") + setup_lds("%14", "%15")
@@ -163,7 +184,7 @@ def tile_stmt():
           f"v_add_u32 v{V_AX[(1, 0)]}, 0x10000, v{V_AX[(0, 0)]}", f"v_add_u32 v{V_AX[(1, 1)]}, 0x10000, v{V_AX[(0, 1)]}",
           f"v_mov_b32 v{V_AW[(0, 0)]}, %20", f"v_xor_b32 v{V_AW[(0, 1)]}, 64, v{V_AW[(0, 0)]}",
           f"v_add_u32 v{V_AW[(1, 0)]}, 0x10000, v{V_AW[(0, 0)]}", f"v_add_u32 v{V_AW[(1, 1)]}, 0x10000, v{V_AW[(0, 1)]}"]
-    L += ["s_cmp_eq_u32 %21, 0", "s_cbranch_scc1 L_nodrain_%=", "s_waitcnt vmcnt(0)", "L_nodrain_%=:", "s_waitcnt vmcnt(32)", "s_barrier"]
+    L += ["s_cmp_eq_u32 %21, 0", "s_cbranch_scc1 L_nodrain_%=", "s_waitcnt vmcnt(0)", "L_nodrain_%=:", f"s_waitcnt vmcnt({STORES})", "s_barrier"]
     L += frag_reads(0, 0, V_SETA_X, V_SETA_W)
     L += ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{S_DK}, 0x100", f"s_mov_b32 s{S_CNT}, %16"]
     L += ["L_k_%=:"] + step(0) + step(1)
@@ -189,12 +210,15 @@ def clob(vlo, vhi, slo, shi, acc):
 
 def main():
     print("// generated by freepose_amd/csrc/gemm_asm_gen.py — do not edit (the generator documents the loop)")
-    emit("FP_GASM_PROLOGUE_TEXT", prologue_stmt())
-    print("#define FP_GASM_PROLOGUE_CLOBBERS " + clob(V_XP, V_WP + PCS - 1, S_RSX, S_LAST, False))
-    emit("FP_GASM_INIT_TEXT", init_stmt())
-    print("#define FP_GASM_INIT_CLOBBERS " + ", ".join(f'"a{i}"' for i in range(NACC)))
-    emit("FP_GASM_TILE_TEXT", tile_stmt())
-    print("#define FP_GASM_TILE_CLOBBERS " + clob(V_SETA_X, V_LAST, S_RSX, S_LAST, True))
+    for nw in (4, 8):
+        set_geometry(nw)
+        p = f"FP_GASM{nw}"
+        emit(f"{p}_PROLOGUE_TEXT", prologue_stmt())
+        print(f"#define {p}_PROLOGUE_CLOBBERS " + clob(V_XP, V_WP + PCS - 1, S_RSX, S_LAST, False))
+        emit(f"{p}_INIT_TEXT", init_stmt())
+        print(f"#define {p}_INIT_CLOBBERS " + ", ".join(f'"a{i}"' for i in range(NACC)))
+        emit(f"{p}_TILE_TEXT", tile_stmt())
+        print(f"#define {p}_TILE_CLOBBERS " + clob(V_SETA_X, V_LAST, S_RSX, S_LAST, True))
 
 
 if __name__ == "__main__":

@@ -99,7 +99,7 @@ int fp_gemm_gelu_table(const uint16_t** out);
 // the hand-scheduled 256x256 kernel (gemm_asm.hip): the big-tile tier of the row-major epilogues
 bool fp_gemm_asm_supported(const FpGemmArgs& a, int epi);
 bool fp_gemm_asm_preferred(const FpGemmArgs& a, int epi);   // supported AND measured faster than the 16-wave kernel
-int fp_gemm_asm(const FpGemmArgs& a, int epi, hipStream_t stream);
+int fp_gemm_asm(const FpGemmArgs& a, int epi, int waves, hipStream_t stream);   // waves: 4 (one per SIMD) or 8 (two per SIMD)
 // y[i] = bf16(gelu_erf(x[i])): the direct expression, elementwise (test entry fp_op_gelu)
 int fp_gemm_gelu_direct(const bf16_t* x, bf16_t* y, size_t n, hipStream_t stream);
 // name of the kernel variant used for (epi) — for profiles / bench bookkeeping

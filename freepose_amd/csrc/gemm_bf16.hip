@@ -527,8 +527,9 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // one kernel per (epilogue, tile tier).  Big tier: the hand-scheduled one-wave-per-SIMD kernel (gemm_asm.hip) for the row-major
     // epilogues where it is the faster one (fp_gemm_asm_preferred: long K), the 16-wave HIP kernel otherwise.
     if constexpr (!FpEpiTraits<EPI>::TRANS) {
-        // lab A/B only: bit 8192 = never, bit 16384 = wherever the asm kernel supports the shape
-        if (big && !(var & 8192) && ((var & 16384) ? fp_gemm_asm_supported(a, EPI) : fp_gemm_asm_preferred(a, EPI))) return fp_gemm_asm(a, EPI, stream);
+        // lab A/B only: bit 8192 = never, bit 16384 = the 4-wave kernel wherever it supports the shape, bit 65536 = the 8-wave kernel
+        if (big && (var & 65536) && fp_gemm_asm_supported(a, EPI)) return fp_gemm_asm(a, EPI, 8, stream);
+        if (big && !(var & 8192) && ((var & 16384) ? fp_gemm_asm_supported(a, EPI) : fp_gemm_asm_preferred(a, EPI))) return fp_gemm_asm(a, EPI, 4, stream);
     }
     return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
          : tiny ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream)

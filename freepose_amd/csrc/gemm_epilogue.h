@@ -236,6 +236,20 @@ __device__ __forceinline__ void epilogue_acc(const FpGemmArgs& p, const Acc& acc
         char* wr = stg + li * 128;
         const int wkey = (li >> 1) & 7;
         const int mbase = m0 + wm * (16 * TM);
+        // Output stores and residual loads go through buffer descriptors clipped at row M (an out-of-range offset is dropped / reads
+        // zero) and a lane whose 8 columns lie past N gets an offset past every range: no bounds branch, no 64-bit address arithmetic
+        // per access (a fifth of the plain epilogue's vector-ALU instructions).  The patch scatter keeps pointers (rows move per crop).
+        constexpr bool BUF = EPI != FP_EPI_PATCH;
+        constexpr int AUX = (VAR & 64) ? 2 : 0;                 // streaming (non-temporal) policy of the big-tile kernels
+        const int rows_left = max(p.M - mbase, 0);
+        auto records = [&](int ld) { const unsigned long long bb = (unsigned long long)rows_left * (unsigned)ld * 2ull; return (int)(bb > 0x7fffffffull ? 0x7fffffffull : bb); };
+        __amdgpu_buffer_rsrc_t rsC, rsR;
+        if constexpr (BUF) {
+            rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (size_t)min(mbase, p.M) * p.ldc), 0, records(p.ldc), 0x00020000);
+            rsR = rsC;
+            if constexpr (LSRES) rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid + (size_t)min(mbase, p.M) * p.ldr), 0, records(p.ldr), 0x00020000);
+        }
+        const int ldc2 = p.ldc * 2, ldr2 = p.ldr * 2;
         static_for<0, NG>([&](auto grp_c) {
             constexpr int grp = decltype(grp_c)::value;
             const int nbw = n0 + wn * (16 * TN) + grp * 64;     // the wave's 64-feature group
@@ -249,12 +263,12 @@ __device__ __forceinline__ void epilogue_acc(const FpGemmArgs& p, const Acc& acc
             // LayerScale+residual: the residual rows of block i+1 are requested (row layout, 16 B per lane) before block i
             // is processed, so their HBM latency overlaps a whole block instead of sitting between an LDS read and its store
             uint4 res[2][2];
+            const bool col_ok = nb2 < p.N;
             auto load_res = [&](int i, uint4 (&r)[2]) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int m = min(mbase + 16 * i + h * 8 + prow, p.M - 1);
-                    const u32x4_t* rp = (const u32x4_t*)(p.resid + (size_t)m * p.ldr + min(nb2, p.N - 8));
-                    const u32x4_t rv = ((VAR & 64) != 0) ? __builtin_nontemporal_load(rp) : *rp;   // read once: streaming too
+                    const int off = col_ok ? (16 * i + h * 8 + prow) * ldr2 + nb2 * 2 : 0x7fffffff;
+                    const u32x4_t rv = __builtin_amdgcn_raw_buffer_load_b128(rsR, off, 0, AUX);        // read once: streaming too
                     r[h] = make_uint4(rv.x, rv.y, rv.z, rv.w);
                 }
             };
@@ -305,7 +319,9 @@ __device__ __forceinline__ void epilogue_acc(const FpGemmArgs& p, const Acc& acc
                     const u32x4_t t = __builtin_bit_cast(
                         u32x4_t, *(const bf16x8_t*)(stg + r * 128 + ((pslot ^ ((r >> 1) & 7)) << 4)));
                     const int m = mbase + 16 * i + r;
-                    if (m >= p.M || nb2 >= p.N) continue;
+                    if constexpr (!BUF) {
+                        if (m >= p.M || nb2 >= p.N) continue;
+                    }
                     size_t orow = (size_t)m;
                     u32x4_t o = t;
                     if constexpr (LSRES) {
@@ -333,7 +349,7 @@ __device__ __forceinline__ void epilogue_acc(const FpGemmArgs& p, const Acc& acc
                             sm += lane_xor<4>(sm); sq += lane_xor<4>(sq);
                             sm += lane_xor<2>(sm); sq += lane_xor<2>(sq);
                             sm += lane_xor<1>(sm); sq += lane_xor<1>(sq);
-                            if (pslot == 0) p.stat_part[(size_t)(nbw >> 6) * p.stat_ld + m] = make_float2(sm, sq);
+                            if (pslot == 0 && m < p.M && nbw < p.N) p.stat_part[(size_t)(nbw >> 6) * p.stat_ld + m] = make_float2(sm, sq);
                         }
                     } else if constexpr (EPI == FP_EPI_PATCH) {
                         const int b = m / p.P, pp = m - b * p.P;
@@ -348,7 +364,8 @@ __device__ __forceinline__ void epilogue_acc(const FpGemmArgs& p, const Acc& acc
                         o = u32x4_t{ow[0], ow[1], ow[2], ow[3]};
                     }
                     if (FP_GEMM_DBG_BIT(p, 16) && o.x != 0x12345678u) continue;   // lab build only (gemm_dbg = 16): everything but the stores
-                    if constexpr ((VAR & 64) != 0) __builtin_nontemporal_store(o, (u32x4_t*)(p.C + orow * p.ldc + nb2));
+                    if constexpr (BUF) __builtin_amdgcn_raw_buffer_store_b128(o, rsC, col_ok ? (16 * i + r) * ldc2 + nb2 * 2 : 0x7fffffff, 0, AUX);
+                    else if constexpr ((VAR & 64) != 0) __builtin_nontemporal_store(o, (u32x4_t*)(p.C + orow * p.ldc + nb2));
                     else *(u32x4_t*)(p.C + orow * p.ldc + nb2) = o;
                 }
             });

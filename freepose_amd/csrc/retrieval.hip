@@ -780,14 +780,11 @@ int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int 
             hipLaunchKernelGGL((bank_scan_kernel<NCHV, QTV, false>), dim3(blocks), dim3(256), 0, s, bank, queries,  \
                                keys, N, D, qb, Q, ldk);                                                             \
     } while (0)
-        // 5+ queries left: EIGHT per pass (the queries of an image's proposals / a frame's objects share one pass over the bank;
-        // the reference scans once per proposal, scripts/extract_proposals_ground.py:136-137).  8 x 16 unpacked query values per lane
-        // put the kernel at ~230 VGPRs / 2 waves per SIMD — 16 KB of rows in flight per wave keep it memory-bound (the FMA work of
-        // 8 queries is ~8 us of vector ALU against >= 15 us of bank traffic); 16 would not fit the register file.  D <= 1024.
-        if (left >= 5 && nch <= 2) {
-            if (nch == 1) FP_SCAN(1, 8); else FP_SCAN(2, 8);
-            qb += 8;
-        } else if (left >= 4) {
+        // (8 queries per pass was measured in round 4 — profiles/r04_ab.md §3: 44.4 us against 2 x 21.9 us for two 4-query passes.
+        // Beyond one query the pass is bound by vector-ALU issue, ~4 us per extra query, and at 8 x 16 unpacked query values per
+        // lane the kernel drops to one wave per SIMD; a matrix-pipe form would change the canonical summation order that makes the
+        // indices bit-exact.  Four per pass stays.)
+        if (left >= 4) {
             if (nch == 1) FP_SCAN(1, 4); else if (nch == 2) FP_SCAN(2, 4); else FP_SCAN(3, 4);
             qb += 4;
         } else {

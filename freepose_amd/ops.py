@@ -29,7 +29,7 @@ def context(device: Optional[int] = None):
 
 
 CTX_OPTIONS = ("ln_fused", "raster_tiled", "gemm_row_split")
-BANK_QUERIES_PER_PASS = 8      # bank_scan_kernel: up to 8 queries share one pass over the bank (retrieval.hip fp_bank_scan)
+BANK_QUERIES_PER_PASS = 4      # bank_scan_kernel: up to 4 queries share one pass over the bank (retrieval.hip fp_bank_scan)
 
 
 def set_option(name: str, value: int, device: Optional[int] = None):

@@ -23,11 +23,15 @@ def timeit(fn, iters=5):
     return t.elapsed_ms() / iters
 
 
-def ab(name, variants, setter, fn, flops, rounds=5):
+def ab(name, variants, setter, fn, flops, rounds=6):
     res = {v: [] for v in variants}
-    for _ in range(rounds):
-        for v in variants:
+    for rd in range(rounds):
+        # the order rotates every round: the variant that runs first after a switch measured ~3 % slow (clock / cache state left by
+        # its predecessor), which biased fixed-order comparisons against the first-listed variant
+        order = variants[rd % len(variants):] + variants[:rd % len(variants)]
+        for v in order:
             setter(v)
+            timeit(fn, iters=2)            # settle
             res[v].append(timeit(fn))
     setter(-1)
     out = []

@@ -39,7 +39,7 @@ def main():
     bias, gamma = torch.randn((N,), generator=g).to(torch.bfloat16), torch.randn((N,), generator=g).to(torch.bfloat16)
     resid = torch.randn((M, N), generator=g).to(torch.bfloat16)
     ref0, ref2 = ops.gemm(x, w, bias, 0).cpu(), ops.gemm(x, w, bias, 2, gamma=gamma, resid=resid).cpu()
-    for var in (0, 6, 14, 46, 110, 238 | 256, 238 | 2048, 238 | 512, 238 | 8192, 238 | 16384):
+    for var in (0, 6, 14, 46, 110, 238 | 256, 238 | 2048, 238 | 512, 238 | 8192, 238 | 16384, 238 | 65536):
         ops.set_option("gemm_variant", var)
         assert torch.equal(ops.gemm(x, w, bias, 0).cpu(), ref0), var
         assert torch.equal(ops.gemm(x, w, bias, 2, gamma=gamma, resid=resid).cpu(), ref2), var
@@ -48,13 +48,13 @@ def main():
     #     table GELU and row statistics through the pipelined epilogue at K = 1024, where the product keeps the 16-wave kernel
     g_ln, b_ln = torch.randn((K,), generator=g).to(torch.bfloat16), (torch.randn((K,), generator=g) * 0.3).to(torch.bfloat16)
     outs = {}
-    for var in (238 | 8192, 238 | 16384):
+    for var in (238 | 8192, 238 | 16384, 238 | 65536):
         ops.set_option("gemm_variant", var)
         st_o, st_r = ops.gemm_stats(x, w, bias, gamma, resid)
         outs[var] = [ops.gemm(x, w, bias, 1).cpu(), ops.ln_linear(x, g_ln, b_ln, w, bias, mode=0).cpu(),
                      ops.ln_linear(x, g_ln, b_ln, w, bias, mode=1).cpu(), st_o.cpu(), st_r.cpu()]
     ops.set_option("gemm_variant", -1)
-    for a_, b_ in zip(outs[238 | 8192], outs[238 | 16384]):
+    for a_, b_ in list(zip(outs[238 | 8192], outs[238 | 16384])) + list(zip(outs[238 | 8192], outs[238 | 65536])):
         assert torch.equal(a_, b_), "hand-scheduled tier differs from the 16-wave kernel"
     # 3. attention: ring depths and the short-tail-off flavour agree to rounding (the exponent reference differs by tile order only)
     B, H, n_tok = 3, 16, 905

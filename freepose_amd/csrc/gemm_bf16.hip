@@ -497,6 +497,13 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // 64x64 tiles instead — 4x the workgroups, all CUs busy (bit 2048, A/B only: keep the 128x128 kernel).
     const long tiles_mid = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     const bool tiny = !big && ((tiles_mid < ncu && !(var & 2048)) || (var & 32768));   // bit 32768 (lab A/B only): one-wave tiles whenever not big
+    // Big tier: the hand-scheduled one-wave-per-SIMD kernel (gemm_asm.hip) for the row-major
+    // epilogues where it is the faster one (fp_gemm_asm_preferred: long K), the 16-wave HIP kernel otherwise.
+    if constexpr (!FpEpiTraits<EPI>::TRANS) {
+        // lab A/B only: bit 8192 = never, bit 16384 = the 4-wave kernel wherever it supports the shape, bit 65536 = the 8-wave kernel
+        if (big && (var & 65536) && fp_gemm_asm_supported(a, EPI)) return fp_gemm_asm(a, EPI, 8, stream);
+        if (big && !(var & 8192) && ((var & 16384) ? fp_gemm_asm_supported(a, EPI) : fp_gemm_asm_preferred(a, EPI))) return fp_gemm_asm(a, EPI, 4, stream);
+    }
 #ifdef FP_LAB
     if constexpr (EPI < FP_EPI_LN_BIAS) {   // lab build: the alternative kernels of the plain epilogues (A/B runs)
         if (var != FP_GEMM_DEFAULT_VARIANT) {
@@ -524,13 +531,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
         }
     }
 #endif
-    // one kernel per (epilogue, tile tier).  Big tier: the hand-scheduled one-wave-per-SIMD kernel (gemm_asm.hip) for the row-major
-    // epilogues where it is the faster one (fp_gemm_asm_preferred: long K), the 16-wave HIP kernel otherwise.
-    if constexpr (!FpEpiTraits<EPI>::TRANS) {
-        // lab A/B only: bit 8192 = never, bit 16384 = the 4-wave kernel wherever it supports the shape, bit 65536 = the 8-wave kernel
-        if (big && (var & 65536) && fp_gemm_asm_supported(a, EPI)) return fp_gemm_asm(a, EPI, 8, stream);
-        if (big && !(var & 8192) && ((var & 16384) ? fp_gemm_asm_supported(a, EPI) : fp_gemm_asm_preferred(a, EPI))) return fp_gemm_asm(a, EPI, 4, stream);
-    }
+    // one kernel per (epilogue, tile tier)
     return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
          : tiny ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream)
                 : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);

@@ -45,6 +45,10 @@ def test_product_library_carries_no_lab():
     stubs = [ln for ln in subprocess.run(["nm", str(obj)], capture_output=True, text=True, check=True).stdout.splitlines()
              if "__device_stub__" in ln]
     assert 0 < len(stubs) <= 30, len(stubs)
+    asm_obj = ROOT / "freepose_amd" / "lib" / "obj" / "gemm_asm.o"     # the hand-scheduled tier: one kernel per epilogue it can be dispatched for
+    asm_stubs = [ln for ln in subprocess.run(["nm", str(asm_obj)], capture_output=True, text=True, check=True).stdout.splitlines()
+                 if "__device_stub__" in ln]
+    assert 0 < len(asm_stubs) <= 4, len(asm_stubs)
     for src in (ROOT / "freepose_amd" / "csrc").glob("*"):
         text = src.read_text()
         depth, bad = 0, []

@@ -75,7 +75,10 @@ __device__ __forceinline__ int key_perm4(int row) {  // rows laid out 16a + 4f +
 }
 
 template <int NSLOT, int VAR = 0>  // LDS ring depth: NSLOT-1 K/V tiles in flight (16 KiB per slot); VAR bit 1: MFMA segments at raised priority
-__global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {   // 3 waves/SIMD: <= 168 VGPRs
+__global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kernel(AttnArgs p) {   // 3 waves/SIMD: <= 168 VGPRs
+    // VAR bit 16 (the shipped flavour since round 4): FOUR waves per SIMD — 128 registers, no spills — by reading the V^T fragments
+    // per 32-key half right before their MFMAs instead of the whole tile up front, and finishing both query halves' softmax before
+    // the PV products.  Bit-identical to the 3-wave flavour; +0.8-1.4 % at 1374 tokens, +2.3-2.7 % at 905 (profiles/r04_ab.md §5).
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,12 +266,15 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
         // contraction slot (lg, j) <-> key 32 ks + 8 lg + j: one 16-byte read per fragment (slot 4 ks + lg), conflict free
         // under the same XOR key as the GEMM's permuted-row operand.  (bf16-typed like the K reads: an integer-typed LDS
         // load makes hipcc protect it against the in-flight LDS DMA with a vmcnt(0), draining the ring every tile.)
-        bf16x8_t vf[2][4];
+        constexpr bool JITV = (VAR & 16) != 0;
+        bf16x8_t vf[JITV ? 1 : 2][4];
+        if constexpr (!JITV) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int sv = (((ks << 2) | lg) ^ keyV) << 4;
 #pragma unroll
             for (int fd = 0; fd < 4; ++fd) vf[ks][fd] = *(const bf16x8_t*)(sb + baseV + fd * 4 * ROWB + sv);
+        }
         }
 
         // ---- online softmax of one 16-query half (per query column; 4 lanes lg=0..3 share a query) ---------------------
@@ -343,11 +349,31 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn_fwd_kernel(AttnArgs p) {  
             for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
                 for (int fd = 0; fd < 4; ++fd)
-                    o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks][fd], pf[fq][ks], o[fd][fq], 0, 0, 0);
+                    o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[JITV ? 0 : ks][fd], pf[fq][ks], o[fd][fq], 0, 0, 0);
                 lacc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[fq][ks], lacc[fq], 0, 0, 0);
             }
         };
 
+        if constexpr (JITV) {
+            softmax_max(0);
+            softmax_exp(0);
+            softmax_max(1);
+            softmax_exp(1);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int sv = (((ks << 2) | lg) ^ keyV) << 4;
+#pragma unroll
+                for (int fd = 0; fd < 4; ++fd) vf[0][fd] = *(const bf16x8_t*)(sb + baseV + fd * 4 * ROWB + sv);
+#pragma unroll
+                for (int fq = 0; fq < 2; ++fq) {
+#pragma unroll
+                    for (int fd = 0; fd < 4; ++fd)
+                        o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0][fd], pf[fq][ks], o[fd][fq], 0, 0, 0);
+                    lacc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[fq][ks], lacc[fq], 0, 0, 0);
+                }
+            }
+            return;
+        }
         softmax_max(0);
         softmax_exp(0);
         softmax_max(1);
@@ -436,9 +462,15 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     if (nslot == 4) { hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(NWAVE * 64), 4 * STAGE, stream, a); FP_LAUNCH_CHECK(); return FP_OK; }
     if (nslot == 3) { hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(NWAVE * 64), 3 * STAGE, stream, a); FP_LAUNCH_CHECK(); return FP_OK; }
     if (avar & 8) { hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a); FP_LAUNCH_CHECK(); return FP_OK; }   // short-tail off
+    if (avar & 32) {   // the round-3 flavour: three waves per SIMD, whole-tile V^T prefetch, half 0's PV under half 1's exponentials
+        if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+        else hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+        FP_LAUNCH_CHECK();
+        return FP_OK;
+    }
 #endif
-    if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4 | 16>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<2, 16>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -532,9 +532,18 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     }
 #endif
     // one kernel per (epilogue, tile tier)
-    return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
-         : tiny ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream)
-                : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);
+    // tiny tier: 64x64 tiles.  Row-major epilogues split the tile over TWO waves (32 x 64 each): a launch that cannot fill the chip is
+    // bound by one wave's walk along K, and per K step a lone wave issues 16 LDS-DMA pieces for 32 MFMAs — two waves halve both
+    // (ViT-L B = 1 @518^2: see profiles/r04_ab.md §4).  The transposed V store needs 64-token wave tiles and keeps one wave.
+    if constexpr (FpEpiTraits<EPI>::TRANS)
+        return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
+             : tiny ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream)
+                    : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);
+    else
+        return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
+             : tiny ? ((var & 131072) ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream)      // bit 131072 (lab A/B only): one wave
+                                      : launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream))
+                    : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);
 }
 
 }  // namespace

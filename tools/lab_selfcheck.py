@@ -62,7 +62,7 @@ def main():
     qk = (torch.randn((B * npad, 2 * H * 64), generator=g) * 0.5).to(torch.bfloat16)
     vt = torch.randn((B, H, 64, npad), generator=g).to(torch.bfloat16)
     base = ops.attention(qk, vt, n_tok).float().cpu()
-    for name, val in (("attn_slots", 3), ("attn_slots", 4), ("attn_variant", 8)):
+    for name, val in (("attn_slots", 3), ("attn_slots", 4), ("attn_variant", 8), ("attn_variant", 32)):
         ops.set_option(name, val)
         o = ops.attention(qk, vt, n_tok).float().cpu()
         ops.set_option(name, -1)

@@ -526,7 +526,7 @@ def main():
                                    f"{args.res}^2, ViT + patchwise score -> top-3 pose; all stages per proposal (no feature cache)",
                        "proposals_per_step_per_gpu": B, "vit_forwards_per_proposal": 1 + args.hyp, "weights": "seeded random init, DINOv2 ViT-L/14-reg shapes",
                        "parallelism": f"proposals sharded over {world} rank(s), bank replicated"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all ViT linear layers)", "achieved": gemm_tf,
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel + gemm_asm_kernel (all ViT linear layers)", "achieved": gemm_tf,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": _pmc_traffic(), "csrc_sha16": csrc_hash(), "launches": prof["gemm_launches"],
                          "avg_launch_ms": prof["ms_gemm"] / max(prof["gemm_launches"], 1),
@@ -607,7 +607,7 @@ def csrc_hash() -> str:
 def _pmc_traffic():
     """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary (tools/profile_job.sh -> profiles/), only if that
     summary was taken on exactly these kernel sources (its csrc_sha16 equals csrc_hash()); otherwise null"""
-    for name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json"):
+    for name in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):
         p = ROOT / "profiles" / name
         if p.exists():
             try:

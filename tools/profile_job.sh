@@ -7,7 +7,7 @@ OUT=$REPO/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
-BENCH="python $REPO/bench.py --no-cpu-baseline --video-frames 0"
+BENCH="python $REPO/bench.py --no-cpu-baseline --video-frames 0 --no-config-legs"
 export FP_CSRC_SHA=$(cd $REPO && python -c "import bench; print(bench.csrc_hash())")
 echo "csrc_sha16 = $FP_CSRC_SHA"
 
@@ -70,7 +70,7 @@ json.dump(kernel_summary("attn_fwd_kernel", "attn_fwd_kernel (all attention laun
 # dominant kernel: all gemm launches (both schedules' kernel names)
 g = collections.defaultdict(lambda: [0.0, 0])
 for k, cs in per.items():
-    if k.startswith("gemm_bf16_kernel") or k.startswith("gemm_ap_kernel"):
+    if k.startswith("gemm_bf16_kernel") or k.startswith("gemm_asm_kernel"):
         for c, v in cs.items():
             g[c][0] += v[0]; g[c][1] += v[1]
 res = {"kernel": "gemm_bf16_kernel (all ViT linear-layer launches of one bench step)", "csrc_sha16": sha, "source": "rocprofv3 --pmc on `bench.py --steps 1 --warmup 0`, separate passes"}

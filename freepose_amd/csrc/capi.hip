@@ -82,6 +82,13 @@ extern "C" int fp_ctx_create(int device, fp_ctx** out) {
                      prop.gcnArchName);
         return FP_ERR_STATE;
     }
+    // the code object is built for gfx950:sramecc+ only (the fc1 epilogue's LDS table gather relies on the d16 load behaviour of that
+    // mode, gemm_epilogue.h): on a device or partition reporting sramecc- no kernel image would load — say so instead of failing on
+    // the first launch with "no kernel image is available"
+    if (strstr(prop.gcnArchName, "sramecc-")) {
+        fp_set_error("ctx_create: device %d is %s; libfreepose_hip is built for gfx950:sramecc+ (SRAM ECC enabled) only", device, prop.gcnArchName);
+        return FP_ERR_STATE;
+    }
     if (int rc = fp_gemm_gelu_table(nullptr)) return rc;   // per-device constant table of the fc1 epilogue
     fp_ctx* c = new fp_ctx();
     c->device = device;

@@ -58,6 +58,7 @@ class DinoPoseEstimator(torch.nn.Module):
         self.feature_cache.move_to_end(key)
         while len(self.feature_cache) > self.cache_size:
             self.feature_cache.popitem(last=False)
+        return features                                # the NORMALISED rows (also when cache_size evicted them at once)
 
     def _get_template_features(self, template_dict, layer=22, batch_size=128):
         """pre-normalised features of the mesh's templates (device store -> <name>.pth -> ViT)"""
@@ -70,8 +71,7 @@ class DinoPoseEstimator(torch.nn.Module):
             feats = torch.load(path, map_location="cpu").to("cuda", dtype=torch.bfloat16)
         else:
             feats = self._extract_features(template_dict["templates"], layer=layer, batch_size=batch_size)
-        self._cache_features(name, feats)
-        return self.feature_cache[name] if name in self.feature_cache else ops.l2_normalize(feats)
+        return self._cache_features(name, feats)           # normalised in place exactly once, whether or not the store kept it
 
     def __del__(self):
         try:
@@ -82,7 +82,9 @@ class DinoPoseEstimator(torch.nn.Module):
 
     def score_templates(self, feats_template, query_feat, normalize_query=True, templates_normalized=False):
         """[T] fp32 (bf16-valued) mean patch cosine of every template against the query.  `templates_normalized`: the rows of
-        feats_template are already F.normalize()d (the device store) -> streaming dot, same bits."""
+        feats_template are already F.normalize()d -> streaming dot, same bits.  NOTE: `self.feature_cache[...]` and what
+        `_get_template_features` returns ARE normalised (pass templates_normalized=True for them); raw features, e.g. straight from
+        `_extract_features`, take the default."""
         q = query_feat.reshape(-1, query_feat.shape[-1])
         if normalize_query:
             q = ops.l2_normalize(q)

@@ -13,10 +13,10 @@ from freepose_amd import ops  # noqa: E402
 
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 518
 vit = ops.ViT("dinov2_vitl14_reg", seed=0)
-for B in (1, 2, 3, 4, 5, 6, 8):
+for B in (2, 3, 4, 5, 6, 8, 10, 12, 16, 21):
     x = torch.rand((B, 3, res, res), device="cuda").to(torch.bfloat16)
     row = []
-    for name, var in (("default (2-wave tiny)", -1), ("1-wave tiny", 238 | 131072), ("no tiny", 238 | 2048)):
+    for name, var in (("default", -1), ("tiny forced below the big tier", 238 | 32768), ("no tiny", 238 | 2048)):
         ops.set_option("gemm_variant", var)
         for _ in range(2):
             vit(x, layer=22, feature_type="patch")

@@ -430,7 +430,7 @@ def main():
     ap.add_argument("--res", type=int, default=518)
     ap.add_argument("--bank", type=int, default=46037)
     ap.add_argument("--mesh-sub", type=int, default=6, help="icosphere subdivisions (6 -> 81 920 triangles)")
-    ap.add_argument("--vit-batch", type=int, default=192)
+    ap.add_argument("--vit-batch", type=int, default=288)   # largest batch whose fc1 output stays below the 4 GiB tile-offset limit; 192 -> 288: -0.6 % (profiles/r04_ab.md)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--video-frames", type=int, default=300,
                     help="frames of the secondary video-tracking measurement (BASELINE config 5; 0 = skip)")

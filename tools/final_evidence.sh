@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU-box job: everything the round's evidence needs from ONE box — GPU suite, smoke, the default bench line, then the rocprofv3
+# passes of tools/profile_job.sh (kernel stats + PMC) on the same tree.   gpurun --timeout 3600 -- bash tools/final_evidence.sh
+cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out/r04
+(timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -6) > gpurun_out/r04/final_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r04/smoke.log 2>&1; tail -1 gpurun_out/r04/smoke.log
+python bench.py > gpurun_out/r04/bench_line.json 2> gpurun_out/r04/bench_line.err
+tail -3 gpurun_out/r04/final_tests.log
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r04/bench_line.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"], d["stage_ms_rank0"])
+PY
+bash tools/profile_job.sh 2>&1 | tail -40

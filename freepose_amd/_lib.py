@@ -94,11 +94,11 @@ SIGNATURES = {
     "fp_op_gemm_vt": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                               c_void_p]),
     "fp_op_ln_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_int,
-                                c_int, c_void_p, c_void_p]),
+                                c_int, c_int, c_float, c_void_p, c_void_p]),
     "fp_op_gemm_stats": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_int, c_int, c_float, c_void_p, c_void_p]),
     "fp_op_gelu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "fp_op_attention": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fp_op_attention": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fp_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "fp_timer_create": (c_int, [P(c_void_p)]),
     "fp_timer_start": (c_int, [c_void_p, c_void_p]),

@@ -178,6 +178,10 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
     float mrow[2] = {-1e30f, -1e30f};
     float mthr[2] = {-1e30f, -1e30f};   // mrow + LAZY_THR and -mrow * scale, kept beside mrow (they change only on a rescale)
     float nmb[2] = {0.f, 0.f};
+    // PRE (VAR bit 64): Q arrives multiplied by log2(e) / sqrt(hd) (folded into the q rows of the qkv weights), and the first S^T MFMA
+    // starts from C = -reference, so the accumulators ARE the exponents: no multiply-add per element in the softmax.
+    constexpr bool PRE = (VAR & 64) != 0;
+    f32x4_t nref[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};   // -reference (log2 units) on every register
     f32x4_t lacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};   // [0]: running sum of P per query
     bf16x8_t ones;
 #pragma unroll
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
                 const bf16x8_t kf = *(const bf16x8_t*)(sb + baseK + (32 * (fk >> 1) + 4 * (fk & 1)) * ROWB + slot);
 #pragma unroll
                 for (int fq = 0; fq < 2; ++fq)
-                    s[fk][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[fq][kk], kk == 0 ? f32x4_t{0.f, 0.f, 0.f, 0.f} : s[fk][fq], 0, 0, 0);
+                    s[fk][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[fq][kk], kk == 0 ? (PRE ? nref[fq] : f32x4_t{0.f, 0.f, 0.f, 0.f}) : s[fk][fq], 0, 0, 0);
             }
         }
         if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
@@ -303,6 +307,28 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
             // The lazy test needs no cross-lane work: "some query's row maximum exceeds its reference + LAZY_THR" is the same
             // predicate as "some LANE's local maximum does" (a row maximum is the maximum of its 4 lanes).  Only the rare
             // rescale reduces over the 4 lanes sharing a query (lane bits 4 and 5: VALU row/half swaps, not ds_bpermute).
+            if constexpr (PRE) {
+                // accumulators are already (logit - reference) in log2 units: the lazy test is a compare with a constant.  The FIRST
+                // tile always moves the reference to its row maximum (from 0, which may sit far above every logit).
+                constexpr float THR2 = LAZY_THR * 1.4426950408889634f / 8.0f;
+                if (__builtin_amdgcn_ballot_w64(mx > THR2) != 0 || t == 0) {   // wave-uniform
+                    mx = xlane_max16(mx);
+                    mx = xlane_max32(mx);
+                    const float delta = vmax2(mx, t == 0 ? -3.0e38f : 0.f);   // how far the reference moves (>= 0 after the first tile)
+                    const float alpha = __builtin_amdgcn_exp2f(-vmax2(delta, 0.f));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nref[fq][r] -= delta;
+#pragma unroll
+                    for (int fk = 0; fk < 2 * NKS; ++fk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[fk][fq][r] -= delta;
+                    lacc[fq][0] *= alpha;
+#pragma unroll
+                    for (int fd = 0; fd < 4; ++fd)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[fd][fq][r] *= alpha;
+                }
+            } else
             if (__builtin_amdgcn_ballot_w64(mx > mthr[fq]) != 0) {   // wave-uniform
                 mx = xlane_max16(mx);
                 mx = xlane_max32(mx);
@@ -320,19 +346,36 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
             }
         };
         auto softmax_exp = [&](int fq) {
-            const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e};
-            const f32x2_t mb2 = {nmb[fq], nmb[fq]};
             float pv[4][4];
+            if constexpr (PRE) {
 #pragma unroll
-            for (int fk = 0; fk < 2 * NKS; ++fk)
+                for (int fk = 0; fk < 2 * NKS; ++fk)
 #pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    // two elements per v_pk_fma_f32 (each lane of it is an ordinary fused multiply-add)
-                    const f32x2_t a = {s[fk][fq][r], s[fk][fq][r + 1]};
-                    const f32x2_t e = __builtin_elementwise_fma(a, sc2, mb2);
-                    pv[fk][r] = __builtin_amdgcn_exp2f(e[0]);
-                    pv[fk][r + 1] = __builtin_amdgcn_exp2f(e[1]);
-                }
+                    for (int r = 0; r < 4; ++r) pv[fk][r] = __builtin_amdgcn_exp2f(s[fk][fq][r]);
+            } else if constexpr (VAR & 128) {   // lab: one packed FMA per two elements (the round-3 form; 4.5 % slower, same bits)
+                const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e};
+                const f32x2_t mb2 = {nmb[fq], nmb[fq]};
+#pragma unroll
+                for (int fk = 0; fk < 2 * NKS; ++fk)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2_t a = {s[fk][fq][r], s[fk][fq][r + 1]};
+                        const f32x2_t e = __builtin_elementwise_fma(a, sc2, mb2);
+                        pv[fk][r] = __builtin_amdgcn_exp2f(e[0]);
+                        pv[fk][r + 1] = __builtin_amdgcn_exp2f(e[1]);
+                    }
+            } else {
+                // one plain v_fma_f32 per element, as asm so that hipcc does not pair them into v_pk_fma_f32: a packed fp32 instruction
+                // costs more than its two halves beside MFMAs on this part (903 -> 944 TFLOP/s at 1374 tokens, identical bits)
+#pragma unroll
+                for (int fk = 0; fk < 2 * NKS; ++fk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float e;
+                        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(e) : "v"(s[fk][fq][r]), "v"(p.scale_log2e), "v"(nmb[fq]));
+                        pv[fk][r] = __builtin_amdgcn_exp2f(e);
+                    }
+            }
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 uint4 w;
@@ -439,16 +482,18 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
 
 }  // namespace
 
-// QK [B*npad, 2D] (ldqk elements), Vt [B,H,64,npad], O [B*npad, D] (ldo elements)
+// QK [B*npad, 2D] (ldqk elements), Vt [B,H,64,npad], O [B*npad, D] (ldo elements).
+// q_prescaled: the q columns hold q * log2(e) / sqrt(64) (the ViT path folds that factor into the q rows of the LayerNorm-folded qkv
+// weights, vit_misc.hip ln_fold_kernel), so S^T accumulates straight into base-2 exponents relative to the running reference.
 int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, int ldo, int B, int H,
-                     int n_tok, int npad, hipStream_t stream) {
+                     int n_tok, int npad, bool q_prescaled, hipStream_t stream) {
     FP_REQUIRE(B > 0 && H > 0 && n_tok > 0 && npad >= n_tok && npad % 16 == 0,
                "attention: bad shape B=%d H=%d n_tok=%d npad=%d", B, H, n_tok, npad);
     FP_REQUIRE(npad >= 8, "attention: npad too small");
     AttnArgs a;
     a.QK = QK; a.ldqk = ldqk; a.Vt = Vt; a.O = O; a.ldo = ldo;
     a.B = B; a.H = H; a.n_tok = n_tok; a.npad = npad; a.D = H * HD;
-    a.scale_log2e = 1.4426950408889634f / 8.0f;
+    a.scale_log2e = FP_ATTN_QSCALE;
     a.q_base = 0;
     dim3 grid(cdiv(npad - a.q_base, QB) * H * B);
     // a last K/V tile whose valid keys all sit in its first half is processed first by a half-length body (kernel flavour 4)
@@ -457,20 +502,33 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
     const int nslot = fp_opt_get(FP_OPT_ATTN_SLOTS, 2);
     static int env_var = [] { const char* e = getenv("FP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
     const int avar = fp_opt_get(FP_OPT_ATTN_VARIANT, env_var);
+    if (!q_prescaled) {
     if (nslot == 2 && (avar & 2)) { hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a); FP_LAUNCH_CHECK(); return FP_OK; }
     if (nslot == 2 && (avar & 1)) { hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a); FP_LAUNCH_CHECK(); return FP_OK; }
     if (nslot == 4) { hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(NWAVE * 64), 4 * STAGE, stream, a); FP_LAUNCH_CHECK(); return FP_OK; }
     if (nslot == 3) { hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, dim3(NWAVE * 64), 3 * STAGE, stream, a); FP_LAUNCH_CHECK(); return FP_OK; }
     if (avar & 8) { hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a); FP_LAUNCH_CHECK(); return FP_OK; }   // short-tail off
+    if ((avar & 128) && !q_prescaled) {   // packed multiply-add in the softmax (the form shipped until round 4)
+        if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4 | 16 | 128>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<2, 16 | 128>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+        FP_LAUNCH_CHECK();
+        return FP_OK;
+    }
     if (avar & 32) {   // the round-3 flavour: three waves per SIMD, whole-tile V^T prefetch, half 0's PV under half 1's exponentials
         if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
         else hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
         FP_LAUNCH_CHECK();
         return FP_OK;
     }
+    }
 #endif
-    if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4 | 16>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<2, 16>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    if (q_prescaled) {
+        if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4 | 16 | 64>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<2, 16 | 64>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    } else {
+        if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4 | 16>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<2, 16>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+    }
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -258,8 +258,9 @@ static int vit_fold(fp_vit* v, int first, int L, hipStream_t s) {
         if (!f.fc1w) FP_HIP(hipMalloc((void**)&f.fc1w, Mm * D * 2));
         if (!f.fc1_cb) FP_HIP(hipMalloc((void**)&f.fc1_cb, Mm * sizeof(uint4)));
         int rc;
-        if ((rc = fp_ln_fold(w.qkvw, w.n1w, w.n1b, w.qkvb, f.qkvw, f.qkv_cb, (int)(3 * D), (int)D, s))) return rc;
-        if ((rc = fp_ln_fold(w.fc1w, w.n2w, w.n2b, w.fc1b, f.fc1w, f.fc1_cb, (int)Mm, (int)D, s))) return rc;
+        // q rows carry log2(e) / sqrt(head_dim): fp_attention_fwd(..., q_prescaled = true) below
+        if ((rc = fp_ln_fold(w.qkvw, w.n1w, w.n1b, w.qkvb, f.qkvw, f.qkv_cb, (int)(3 * D), (int)D, (int)D, FP_ATTN_QSCALE, s))) return rc;
+        if ((rc = fp_ln_fold(w.fc1w, w.n2w, w.n2b, w.fc1b, f.fc1w, f.fc1_cb, (int)Mm, (int)D, 0, 1.0f, s))) return rc;
     }
     return FP_OK;
 }
@@ -395,7 +396,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         }
         {
             ProfScope ps(v, s, &v->ms_attn);
-            if ((rc = fp_attention_fwd(QK, 2 * D, Vt, AO, D, B, a.heads, n_tok, npad, s))) return rc;
+            if ((rc = fp_attention_fwd(QK, 2 * D, Vt, AO, D, B, a.heads, n_tok, npad, /*q_prescaled=*/lnf, s))) return rc;
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
@@ -574,7 +575,8 @@ extern "C" int fp_op_gemm_vt(fp_ctx* ctx, const void* X, int ldx, const void* W,
 // LayerNorm folded into a linear layer, as fp_vit_forward runs LN1 -> qkv and LN2 -> fc1 (kernel-level entry for the tests):
 // fold W' / (colsum, b') -> row statistics of X -> the LN-folded GEMM.  mode 0: bias, 1: bias + GELU, 2: transposed V store.
 extern "C" int fp_op_ln_linear(fp_ctx* ctx, const void* X, int M, int K, const void* g_ln, const void* b_ln, float eps,
-                               const void* W, int N, const void* bias, int mode, int npad, int heads, void* out, void* stream) {
+                               const void* W, int N, const void* bias, int mode, int npad, int heads, int n_scaled, float row_scale,
+                               void* out, void* stream) {
     FP_REQUIRE(ctx && X && g_ln && b_ln && W && bias && out, "op_ln_linear: null argument");
     FP_REQUIRE(mode >= 0 && mode <= 2, "op_ln_linear: mode %d (0..2)", mode);
     hipStream_t s = (hipStream_t)stream;
@@ -586,7 +588,8 @@ extern "C" int fp_op_ln_linear(fp_ctx* ctx, const void* X, int M, int K, const v
     if ((rc = ctx->get("op.ln_cb", (size_t)N * sizeof(uint4), (void**)&cb))) return rc;
     if ((rc = ctx->get("op.ln_stat", (size_t)M * sizeof(uint4), (void**)&stat))) return rc;
     if ((rc = ctx->get("op.ln_rstd", (size_t)M * sizeof(float), (void**)&rstd))) return rc;
-    if ((rc = fp_ln_fold((const bf16_t*)W, (const bf16_t*)g_ln, (const bf16_t*)b_ln, (const bf16_t*)bias, Wf, cb, N, K, s))) return rc;
+    FP_REQUIRE(n_scaled >= 0 && n_scaled <= N, "op_ln_linear: n_scaled %d outside [0, N]", n_scaled);
+    if ((rc = fp_ln_fold((const bf16_t*)W, (const bf16_t*)g_ln, (const bf16_t*)b_ln, (const bf16_t*)bias, Wf, cb, N, K, n_scaled, row_scale, s))) return rc;
     if ((rc = fp_row_stats((const bf16_t*)X, stat, rstd, M, K, eps, s))) return rc;
     FpGemmArgs g{};
     g.X = (const bf16_t*)X; g.ldx = K; g.W = Wf; g.ldw = K; g.C = (bf16_t*)out; g.ldc = mode == 2 ? 8 : N;
@@ -626,9 +629,9 @@ extern "C" int fp_op_gelu(const void* x, void* y, size_t n, void* stream) {
     return fp_gemm_gelu_direct((const bf16_t*)x, (bf16_t*)y, n, (hipStream_t)stream);
 }
 extern "C" int fp_op_attention(const void* QK, int ldqk, const void* Vt, void* O, int ldo, int B, int H, int n_tok,
-                               int npad, void* stream) {
+                               int npad, int q_prescaled, void* stream) {
     FP_REQUIRE(QK && Vt && O, "op_attention: null argument");
-    return fp_attention_fwd((const bf16_t*)QK, ldqk, (const bf16_t*)Vt, (bf16_t*)O, ldo, B, H, n_tok, npad,
+    return fp_attention_fwd((const bf16_t*)QK, ldqk, (const bf16_t*)Vt, (bf16_t*)O, ldo, B, H, n_tok, npad, q_prescaled != 0,
                             (hipStream_t)stream);
 }
 extern "C" int fp_op_layernorm(const void* X, void* Y, const void* g, const void* b, int rows, int D, float eps,

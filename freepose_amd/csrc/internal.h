@@ -26,8 +26,10 @@ struct fp_ctx {
 };
 
 // attention.hip
+// log2(e) / sqrt(head_dim = 64): what the softmax multiplies q k^T by before exp2 — or what the q rows of the folded qkv weights carry
+constexpr float FP_ATTN_QSCALE = 1.4426950408889634f / 8.0f;
 int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, int ldo, int B, int H, int n_tok,
-                     int npad, hipStream_t stream);
+                     int npad, bool q_prescaled, hipStream_t stream);
 // vit_misc.hip
 int fp_im2col_norm(const bf16_t* img, bf16_t* A, int B, int H, int W, int ps, int KP, hipStream_t s);
 int fp_token_init(bf16_t* X, const bf16_t* cls, const bf16_t* pos0, const bf16_t* reg, int nreg, int B, int n_tok,
@@ -42,7 +44,7 @@ int fp_l2norm_rows(const bf16_t* X, bf16_t* Y, int rows, int D, hipStream_t s);
 int fp_row_stats(const bf16_t* X, uint4* mfrag, float* rstd, int rows, int D, float eps, hipStream_t s);
 int fp_stats_finalize(const float2* part, uint4* mfrag, float* rstd, int rows, int D, float eps, hipStream_t s);
 int fp_ln_fold(const bf16_t* W, const bf16_t* gamma, const bf16_t* beta, const bf16_t* bias, bf16_t* Wf, uint4* cfrag, int N, int K,
-               hipStream_t s);
+               int n_scaled, float row_scale, hipStream_t s);
 // retrieval.hip
 int fp_cast_f32_bf16(const float* x, bf16_t* y, size_t n, hipStream_t s);
 int fp_bank_scan(const bf16_t* bank, const bf16_t* queries, uint16_t* keys, int ldk, int N, int D, int Q, hipStream_t s);

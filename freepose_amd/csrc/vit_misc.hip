@@ -358,12 +358,17 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float2* __res
 // ln_fold_kernel (once per weight load): W' = bf16(W diag(gamma)),  cs[n] = sum_k W'[n,k],  b'[n] = bias[n] + sum_k W[n,k] beta[k];
 // written as the per-feature init-MFMA record {b'h, b'h, b'l, ch, ch, cl, 0, 0} (two-piece bf16 splits).
 // One wave per output feature n; the column sum runs over the ROUNDED W' — it must cancel what the MFMAs accumulate.
+// Output features n < n_scaled additionally carry the factor row_scale (W' = bf16(W gamma row_scale), b' = (b + W beta) row_scale; one
+// rounding, like the fold itself): the ViT passes the q rows of the qkv layer with log2(e) / sqrt(head_dim), so the attention kernel's
+// S^T accumulators are base-2 exponents and its softmax spends no multiply-add per element (attention.hip, q_prescaled).
 __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ gamma,
                                                       const bf16_t* __restrict__ beta, const bf16_t* __restrict__ bias,
-                                                      bf16_t* __restrict__ Wf, uint4* __restrict__ cfrag, int N, int K) {
+                                                      bf16_t* __restrict__ Wf, uint4* __restrict__ cfrag, int N, int K, int n_scaled,
+                                                      float row_scale) {
     const int lane = threadIdx.x & 63;
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (n >= N) return;
+    const float rs = n < n_scaled ? row_scale : 1.0f;   // x 1.0f is exact: unscaled rows keep their bits
     float cs = 0.f, wb = 0.f;
     for (int k = lane * 8; k < K; k += 512) {
         const uint4 w = *(const uint4*)(W + (size_t)n * K + k), g = *(const uint4*)(gamma + k), b = *(const uint4*)(beta + k);
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__
         uint32_t o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float f0 = rbf(lo_bf(ww[e]) * lo_bf(gw[e])), f1 = rbf(hi_bf(ww[e]) * hi_bf(gw[e]));
+            const float f0 = rbf(lo_bf(ww[e]) * lo_bf(gw[e]) * rs), f1 = rbf(hi_bf(ww[e]) * hi_bf(gw[e]) * rs);
             o[e] = pack_bf2(f0, f1);
             cs += f0;
             cs += f1;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__
     cs = wave_sum(cs);
     wb = wave_sum(wb);
     if (lane == 0) {
-        const float bp = (bias ? bf2f(bias[n]) : 0.f) + wb;
+        const float bp = ((bias ? bf2f(bias[n]) : 0.f) + wb) * rs;
         const float bh = rbf(bp), bl = rbf(bp - bh), ch = rbf(cs), cl = rbf(cs - ch);
         cfrag[n] = make_uint4(pack_bf2(bh, bh), pack_bf2(bl, ch), pack_bf2(ch, cl), 0u);
     }
@@ -409,10 +414,10 @@ int fp_stats_finalize(const float2* part, uint4* ms, float* rstd, int rows, int 
 }
 
 int fp_ln_fold(const bf16_t* W, const bf16_t* gamma, const bf16_t* beta, const bf16_t* bias, bf16_t* Wf, uint4* cb, int N, int K,
-               hipStream_t s) {
+               int n_scaled, float row_scale, hipStream_t s) {
     FP_REQUIRE(W && gamma && beta && bias && Wf && cb, "ln_fold: null argument (W / LayerNorm gamma, beta / bias / outputs)");
     FP_REQUIRE(N > 0 && K % 8 == 0, "ln_fold: N=%d, K=%d (K must be a multiple of 8)", N, K);
-    hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, gamma, beta, bias, Wf, cb, N, K);
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, gamma, beta, bias, Wf, cb, N, K, n_scaled, row_scale);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -463,8 +463,9 @@ def gemm_vt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, npad: int, hea
 
 
 def ln_linear(x: torch.Tensor, g_ln: torch.Tensor, b_ln: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, mode: int = 0,
-              npad: int = 0, heads: int = 0, eps: float = 1e-6) -> torch.Tensor:
-    """LayerNorm folded into the consuming linear layer (fp_op_ln_linear): mode 0 LN(x) w^T + b, 1 gelu(.), 2 transposed V store"""
+              npad: int = 0, heads: int = 0, eps: float = 1e-6, n_scaled: int = 0, row_scale: float = 1.0) -> torch.Tensor:
+    """LayerNorm folded into the consuming linear layer (fp_op_ln_linear): mode 0 LN(x) w^T + b, 1 gelu(.), 2 transposed V store.
+    Output features below n_scaled are multiplied by row_scale inside the fold (the ViT's q rows: ATTN_QSCALE)"""
     lib = _lib.load()
     x, w, bias = _dev(x, torch.bfloat16), _dev(w, torch.bfloat16), _dev(bias, torch.bfloat16)
     g_ln, b_ln = _dev(g_ln, torch.bfloat16), _dev(b_ln, torch.bfloat16)
@@ -475,7 +476,7 @@ def ln_linear(x: torch.Tensor, g_ln: torch.Tensor, b_ln: torch.Tensor, w: torch.
     else:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     check(lib.fp_op_ln_linear(context(), ptr(x), M, K, ptr(g_ln), ptr(b_ln), float(eps), ptr(w), N, ptr(bias), int(mode), int(npad),
-                              int(heads), ptr(out), current_stream()), "fp_op_ln_linear")
+                              int(heads), int(n_scaled), float(row_scale), ptr(out), current_stream()), "fp_op_ln_linear")
     return out
 
 
@@ -496,14 +497,18 @@ def gemm_stats(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gamma: torc
     return out, stat
 
 
-def attention(qk: torch.Tensor, vt: torch.Tensor, n_tok: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """qk bf16 [B*npad, 2*H*64], vt bf16 [B,H,64,npad] -> o bf16 [B*npad, H*64]"""
+ATTN_QSCALE = 1.4426950408889634 / 8.0   # log2(e) / sqrt(64): what q_prescaled=True expects the q columns to carry
+
+
+def attention(qk: torch.Tensor, vt: torch.Tensor, n_tok: int, out: Optional[torch.Tensor] = None, q_prescaled: bool = False) -> torch.Tensor:
+    """qk bf16 [B*npad, 2*H*64], vt bf16 [B,H,64,npad] -> o bf16 [B*npad, H*64].  q_prescaled: the q columns already hold
+    q * ATTN_QSCALE (what the ViT's LayerNorm-folded qkv layer produces)"""
     lib = _lib.load()
     qk, vt = _dev(qk, torch.bfloat16), _dev(vt, torch.bfloat16)
     B, H, _, npad = vt.shape
     if out is None:
         out = torch.zeros((B * npad, H * 64), dtype=torch.bfloat16, device=qk.device)
-    check(lib.fp_op_attention(ptr(qk), 2 * H * 64, ptr(vt), ptr(out), H * 64, B, H, n_tok, npad, current_stream()),
+    check(lib.fp_op_attention(ptr(qk), 2 * H * 64, ptr(vt), ptr(out), H * 64, B, H, n_tok, npad, int(bool(q_prescaled)), current_stream()),
           "fp_op_attention")
     return out
 

@@ -213,9 +213,11 @@ int fp_op_gemm_vt(fp_ctx* ctx, const void* d_X, int ldx, const void* d_W, int ld
  * x + ls1 * attn(norm1(x)); x + ls2 * mlp(norm2(x)) — the nn.LayerNorm + nn.Linear pairs behind src/pipeline/retrieval/dino.py:18-19):
  *   LN(x) W^T + b  =  rstd (x W'^T - mean colsum(W')) + b',   W' = W diag(gamma_ln),  b' = b + W beta_ln
  * d_X bf16 [M,K] raw rows, d_g_ln / d_b_ln bf16 [K], d_W bf16 [N,K], d_bias bf16 [N].  mode 0: d_out bf16 [M,N] = linear,
- * 1: GELU(linear), 2: transposed per head like fp_op_gemm_vt (npad, heads).  Kernel-level entry used by the tests. */
+ * 1: GELU(linear), 2: transposed per head like fp_op_gemm_vt (npad, heads).  Output features n < n_scaled are multiplied by row_scale
+ * inside the fold (W' and b' of those rows; one rounding) — the ViT's q rows with log2(e) / sqrt(64); n_scaled = 0 for none.
+ * Kernel-level entry used by the tests. */
 int fp_op_ln_linear(fp_ctx* ctx, const void* d_X, int M, int K, const void* d_g_ln, const void* d_b_ln, float eps, const void* d_W,
-                    int N, const void* d_bias, int mode, int npad, int heads, void* d_out, void* stream);
+                    int N, const void* d_bias, int mode, int npad, int heads, int n_scaled, float row_scale, void* d_out, void* stream);
 /* fp_op_gemm with epilogue 2 (LayerScale + residual) that also emits the row statistics of what it wrote — the producer side of the
  * folded LayerNorm (per-64-column partial sums in the epilogue, summed in block order).  d_stat u32/f32 [M,6]: words 0-3 the 16-byte
  * init-MFMA record of the row as the consuming GEMM reads it — bf16 {sh, sl, sh, -mh, -ml, -mh, 0, 0}, sigma = sqrt(var + eps) and
@@ -226,9 +228,11 @@ int fp_op_gemm_stats(fp_ctx* ctx, const void* d_X, int ldx, const void* d_W, int
  * is filled from (hub DINOv2 Mlp act_layer = nn.GELU behind src/pipeline/retrieval/dino.py:18-19); the table-GELU GEMM is tested
  * against it on all 65 536 bf16 inputs */
 int fp_op_gelu(const void* d_x, void* d_y, size_t n, void* stream);
-/* flash attention forward on QK [B*npad, 2*H*64] (ldqk elements) + Vt [B,H,64,npad] -> O [B*npad, H*64] */
+/* flash attention forward on QK [B*npad, 2*H*64] (ldqk elements) + Vt [B,H,64,npad] -> O [B*npad, H*64].
+ * q_prescaled != 0: the q columns already hold q * log2(e) / sqrt(64) (fp_vit_forward folds that factor into the q rows of its
+ * LayerNorm-folded qkv weights — fp_op_ln_linear's n_scaled / row_scale — so the softmax needs no multiply-add per element) */
 int fp_op_attention(const void* d_QK, int ldqk, const void* d_Vt, void* d_O, int ldo, int B, int H, int n_tok,
-                    int npad, void* stream);
+                    int npad, int q_prescaled, void* stream);
 int fp_op_layernorm(const void* d_X, void* d_Y, const void* d_gamma, const void* d_beta, int rows, int D, float eps,
                     void* stream);
 

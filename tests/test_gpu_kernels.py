@@ -115,6 +115,25 @@ def test_ln_folded_linear(M, N, K, mode):
     assert _rel(out, ref) <= 1.25 * _rel(sep, ref) + 1e-4, "the folded form must not be less accurate than LN-then-GEMM"
 
 
+def test_ln_folded_linear_row_scale():
+    """rows below n_scaled carry row_scale inside the fold (the ViT's q rows: log2(e) / 8): those outputs are the unscaled ones times
+    the factor up to one bf16 rounding, the others keep their bits"""
+    from freepose_amd import ops
+    M, N, K, n_scaled = 3000, 2048, 1024, 1024
+    g = torch.Generator().manual_seed(37)
+    x = (torch.randn((M, K), generator=g) * (0.2 + 3.0 * torch.rand((M, 1), generator=g)) + 2.0 * torch.randn((M, 1), generator=g)).to(torch.bfloat16)
+    w, bias = _rand((N, K), 38, 0.05), _rand((N,), 39, 0.5)
+    g_ln, b_ln = (1.0 + 0.3 * torch.randn(K, generator=g)).to(torch.bfloat16), (0.2 * torch.randn(K, generator=g)).to(torch.bfloat16)
+    plain = ops.ln_linear(x, g_ln, b_ln, w, bias, 0)
+    scaled = ops.ln_linear(x, g_ln, b_ln, w, bias, 0, n_scaled=n_scaled, row_scale=ops.ATTN_QSCALE)
+    torch.cuda.synchronize()
+    assert torch.equal(plain[:, n_scaled:], scaled[:, n_scaled:])
+    y = torch.nn.functional.layer_norm(x.double(), (K,), g_ln.double(), b_ln.double(), 1e-6)
+    ref = (y @ w.double().t() + bias.double())[:, :n_scaled] * ops.ATTN_QSCALE
+    assert _rel(scaled[:, :n_scaled], ref) < 8e-3
+    assert _rel(scaled[:, :n_scaled], ref) <= 1.25 * _rel(plain[:, :n_scaled].double().cpu() * ops.ATTN_QSCALE, ref) + 1e-3
+
+
 @pytest.mark.parametrize("B,npad,H", [(1, 272, 6), (3, 912, 16), (52, 1376, 16)])
 def test_ln_folded_vt(B, npad, H):
     from freepose_amd import ops
@@ -222,17 +241,22 @@ def test_hand_scheduled_tier_gives_the_bits_of_the_small_tiers(M, N, K):
 # 97 (33 keys in the tail), 64 and 17 take the plain kernel; 2 tiles (70, 97, 129 -> 3) exercise the shortest loops of both
 @pytest.mark.parametrize("B,H,n_tok", [(1, 6, 261), (2, 16, 905), (2, 16, 1374), (1, 16, 64), (1, 2, 17), (1, 2, 70), (1, 2, 97),
                                        (2, 3, 129)])
-def test_attention(B, H, n_tok):
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention(B, H, n_tok, prescaled):
+    """prescaled: the q columns hold q log2(e) / 8 in bf16 (what the ViT's folded qkv layer writes) and the kernel takes base-2
+    exponents straight from the S^T accumulators; the reference is the softmax of exactly those bf16 values"""
     from freepose_amd import ops
     npad = (n_tok + 15) // 16 * 16
     D = H * 64
     qkv = _rand((B, npad, 3, H, 64), 21, 1.5)
+    if prescaled:
+        qkv[:, :, 0] = (qkv[:, :, 0].float() * ops.ATTN_QSCALE).to(torch.bfloat16)
     qk = qkv[:, :, :2].reshape(B * npad, 2 * D).contiguous()
     vt = qkv[:, :, 2].permute(0, 2, 3, 1).contiguous()  # [B,H,64,npad]
-    o = ops.attention(qk, vt, n_tok)
+    o = ops.attention(qk, vt, n_tok, q_prescaled=prescaled)
     torch.cuda.synchronize()
     q, k, v = (qkv[:, :n_tok, i].permute(0, 2, 1, 3).double() for i in range(3))  # [B,H,n,64]
-    ref = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v
+    ref = torch.softmax(q @ k.transpose(-1, -2) * (float(np.log(2.0)) if prescaled else 1.0 / 8.0), dim=-1) @ v
     ref = ref.permute(0, 2, 1, 3).reshape(B, n_tok, D)
     got = o.reshape(B, npad, D)[:, :n_tok].float().cpu()
     assert torch.isfinite(o.float()).all(), "pad rows must stay finite"
@@ -241,20 +265,28 @@ def test_attention(B, H, n_tok):
     assert (got - ref.float()).abs().max().item() < 0.05
 
 
-def test_attention_forced_rescale():
-    """spike one key against one query at a late tile so the running max jumps (online-softmax rescale path)"""
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_forced_rescale(prescaled):
+    """spike one key against one query at a late tile so the running max jumps (online-softmax rescale path); a second query whose
+    logits all sit far BELOW zero (the prescaled kernel's initial reference) must not underflow to 0 / 0"""
     from freepose_amd import ops
     B, H, n_tok = 1, 1, 300
     npad = 304
     qkv = _rand((B, npad, 3, H, 64), 31, 0.3).float()
     qkv[0, 5, 0, 0] = 4.0          # query 5
     qkv[0, 250, 1, 0] = 4.0        # key 250 (4th tile): q.k = 1024 -> /8 = 128
+    qkv[0, :, 1, 0, 1] = 6.0       # every key: component 1 = 6
+    qkv[0, 9, 0, 0, 1] = -48.0     # query 9: logits ~ -288 / 8 = -36 ... (x 64 dims of noise); prescaled: ~ -52 in log2 units
+    qkv[0, 11, 0, 0, 1] = -400.0   # query 11: logits ~ -300, far below exp2's underflow when taken against a reference of 0
     qkv = qkv.to(torch.bfloat16)
+    if prescaled:
+        qkv[:, :, 0] = (qkv[:, :, 0].float() * ops.ATTN_QSCALE).to(torch.bfloat16)
     qk = qkv[:, :, :2].reshape(B * npad, 128).contiguous()
     vt = qkv[:, :, 2].permute(0, 2, 3, 1).contiguous()
-    o = ops.attention(qk, vt, n_tok).float().cpu().reshape(npad, 64)
+    o = ops.attention(qk, vt, n_tok, q_prescaled=prescaled).float().cpu().reshape(npad, 64)
+    assert torch.isfinite(o).all()
     q, k, v = (qkv[0, :n_tok, i, 0].double() for i in range(3))
-    ref = torch.softmax(q @ k.t() / 8.0, dim=-1) @ v
+    ref = torch.softmax(q @ k.t() * (float(np.log(2.0)) if prescaled else 1.0 / 8.0), dim=-1) @ v
     assert (o[:n_tok] - ref.float()).abs().max().item() < 0.02
     assert (o[5] - v[250].float()).abs().max().item() < 0.02  # query 5 attends (almost) only to key 250
 

@@ -1,5 +1,5 @@
-"""Attention kernel flavours in one process (lab build): 0 = shipped (four waves per SIMD, just-in-time V^T fragments), 32 = the round-3 flavour (three waves
-per SIMD, whole-tile V^T prefetch).  python tools/attn_variant_ab.py [variants] [B]"""
+"""Attention kernel flavours in one process (lab build): 0 = unscaled q (four waves per SIMD, just-in-time V^T fragments, plain FMAs), 64 = q prescaled by
+log2(e)/8 (what the ViT runs), 128 = packed FMAs (shipped until round 4), 32 = the round-3 flavour (three waves per SIMD, whole-tile V^T prefetch).  python tools/attn_variant_ab.py [variants] [B]"""
 import sys
 from pathlib import Path
 
@@ -18,12 +18,22 @@ for n_tok in (1374, 905):
     qk = (torch.randn(B * npad, 2048, device="cuda") * 1.0).to(torch.bfloat16)
     vt = torch.randn(B, 16, 64, npad, device="cuda").to(torch.bfloat16)
     o = torch.empty(B * npad, 1024, device="cuda", dtype=torch.bfloat16)
+    # flavours with bit 64 expect q already multiplied by log2(e) / 8 (in the product: folded into the q rows of the qkv weights)
+    qk_pre = qk.clone()
+    qk_pre[:, :1024] = (qk[:, :1024].float() * (1.4426950408889634 / 8.0)).to(torch.bfloat16)
+    cur = {"v": 0}
+
+    def pick(v):
+        cur["v"] = max(v, 0)
+        ops.set_option("attn_variant", max(v, 0))
+
     outs = {}
     for v in variants:
-        ops.set_option("attn_variant", v)
-        outs[v] = ops.attention(qk, vt, n_tok).float().cpu()
+        pick(v)
+        outs[v] = ops.attention(qk_pre if v & 64 else qk, vt, n_tok, q_prescaled=bool(v & 64)).float().cpu()
     ops.set_option("attn_variant", -1)
     for v in variants[1:]:
-        print(f"n_tok={n_tok}: variant {v} vs {variants[0]}: max |diff| {(outs[v] - outs[variants[0]]).abs().max().item():.3e}")
-    ab(f"attention B={B} n={n_tok}", variants, lambda v: ops.set_option("attn_variant", max(v, 0)),
-       lambda: ops.attention(qk, vt, n_tok, out=o), 4.0 * B * n_tok * n_tok * 1024, rounds=8)
+        d = outs[v] - outs[variants[0]]
+        print(f"n_tok={n_tok}: variant {v} vs {variants[0]}: max |diff| {d.abs().max().item():.3e}, relative L2 {(d.norm() / outs[variants[0]].norm()).item():.3e}")
+    ab(f"attention B={B} n={n_tok}", variants, pick,
+       lambda: ops.attention(qk_pre if cur["v"] & 64 else qk, vt, n_tok, out=o, q_prescaled=bool(cur["v"] & 64)), 4.0 * B * n_tok * n_tok * 1024, rounds=8)

@@ -29,7 +29,8 @@
 #endif
 #define FP_GEMM_DEFAULT_VARIANT 238   // 2|4|8|32|64|128 (profiles/r02_ab.md: +4..6 % over 110 on every ViT shape)
 #define FP_GEMM_VAR_BIG (4 | 32 | 64 | 128)   // 16-wave 256x256: table GELU, persistent walk, streaming epilogue I/O, split DMA issue
-#define FP_GEMM_VAR_SMALL 6                   // 128x128 (4 waves) and 64x64 (1 wave): pipelined fragment reads, table GELU
+#define FP_GEMM_VAR_SMALL 6                   // 128x128 (4 waves): pipelined fragment reads, table GELU
+#define FP_GEMM_VAR_TINY (6 | 1024)           // 64x64 (2 waves, 1 for the transposed store): the same with a 4-deep K-tile ring
 
 namespace {
 
@@ -244,6 +245,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     init_acc(m0, n0);
 
     const int nkt = p.K / BK;
+    constexpr int NS = ((VAR & 2) && (VAR & 1024)) ? 4 : 2;   // K-tile ring depth (software-pipelined loop only)
+    int last_slot = (nkt - 1) & 1;                            // ring slot the last K step read (RELOC slabs live there)
     auto load_frags = [&](const char* sb, int kk, bf16x8_t (&fr)[TR], bf16x8_t (&fc)[TC]) {
         const int slotR = (((kk << 2) | lg) ^ keyR) << 4;
         const int slotC = (((kk << 2) | lg) ^ keyC) << 4;
@@ -338,10 +341,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         // ---- software-pipelined loop: fragments of k-step j+1 are read while k-step j's MFMAs run; the single
         // barrier of a tile sits at its SECOND k-step, where every wave has finished reading the tile, so the DMA
         // of tile t+2 is issued half a tile earlier and the next tile's first fragments are already in flight.
+        // Ring of NS K-tile buffers (2, or 4 for the 64x64 tier — VAR bit 1024): NS - 1 stages stay in flight.  A launch of the small
+        // tiers is a handful of workgroups per CU, each walking K alone: with two buffers every K step waits for one fresh memory
+        // round trip (weights come from HBM: 0.7 us per step measured on a single-crop ViT-L forward), with four the round trips
+        // overlap.  Same K order, same MFMA sequence: the bits do not change.
         bf16x8_t frA[TR], fcA[TC], frB[TR], fcB[TC];
-        stage(0, 0);
-        if (nkt > 1) stage(1, 1);
-        if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IX + IW) : "memory");
+        constexpr int IPS = IX + IW;   // LDS-DMA instructions per stage and wave
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (s < nkt) stage(s, s);
+        // stage 0 has landed when at most the later stages' instructions are outstanding (vmcnt counts in issue order)
+        if (nkt >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * IPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -355,24 +365,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
             for (int f = 0; f < TC; ++f) asm volatile("" : "+v"(fc[f]));
         };
         load_frags(smem, 0, frA, fcA);
+        int cur = 0;   // ring slot of stage kt
         for (int kt = 0; kt < nkt; ++kt) {
-            const char* sb = smem + (kt & 1) * STAGE;
+            const char* sb = smem + cur * STAGE;
+            const int nxt = cur + 1 == NS ? 0 : cur + 1;
             settle(frA, fcA);
             load_frags(sb, 1, frB, fcB);
             mma_block(frA, fcA);
             if (kt + 1 < nkt) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                // stage kt+1 must have landed; stages kt+2 .. kt+NS-1 may stay in flight (near the end of K fewer were issued: drain)
+                if (NS > 2 && kt + NS - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * IPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (kt + 2 < nkt) stage(kt & 1, kt + 2);
+                if (kt + NS < nkt) stage(cur, kt + NS);   // every wave is done reading stage kt: its slot takes stage kt + NS
                 settle(frB, fcB);
-                load_frags(smem + ((kt + 1) & 1) * STAGE, 0, frA, fcA);
+                load_frags(smem + nxt * STAGE, 0, frA, fcA);
             }
             mma_block(frB, fcB);
+            cur = nxt;
         }
+        last_slot = (nkt - 1) % NS;
     }
 
-    if constexpr (RELOC) epi_stage = reloc_stage((nkt - 1) & 1);
+    if constexpr (RELOC) epi_stage = reloc_stage(last_slot);
     fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage, smem_raw);
 }
 
@@ -393,7 +409,8 @@ template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr bool LUT = FpEpiTraits<EPI>::GELU && (VAR & 4) != 0;
-    constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + 2 * STAGE;   // dynamic part; the slabs are static (see the kernel)
+    constexpr int NS = ((VAR & 2) && (VAR & 1024)) ? 4 : 2;
+    constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + NS * STAGE;   // dynamic part; the slabs are static (see the kernel)
     static_assert(SMEM <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
     FP_DYN_LDS_ONCE(kern, SMEM);
@@ -537,13 +554,16 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // (ViT-L B = 1 @518^2: see profiles/r04_ab.md §4).  The transposed V store needs 64-token wave tiles and keeps one wave.
     if constexpr (FpEpiTraits<EPI>::TRANS)
         return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
-             : tiny ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream)
+             : tiny ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_TINY>(a, stream)
                     : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);
-    else
+    else {
+#ifdef FP_LAB
+        if (!big && tiny && (var & 131072)) return launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream);   // lab A/B: two K-tile buffers
+#endif
         return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
-             : tiny ? ((var & 131072) ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream)      // bit 131072 (lab A/B only): one wave
-                                      : launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream))
+             : tiny ? launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_TINY>(a, stream)
                     : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);
+    }
 }
 
 }  // namespace

@@ -1,5 +1,6 @@
-"""Small-batch ViT-L forwards (B = 1 .. 8) under the GEMM tile tiers (lab build): default dispatch, 128x128 kept for small grids
-(bit 2048), one-wave 64x64 tiles for everything below the big tier (bit 32768).  python tools/small_batch_ab.py [res]"""
+"""Small-batch ViT-L forwards under the GEMM tile tiers (lab build): default dispatch (64x64 tier on a 4-deep K-tile ring), the 64x64
+tier on two K-tile buffers (bit 131072: the form shipped until round 4), 64x64 tiles for everything below the big tier (bit 32768),
+128x128 kept for small grids (bit 2048).  python tools/small_batch_ab.py [res] [B,B,...]"""
 import statistics
 import sys
 from pathlib import Path
@@ -13,10 +14,10 @@ from freepose_amd import ops  # noqa: E402
 
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 518
 vit = ops.ViT("dinov2_vitl14_reg", seed=0)
-for B in (2, 3, 4, 5, 6, 8, 10, 12, 16, 21):
+for B in ([int(b) for b in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 2, 3, 4, 5, 6, 8, 12, 21)):
     x = torch.rand((B, 3, res, res), device="cuda").to(torch.bfloat16)
     row = []
-    for name, var in (("default", -1), ("tiny forced below the big tier", 238 | 32768), ("no tiny", 238 | 2048)):
+    for name, var in (("default", -1), ("two K-tile buffers", 238 | 131072), ("64x64 forced below the big tier", 238 | 32768), ("no 64x64", 238 | 2048)):
         ops.set_option("gemm_variant", var)
         for _ in range(2):
             vit(x, layer=22, feature_type="patch")

@@ -31,6 +31,7 @@ extern "C" int fp_lab_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_dbg")) g_opts[FP_OPT_GEMM_DBG] = value;   // measurement hooks with wrong numerics
     else if (!strcmp(name, "attn_variant")) g_opts[FP_OPT_ATTN_VARIANT] = value;
     else if (!strcmp(name, "topk_select")) g_opts[FP_OPT_TOPK_SELECT] = value;
+    else if (!strcmp(name, "gemm_ring")) g_opts[FP_OPT_GEMM_RING] = value;   // cap on the 64x64 tier's K-tile ring depth
     else { fp_set_error("lab_set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
     return FP_OK;
 }

@@ -58,6 +58,7 @@ struct FpGemmArgs {
     float2* stat_part;
     int no_split;  // 1: never split this launch by rows between the tile tiers (set on the parts of a split; callers may set it too)
     int stat_ld;   // row stride of stat_part (= the whole problem's M; a row-split launch covers only part of it).  0 = M
+    int ring;      // K-tile ring depth of the 64x64 tier (2 .. 8 buffers; chosen by the launcher from the grid size, gemm_bf16.hip)
 #ifdef FP_LAB
     int dbg;   // LAB BUILD ONLY (libfreepose_hip_lab.so, tools/): measurement bits with wrong numerics — 2 = LN-folded kernels start from
                // zero accumulators, 8 = persistent kernels skip the epilogue, 16 = epilogue without its stores, 32 = staggered start

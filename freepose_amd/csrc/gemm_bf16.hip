@@ -30,7 +30,7 @@
 #define FP_GEMM_DEFAULT_VARIANT 238   // 2|4|8|32|64|128 (profiles/r02_ab.md: +4..6 % over 110 on every ViT shape)
 #define FP_GEMM_VAR_BIG (4 | 32 | 64 | 128)   // 16-wave 256x256: table GELU, persistent walk, streaming epilogue I/O, split DMA issue
 #define FP_GEMM_VAR_SMALL 6                   // 128x128 (4 waves): pipelined fragment reads, table GELU
-#define FP_GEMM_VAR_TINY (6 | 1024)           // 64x64 (2 waves, 1 for the transposed store): the same with a 4-deep K-tile ring
+#define FP_GEMM_VAR_TINY (6 | 1024)           // 64x64 (2 waves, 1 for the transposed store): the same on a K-tile ring of run-time depth
 
 namespace {
 
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     init_acc(m0, n0);
 
     const int nkt = p.K / BK;
-    constexpr int NS = ((VAR & 2) && (VAR & 1024)) ? 4 : 2;   // K-tile ring depth (software-pipelined loop only)
+    constexpr bool RING = (VAR & 2) && (VAR & 1024);          // K-tile ring of run-time depth (software-pipelined loop, 64x64 tier)
     int last_slot = (nkt - 1) & 1;                            // ring slot the last K step read (RELOC slabs live there)
     auto load_frags = [&](const char* sb, int kk, bf16x8_t (&fr)[TR], bf16x8_t (&fc)[TC]) {
         const int slotR = (((kk << 2) | lg) ^ keyR) << 4;
@@ -341,17 +341,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         // ---- software-pipelined loop: fragments of k-step j+1 are read while k-step j's MFMAs run; the single
         // barrier of a tile sits at its SECOND k-step, where every wave has finished reading the tile, so the DMA
         // of tile t+2 is issued half a tile earlier and the next tile's first fragments are already in flight.
-        // Ring of NS K-tile buffers (2, or 4 for the 64x64 tier — VAR bit 1024): NS - 1 stages stay in flight.  A launch of the small
-        // tiers is a handful of workgroups per CU, each walking K alone: with two buffers every K step waits for one fresh memory
-        // round trip (weights come from HBM: 0.7 us per step measured on a single-crop ViT-L forward), with four the round trips
-        // overlap.  Same K order, same MFMA sequence: the bits do not change.
+        // Ring of NS K-tile buffers, NS - 1 stages in flight: 2 for the 128x128 tier, 2 .. 8 (p.ring) for the 64x64 tier.  A launch of
+        // the small tiers is a few workgroups per CU, each walking K alone: with two buffers every K step waits for one fresh memory
+        // round trip (weights come from HBM: 0.7 us per step measured on a single-crop ViT-L forward), with a deeper ring the round
+        // trips overlap.  The launcher takes the deepest ring that still keeps the whole grid resident (LDS per workgroup = NS x 16
+        // KiB).  Same K order, same MFMA sequence: the bits do not depend on the depth.
         bf16x8_t frA[TR], fcA[TC], frB[TR], fcB[TC];
         constexpr int IPS = IX + IW;   // LDS-DMA instructions per stage and wave
-#pragma unroll
+        const int NS = RING ? p.ring : 2;
+        // "at most n later stages' instructions outstanding" (vmcnt counts in issue order and takes an immediate); LG: also lgkmcnt(0)
+        auto wait_stages = [&](int n, auto lg_c) {
+            constexpr bool LG = decltype(lg_c)::value;
+#define FP_WAIT_CASE(N)                                                                                          \
+    case N:                                                                                                      \
+        if constexpr (LG) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((N) * IPS <= 63 ? (N) * IPS : 63) : "memory");   \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N) * IPS <= 63 ? (N) * IPS : 63) : "memory");              \
+        break;
+            if constexpr (!RING) {
+                if constexpr (LG) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                switch (n) {
+                    FP_WAIT_CASE(1) FP_WAIT_CASE(2) FP_WAIT_CASE(3) FP_WAIT_CASE(4) FP_WAIT_CASE(5) FP_WAIT_CASE(6) FP_WAIT_CASE(7)
+                    default:
+                        if constexpr (LG) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+#undef FP_WAIT_CASE
+        };
         for (int s = 0; s < NS; ++s)
             if (s < nkt) stage(s, s);
-        // stage 0 has landed when at most the later stages' instructions are outstanding (vmcnt counts in issue order)
-        if (nkt >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * IPS) : "memory");
+        // stage 0 has landed when at most the later stages' instructions are outstanding
+        if (RING) wait_stages(nkt >= NS ? NS - 1 : 0, std::false_type{});
+        else if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -374,8 +397,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
             mma_block(frA, fcA);
             if (kt + 1 < nkt) {
                 // stage kt+1 must have landed; stages kt+2 .. kt+NS-1 may stay in flight (near the end of K fewer were issued: drain)
-                if (NS > 2 && kt + NS - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * IPS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                wait_stages(kt + NS - 1 < nkt ? NS - 2 : 0, std::true_type{});
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (kt + NS < nkt) stage(cur, kt + NS);   // every wave is done reading stage kt: its slot takes stage kt + NS
@@ -409,17 +431,38 @@ template <int BM, int BN, int WM, int WN, int EPI, int VAR>
 int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr bool LUT = FpEpiTraits<EPI>::GELU && (VAR & 4) != 0;
-    constexpr int NS = ((VAR & 2) && (VAR & 1024)) ? 4 : 2;
-    constexpr int SMEM = (LUT ? fp_gemm::GELU_TAB_BYTES : 0) + NS * STAGE;   // dynamic part; the slabs are static (see the kernel)
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    constexpr bool RING = (VAR & 2) && (VAR & 1024);
+    constexpr int TABB = LUT ? fp_gemm::GELU_TAB_BYTES : 0;
+    constexpr int SMEM_MAX = TABB + (RING ? 8 : 2) * STAGE;   // dynamic part; the slabs are static (see the kernel)
+    static_assert(SMEM_MAX + (LUT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES) <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
-    FP_DYN_LDS_ONCE(kern, SMEM);
+    FP_DYN_LDS_ONCE(kern, SMEM_MAX);
     int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    FpGemmArgs ar = a;
+    ar.ring = 2;
+    if constexpr (RING) {
+        // the deepest ring (4 / 3 / 2 K-tile buffers) with which the whole grid is still resident at once; no deeper than K.  Deeper
+        // rings were measured and bring nothing (profiles/r04_ab.md §3: caps 8 / 6 / 4 / 3 within 1 %, 2 buffers 20-28 % slower at B = 1)
+        static int ncu_r = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        constexpr int IPS = (BM + BN) / 8 / (WM * WN);
+        constexpr int FIXED = TABB + (LUT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES);
+        const int nkt = a.K / BK;
+        int cap = 4;
+#ifdef FP_LAB
+        cap = fp_opt_get(FP_OPT_GEMM_RING, 4);   // lab: up to 8
+#endif
+        for (const int r : {8, 6, 4, 3}) {
+            if ((r - 1) * IPS > 63 || r > nkt || r > cap) continue;
+            const long resident = (long)ncu_r * ((160 * 1024) / (FIXED + r * STAGE));
+            if (tiles <= resident) { ar.ring = r; break; }
+        }
+    }
+    const int SMEM = TABB + ar.ring * STAGE;
     if constexpr ((VAR & 32) != 0) {   // one resident workgroup per CU (128 KiB of LDS each)
         static int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n & ~7; }();
         tiles = tiles < ncu ? tiles : ncu;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), SMEM, stream, a);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), SMEM, stream, ar);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

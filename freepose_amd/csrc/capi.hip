@@ -380,13 +380,16 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
             ProfScope ps(v, s, &v->ms_other);
             if (!lnf) { if ((rc = fp_layernorm(X, Y, w.n1w, w.n1b, Mi, D, a.ln_eps, 0, 0, 0, s))) return rc; }
             else if (i == 0) { if ((rc = fp_row_stats(X, stat, rstd, Mi, D, a.ln_eps, s))) return rc; }     // rows from patch-embed + token init
-            else { if ((rc = fp_stats_finalize(part, stat, rstd, Mi, D, a.ln_eps, s))) return rc; }         // partials of the previous fc2
+            // i > 0: the previous fc2 left partial sums.  On the small tile tiers the qk launch below finalises them in its prologue (and the
+            // V^T launch reads what it wrote); launches that reach the big tier get them from the finalisation kernel
+            else if (!fp_gemm_fuses_ln_part(Mi, (int)(2 * D))) { if ((rc = fp_stats_finalize(part, stat, rstd, Mi, D, a.ln_eps, s))) return rc; }
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
             FpGemmArgs g{}; g.no_split = nosplit;
             g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.qkvw : w.qkvw; g.ldw = D; g.C = QK; g.ldc = 2 * D; g.bias = w.qkvb;
             g.M = Mi; g.N = 2 * D; g.K = D; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = f.qkv_cb;
+            if (lnf && i > 0 && fp_gemm_fuses_ln_part(Mi, (int)(2 * D))) { g.ln_part = part; g.ln_part_ld = Mi; g.ln_part_nb = (int)(D / 64); g.ln_eps = a.ln_eps; g.ln_inv_d = 1.0f / (float)D; }
             if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_BIAS : FP_EPI_BIAS, s))) return rc;
             FpGemmArgs gv{}; gv.no_split = nosplit;
             gv.X = lnf ? X : Y; gv.ldx = D; gv.W = (lnf ? f.qkvw : w.qkvw) + (size_t)2 * D * D; gv.ldw = D; gv.C = Vt; gv.ldc = 8;
@@ -410,13 +413,15 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         {
             ProfScope ps(v, s, &v->ms_other);
             if (!lnf) { if ((rc = fp_layernorm(X, Y, w.n2w, w.n2b, Mi, D, a.ln_eps, 0, 0, 0, s))) return rc; }
-            else { if ((rc = fp_stats_finalize(part, stat, rstd, Mi, D, a.ln_eps, s))) return rc; }
+            else if (!fp_gemm_fuses_ln_part(Mi, (int)a.mlp_dim)) { if ((rc = fp_stats_finalize(part, stat, rstd, Mi, D, a.ln_eps, s))) return rc; }
+            // (small tiers: the fc1 launch below finalises proj's partial sums in its prologue)
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
             FpGemmArgs g{}; g.no_split = nosplit;
             g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.fc1w : w.fc1w; g.ldw = D; g.C = H1; g.ldc = a.mlp_dim; g.bias = w.fc1b;
             g.M = Mi; g.N = a.mlp_dim; g.K = D; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = f.fc1_cb;
+            if (lnf && fp_gemm_fuses_ln_part(Mi, (int)a.mlp_dim)) { g.ln_part = part; g.ln_part_ld = Mi; g.ln_part_nb = (int)(D / 64); g.ln_eps = a.ln_eps; g.ln_inv_d = 1.0f / (float)D; }
             if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_GELU : FP_EPI_BIAS_GELU, s))) return rc;
             FpGemmArgs g2{}; g2.no_split = nosplit;
             g2.X = H1; g2.ldx = a.mlp_dim; g2.W = w.fc2w; g2.ldw = a.mlp_dim; g2.C = X; g2.ldc = D; g2.bias = w.fc2b;

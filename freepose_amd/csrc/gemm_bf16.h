@@ -54,6 +54,11 @@ struct FpGemmArgs {
     const uint4* ln_mfrag;
     const float* ln_rstd;
     const uint4* ln_cfrag;
+    // optional (row-major LN epilogues): the producing GEMM's partial row statistics [D/64][ln_part_ld] (sum, sum of squares).  When set,
+    // the row records are not there yet: a launch that runs on the small tile tiers finalises the rows of each tile in the kernel's
+    // prologue (and writes ln_mfrag / ln_rstd back for later consumers of the same rows — every workgroup of a row block writes the same
+    // bits); a launch that takes the big tier runs fp_stats_finalize first.  Saves a 5 us dependent kernel per LayerNorm at small batch.
+    const float2* ln_part; int ln_part_ld; int ln_part_nb; float ln_eps; float ln_inv_d;   // nb = D / 64 blocks, inv_d = 1 / D (host-rounded)
     // FP_EPI_LS_RES_STATS: partial row statistics [N/64][M] (sum, sum of squares), N % 64 == 0
     float2* stat_part;
     int no_split;  // 1: never split this launch by rows between the tile tiers (set on the parts of a split; callers may set it too)
@@ -70,6 +75,28 @@ struct FpGemmArgs {
 #else
 #define FP_GEMM_DBG_BIT(p, bit) 0
 #endif
+
+// (sigma, -mean) of one row as the init-MFMA operand record {sh, sl, sh, -mh, -ml, -mh, 0, 0} (two-piece bf16 splits), and 1 / sigma, from the
+// per-64-column partial sums of the producing epilogue added in block order: the ONE definition used by stats_finalize_kernel
+// (vit_misc.hip) and by the small-tier GEMM prologue (gemm_bf16.hip) — same bits wherever a row is finalised.
+__device__ __forceinline__ uint4 fp_ln_row_record(float mean, float sigma) {
+    const float sh = rbf(sigma), sl = rbf(sigma - sh), nm = -mean, mh = rbf(nm), ml = rbf(nm - mh);
+    return make_uint4(pack_bf2(sh, sl), pack_bf2(sh, mh), pack_bf2(ml, mh), 0u);
+}
+__device__ __forceinline__ void fp_ln_finalize_row(const float2* __restrict__ part, size_t ld, int nb, int r, float inv_d, float eps, uint4& rec,
+                                                   float& rstd) {
+    float s = 0.f, q = 0.f;
+    for (int b = 0; b < nb; ++b) {
+        const float2 p = part[(size_t)b * ld + r];
+        s += p.x;
+        q += p.y;
+    }
+    const float mean = s * inv_d;
+    const float var = fmaxf(__fmaf_rn(-mean, mean, q * inv_d), 0.f);
+    const float sigma = __fsqrt_rn(var + eps);
+    rec = fp_ln_row_record(mean, sigma);
+    rstd = __builtin_amdgcn_rcpf(sigma);
+}
 
 // Tile order shared by the GEMM kernels.  blockIdx -> logical id (XCD-contiguous, bijective) -> (tile_m, tile_n) in
 // column STRIPS of 4 n-tiles swept m-major: the 32 tiles an XCD runs concurrently then cover 8 X row-panels x 4 W
@@ -95,6 +122,9 @@ __device__ __forceinline__ void fp_gemm_tile(int block, int nblocks, int tiles_m
 
 // Launch on `stream`. Returns FP_OK / error code (fp_last_error() has the text).
 int fp_gemm_bf16(const FpGemmArgs& a, int epi, hipStream_t stream);
+// true when a row-major LN-folded launch of this size stays on the small tile tiers, i.e. finalises FpGemmArgs::ln_part in its prologue
+// (otherwise fp_gemm_bf16 runs fp_stats_finalize first; callers that account for that kernel separately call it themselves)
+bool fp_gemm_fuses_ln_part(int M, int N);
 // builds (once per device) and returns the bf16 -> bf16 GELU table the fc1 epilogue gathers from
 int fp_gemm_gelu_table(const uint16_t** out);
 // the hand-scheduled 256x256 kernel (gemm_asm.hip): the big-tile tier of the row-major epilogues

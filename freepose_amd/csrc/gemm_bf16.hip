@@ -17,6 +17,7 @@
 // src/pipeline/retrieval/dino.py:16-23 (patch_embed.proj, attn.qkv, attn.proj, mlp.fc1, mlp.fc2).
 #include "gemm_bf16.h"
 #include "gemm_epilogue.h"
+#include "internal.h"
 
 #include <mutex>
 
@@ -242,11 +243,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         }
     };
     auto zero_acc = [&]() { init_acc(m0, n0); };   // (name kept: every loop form re-arms the accumulators through it)
-    init_acc(m0, n0);
-
     const int nkt = p.K / BK;
     constexpr bool RING = (VAR & 2) && (VAR & 1024);          // K-tile ring of run-time depth (software-pipelined loop, 64x64 tier)
     int last_slot = (nkt - 1) & 1;                            // ring slot the last K step read (RELOC slabs live there)
+    const int NS = RING ? p.ring : 2;                         // ring depth of the software-pipelined loop
+    if constexpr ((VAR & 2) != 0 && !PERSIST) {
+        // the software-pipelined loop's first NS K tiles go out before anything else: they stream in while the row statistics are
+        // finalised and the accumulators initialised below
+        for (int s = 0; s < NS; ++s)
+            if (s < nkt) stage(s, s);
+    }
+    if constexpr (LNF && !TRANS && !PERSIST) {
+        // Small tiers, row statistics not finalised yet (FpGemmArgs::ln_part): this tile's rows are finalised here — the arithmetic of
+        // stats_finalize_kernel, shared through fp_ln_finalize_row — and written where init_acc and the epilogue (and the V^T launch
+        // that follows on the stream) read them.  Every workgroup of a row block writes the same bits.
+        if (p.ln_part) {
+            for (int r = tid; r < BM; r += NW * 64) {
+                const int row = m0 + r;
+                if (row < p.M) {
+                    uint4 rec;
+                    float rstd;
+                    fp_ln_finalize_row(p.ln_part, (size_t)p.ln_part_ld, p.ln_part_nb, row, p.ln_inv_d, p.ln_eps, rec, rstd);
+                    const_cast<uint4*>(p.ln_mfrag)[row] = rec;
+                    const_cast<float*>(p.ln_rstd)[row] = rstd;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+    init_acc(m0, n0);
+
     auto load_frags = [&](const char* sb, int kk, bf16x8_t (&fr)[TR], bf16x8_t (&fc)[TC]) {
         const int slotR = (((kk << 2) | lg) ^ keyR) << 4;
         const int slotC = (((kk << 2) | lg) ^ keyC) << 4;
@@ -348,7 +375,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         // KiB).  Same K order, same MFMA sequence: the bits do not depend on the depth.
         bf16x8_t frA[TR], fcA[TC], frB[TR], fcB[TC];
         constexpr int IPS = IX + IW;   // LDS-DMA instructions per stage and wave
-        const int NS = RING ? p.ring : 2;
         // "at most n later stages' instructions outstanding" (vmcnt counts in issue order and takes an immediate); LG: also lgkmcnt(0)
         auto wait_stages = [&](int n, auto lg_c) {
             constexpr bool LG = decltype(lg_c)::value;
@@ -370,9 +396,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
             }
 #undef FP_WAIT_CASE
         };
-        for (int s = 0; s < NS; ++s)
-            if (s < nkt) stage(s, s);
-        // stage 0 has landed when at most the later stages' instructions are outstanding
+        // (the first NS stages were issued at the top of the kernel) stage 0 has landed when at most the later stages' instructions are
+        // outstanding; any vector-memory operation issued since (row statistics, init records) only makes this wait stricter
         if (RING) wait_stages(nkt >= NS ? NS - 1 : 0, std::false_type{});
         else if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -488,6 +513,19 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // (fc2), 0.046 vs 0.063 (V) at M = 19 152, while the big tile wins whenever >= ~75 % of its rounds are filled.
     static int ncu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 8 ? (n & ~7) : 256; }();
     const long rounds_big = (tiles_big + ncu - 1) / ncu;
+    if constexpr (FpEpiTraits<EPI>::LN) {
+        // row statistics handed over as partial sums: the small tiers finalise them in the kernel prologue; anything that may touch the
+        // big tier (or is a transposed store) gets them from the finalisation kernel first
+        if (a.ln_part && (FpEpiTraits<EPI>::TRANS || !fp_gemm_fuses_ln_part(a.M, a.N))) {
+            FP_REQUIRE(a.ln_part_nb > 0 && a.ln_part_ld >= a.M, "gemm: ln_part needs ln_part_nb and ln_part_ld");
+            const int rc = fp_stats_finalize(a.ln_part, const_cast<uint4*>(a.ln_mfrag), const_cast<float*>(a.ln_rstd), a.M, a.ln_part_nb * 64,
+                                             a.ln_eps, stream, a.ln_part_ld);
+            if (rc != FP_OK) return rc;
+            FpGemmArgs b = a;
+            b.ln_part = nullptr;
+            return launch_epi<EPI>(b, stream);
+        }
+    }
     const bool filled = tiles_big * 4 >= rounds_big * ncu * 3;          // >= 75 % of the big-tile rounds are real work
     bool big = tiles_big >= 192 && filled && !(var & 256);              // bit 256 (A/B only): force the 128x128 kernel
     // ROW SPLIT (round 3): whole rounds of the resident grid on 256x256 tiles, the remaining rows on the finer tiers — for the launch
@@ -516,6 +554,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
                 if (a.resid) a2.resid = a.resid + m1 * a.ldr;
                 if (a.ln_mfrag) a2.ln_mfrag = a.ln_mfrag + m1;
                 if (a.ln_rstd) a2.ln_rstd = a.ln_rstd + m1;
+                if (a.ln_part) a2.ln_part = a.ln_part + m1;
                 if (a.stat_part) a2.stat_part = a.stat_part + m1;
                 const int rc = launch_epi<EPI>(a1, stream);              // whole rounds: takes the 256x256 tier below
                 if (rc != FP_OK) return rc;
@@ -546,6 +585,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
                 if (a.resid) a2.resid = a.resid + m1 * a.ldr;
                 if (a.ln_mfrag) a2.ln_mfrag = a.ln_mfrag + m1;
                 if (a.ln_rstd) a2.ln_rstd = a.ln_rstd + m1;
+                if (a.ln_part) a2.ln_part = a.ln_part + m1;
                 if (a.stat_part) a2.stat_part = a.stat_part + m1;
                 const int rc = launch_epi<EPI>(a1, stream);
                 if (rc != FP_OK) return rc;
@@ -610,6 +650,8 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+bool fp_gemm_fuses_ln_part(int M, int N) { return (long)cdiv(M, 256) * cdiv(N, 256) < 192; }
 
 // Per-device GELU table (16 KiB), built on first use; fp_ctx_create calls this so that no launch path ever allocates.
 int fp_gemm_gelu_table(const uint16_t** out) {

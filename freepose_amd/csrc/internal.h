@@ -42,7 +42,7 @@ int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* ou
 int fp_l2norm_rows(const bf16_t* X, bf16_t* Y, int rows, int D, hipStream_t s);
 // LayerNorm folded into the consuming GEMM (gemm_bf16.h FP_EPI_LN_*): row statistics and the one-off weight fold
 int fp_row_stats(const bf16_t* X, uint4* mfrag, float* rstd, int rows, int D, float eps, hipStream_t s);
-int fp_stats_finalize(const float2* part, uint4* mfrag, float* rstd, int rows, int D, float eps, hipStream_t s);
+int fp_stats_finalize(const float2* part, uint4* mfrag, float* rstd, int rows, int D, float eps, hipStream_t s, int part_ld = 0);   // part_ld: row stride of part (0 = rows)
 int fp_ln_fold(const bf16_t* W, const bf16_t* gamma, const bf16_t* beta, const bf16_t* bias, bf16_t* Wf, uint4* cfrag, int N, int K,
                int n_scaled, float row_scale, hipStream_t s);
 // retrieval.hip

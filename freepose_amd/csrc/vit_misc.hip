@@ -8,6 +8,7 @@
 //   ffa           : mask any-pool 14x14 -> masked mean over patches -> optional L2 normalise
 //                   (scripts/extract_retrieval_features.py:51-57, extract_proposals_ground.py:129-134)
 #include "internal.h"
+#include "gemm_bf16.h"
 
 namespace {
 
@@ -293,10 +294,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_vec_kernel(const bf16_t* X, b
 // and -mean as two-piece bf16 splits (x ~ xh + xl, xh = bf16(x), xl = bf16(x - xh): 16 mantissa bits) — and rstd = 1 / sigma (fp32).
 // row_stats_kernel: statistics straight from the rows (block 0, whose input comes from the patch-embed scatter + token init);
 // two-pass variance like layernorm_kernel.  One wave per row.
-__device__ __forceinline__ uint4 ln_row_record(float mean, float sigma) {
-    const float sh = rbf(sigma), sl = rbf(sigma - sh), nm = -mean, mh = rbf(nm), ml = rbf(nm - mh);
-    return make_uint4(pack_bf2(sh, sl), pack_bf2(sh, mh), pack_bf2(ml, mh), 0u);
-}
+__device__ __forceinline__ uint4 ln_row_record(float mean, float sigma) { return fp_ln_row_record(mean, sigma); }   // gemm_bf16.h
 template <int MAXC>
 __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ X, uint4* __restrict__ mfrag, float* __restrict__ rstd_out,
                                                         int rows, int D, float eps) {
@@ -339,20 +337,14 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict
 // stats_finalize_kernel: (mean, rstd) from the per-64-column partial sums the producing GEMM's epilogue wrote
 // (part[nb][m] = (sum x, sum x^2) of row m over columns 64 nb .. 64 nb + 63; FP_EPI_LS_RES_STATS), added in block order.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float2* __restrict__ part, uint4* __restrict__ mfrag,
-                                                             float* __restrict__ rstd_out, int rows, int nb, float inv_d, float eps) {
+                                                             float* __restrict__ rstd_out, int rows, int nb, float inv_d, float eps, int part_ld) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    float s = 0.f, q = 0.f;
-    for (int b = 0; b < nb; ++b) {
-        const float2 p = part[(size_t)b * rows + r];
-        s += p.x;
-        q += p.y;
-    }
-    const float mean = s * inv_d;
-    const float var = fmaxf(__fmaf_rn(-mean, mean, q * inv_d), 0.f);
-    const float sigma = __fsqrt_rn(var + eps);
-    mfrag[r] = ln_row_record(mean, sigma);
-    rstd_out[r] = __builtin_amdgcn_rcpf(sigma);
+    uint4 rec;
+    float rstd;
+    fp_ln_finalize_row(part, (size_t)part_ld, nb, r, inv_d, eps, rec, rstd);
+    mfrag[r] = rec;
+    rstd_out[r] = rstd;
 }
 
 // ln_fold_kernel (once per weight load): W' = bf16(W diag(gamma)),  cs[n] = sum_k W'[n,k],  b'[n] = bias[n] + sum_k W[n,k] beta[k];
@@ -406,9 +398,9 @@ int fp_row_stats(const bf16_t* X, uint4* ms, float* rstd, int rows, int D, float
     return FP_OK;
 }
 
-int fp_stats_finalize(const float2* part, uint4* ms, float* rstd, int rows, int D, float eps, hipStream_t s) {
+int fp_stats_finalize(const float2* part, uint4* ms, float* rstd, int rows, int D, float eps, hipStream_t s, int part_ld) {
     FP_REQUIRE(D % 64 == 0, "stats_finalize: D=%d must be a multiple of 64", D);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, part, ms, rstd, rows, D / 64, 1.0f / (float)D, eps);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, part, ms, rstd, rows, D / 64, 1.0f / (float)D, eps, part_ld > 0 ? part_ld : rows);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

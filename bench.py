@@ -582,7 +582,7 @@ def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
         f"one pass over the bf16 bank per step, shared by its Q = {args.proposals_per_step} queries; the stage is scan + exact "
         "top-100 select + merge (single-query select ~17 us, latency-bound); the scan kernel alone, measured with the bank evicted / "
         "resident: profiles/r03_scan_cold_warm.log (18.2 us = 5.2 TB/s after a clean 1 GiB read sweep, 15.7 us = 6.0 TB/s resident in the "
-        "Infinity Cache; in this pipeline, behind the ViT's dirty activations: see the bank_scan_kernel row of profiles/r03_bench_kernel_stats.csv)")
+        "Infinity Cache; in this pipeline, behind the ViT's dirty activations: see the bank_scan_kernel row of profiles/r04_bench_kernel_stats.csv)")
     add("rasterize", stage_ms.get("rasterize", 0), "hbm", (H * 420 * 420 * 7.0 + n_vert * 32.0 + n_tri * 12.0) * n_prop,
         f"mandatory rgb+depth writes; {H * n_tri * n_prop / max(stage_ms.get('rasterize', 1e9), 1e-9) / 1e6:.1f} G triangle set-ups/s")
     add("depth_extents", stage_ms.get("depth_extents", 0), "hbm", H * 420 * 420 * 4.0 * n_prop, "depth read")

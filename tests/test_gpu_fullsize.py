@@ -26,6 +26,9 @@ def test_vit_l_518_big_batch_equals_small_batches_bitwise():
     for i in (0, 31, 62):
         small = vit(img[i:i + 2], layer=22, feature_type="patch")
         assert torch.equal(big[i:i + 2], small), f"crops {i},{i + 1}: big-batch features differ from the small-batch path"
+    # one crop alone: the 64x64 tier on its deepest K-tile ring, row statistics finalised in the qk / fc1 prologues (big batch: the
+    # finalisation kernel) — still the same bits
+    assert torch.equal(big[5:6], vit(img[5:6], layer=22, feature_type="patch")), "single-crop features differ from the big-batch path"
     again = vit(img, layer=22, feature_type="patch")
     assert torch.equal(big, again), "the forward must be deterministic"
 

@@ -2,7 +2,8 @@
 within a stated tolerance on identical proposals ... within 2 deg / 2 mm").
 
 BASELINE config 4 at reduced size: ViT-L/14-reg layer 22 @420^2 (seeded random-init weights of the real architecture), 64 pose
-hypotheses of a TEXTURED mesh, 8 queries = renders of the same mesh at perturbed hypothesis poses.
+hypotheses of a TEXTURED mesh, 8 queries = renders of the same mesh at perturbed hypothesis poses.  FP_PARITY_FULL=1 runs the same test
+at the configuration's own size: 576 hypotheses, 518^2 crops.
 
   oracle side (CPU, nothing from freepose_amd):  fo.rasterize -> fo.depth_extents -> fo.crop_resize_pad -> vit_ref.vit_forward
       (fp32, and the reference's bf16 regime: bf16 weights/activations, pose_estimator.py:21) -> fo.template_score
@@ -32,6 +33,10 @@ from tests._meshes import checker_gradient_texture, textured_cube
 pytestmark = pytest.mark.gpu
 
 N_HYP, N_QUERY, RES, LAYER = 64, 8, 420, 22
+# BASELINE config 4 at FULL size (576 hypotheses, 518^2 crops: ~10 min of CPU oracle ViT on a 16-thread host) is opt-in:
+#   FP_PARITY_FULL=1 python -m pytest tests/test_gpu_pose_parity.py -s          (log of one run: profiles/r04_pose_parity_full.log)
+if os.environ.get("FP_PARITY_FULL") == "1":
+    N_HYP, N_QUERY, RES = 576, int(os.environ.get("FP_PARITY_QUERIES", "6")), 518
 MARGIN_ULP = 3          # bf16 ulps of lead that make an arg-max decisive (scores ~0.3-0.9: 1 ulp = 2^-9 .. 2^-8)
 SCORE_ULP = 3           # per-hypothesis |HIP score - oracle score| bound, bf16 ulps of the oracle score
 
@@ -62,9 +67,14 @@ def _rot(axis, deg):
 def _oracle_feats(sd, crops_f32, dtype, batch=8):
     from oracle import vit_ref
     out = []
-    with torch.inference_mode():
-        for i in range(0, crops_f32.shape[0], batch):
-            out.append(vit_ref.vit_forward(sd, crops_f32[i:i + batch], layer=LAYER, feature_type="patch", dtype=dtype).to(torch.bfloat16))
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(16, nthr))     # the fastest count on the 256-thread hosts of the pool (bench.py's cpu_baseline probe); all cores are several times slower
+    try:
+        with torch.inference_mode():
+            for i in range(0, crops_f32.shape[0], batch):
+                out.append(vit_ref.vit_forward(sd, crops_f32[i:i + batch], layer=LAYER, feature_type="patch", dtype=dtype).to(torch.bfloat16))
+    finally:
+        torch.set_num_threads(nthr)
     return torch.cat(out)
 
 
@@ -130,7 +140,10 @@ def test_pose_parity_vit_in_the_loop(capsys):
     sd32 = {k: t.float() for k, t in sd.items()}
 
     report = {}
-    for regime, dtype in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+    regimes = (("bf16", torch.bfloat16), ("fp32", torch.float32))
+    if os.environ.get("FP_PARITY_FULL") == "1" and os.environ.get("FP_PARITY_FP32") != "1":
+        regimes = regimes[:1]      # full size: the reference's own (bf16) regime; FP_PARITY_FP32=1 adds the fp32 oracle (~6 more minutes)
+    for regime, dtype in regimes:
         src = sd if dtype == torch.bfloat16 else sd32
         hf = fo.torch_to_bits(_oracle_feats(src, h_crops_t, dtype))
         qf = fo.torch_to_bits(_oracle_feats(src, q_crops_t, dtype))
@@ -173,4 +186,4 @@ def test_pose_parity_vit_in_the_loop(capsys):
             for r in rows:
                 print("  %5d %7d %6d %3d  %9.1f %11.2f  %7.3f %6.3f                  | %7.2f %6.2f" % r)
     # with 64 hypotheses (~45 deg apart) and 3-7 deg perturbations most queries must be decisive, or the test shows nothing
-    assert report["bf16"][1] >= N_QUERY // 2 and report["fp32"][1] >= N_QUERY // 2
+    assert all(r[1] >= N_QUERY // 2 for r in report.values())

@@ -3,7 +3,7 @@
 # passes of tools/profile_job.sh (kernel stats + PMC) on the same tree.   gpurun --timeout 3600 -- bash tools/final_evidence.sh
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/r04
-(timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -6) > gpurun_out/r04/final_tests.log
+(timeout 1700 python -m pytest tests -m gpu -q -rf 2>&1 | grep -v amdgpu.ids | tail -40) > gpurun_out/r04/final_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r04/smoke.log 2>&1; tail -1 gpurun_out/r04/smoke.log
 python bench.py > gpurun_out/r04/bench_line.json 2> gpurun_out/r04/bench_line.err
 tail -3 gpurun_out/r04/final_tests.log

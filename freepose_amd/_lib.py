@@ -100,6 +100,7 @@ SIGNATURES = {
     "fp_op_gelu": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fp_op_attention": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fp_op_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "fp_op_im2col_norm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fp_timer_create": (c_int, [P(c_void_p)]),
     "fp_timer_start": (c_int, [c_void_p, c_void_p]),
     "fp_timer_stop": (c_int, [c_void_p, c_void_p]),

@@ -640,6 +640,10 @@ extern "C" int fp_op_attention(const void* QK, int ldqk, const void* Vt, void* O
     return fp_attention_fwd((const bf16_t*)QK, ldqk, (const bf16_t*)Vt, (bf16_t*)O, ldo, B, H, n_tok, npad, q_prescaled != 0,
                             (hipStream_t)stream);
 }
+extern "C" int fp_op_im2col_norm(const void* img, void* A, int B, int H, int W, int ps, int KP, void* stream) {
+    FP_REQUIRE(img && A && B > 0, "op_im2col_norm: null argument / empty batch");
+    return fp_im2col_norm((const bf16_t*)img, (bf16_t*)A, B, H, W, ps, KP, (hipStream_t)stream);
+}
 extern "C" int fp_op_layernorm(const void* X, void* Y, const void* g, const void* b, int rows, int D, float eps,
                                void* stream) {
     FP_REQUIRE(X && Y && g && b, "op_layernorm: null argument");

@@ -513,6 +513,18 @@ def attention(qk: torch.Tensor, vt: torch.Tensor, n_tok: int, out: Optional[torc
     return out
 
 
+def im2col_norm(images: torch.Tensor, ps: int = 14, kp: Optional[int] = None) -> torch.Tensor:
+    """bf16 crops [B,3,H,W] in [0,1] -> normalised patch rows [B*(H/ps)*(W/ps), kp] (fp_op_im2col_norm; kp defaults to 3*ps*ps rounded
+    up to a multiple of 64, what fp_vit_forward uses)"""
+    lib = _lib.load()
+    images = _dev(images, torch.bfloat16)
+    B, _, H, W = images.shape
+    kp = kp or (3 * ps * ps + 63) // 64 * 64
+    out = torch.empty((B * (H // ps) * (W // ps), kp), dtype=torch.bfloat16, device=images.device)
+    check(lib.fp_op_im2col_norm(ptr(images), ptr(out), B, H, W, ps, kp, current_stream()), "fp_op_im2col_norm")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     lib = _lib.load()
     x, gamma, beta = _dev(x, torch.bfloat16), _dev(gamma, torch.bfloat16), _dev(beta, torch.bfloat16)

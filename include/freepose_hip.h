@@ -235,6 +235,10 @@ int fp_op_attention(const void* d_QK, int ldqk, const void* d_Vt, void* d_O, int
                     int npad, int q_prescaled, void* stream);
 int fp_op_layernorm(const void* d_X, void* d_Y, const void* d_gamma, const void* d_beta, int rows, int D, float eps,
                     void* stream);
+/* ImageNet normalise (torchvision Normalize on a bf16 tensor: subtract, round, divide, round — src/pipeline/retrieval/dino.py:12,16) +
+ * patch unfold of bf16 crops [B,3,H,W] in [0,1] into the patch-embed GEMM's A operand [B*(H/ps)*(W/ps), KP], k = c*ps*ps + dy*ps + dx,
+ * columns >= 3*ps*ps zero (the Conv2d patch_embed.proj of hub DINOv2 behind dino.py:18).  Kernel-level entry used by the tests. */
+int fp_op_im2col_norm(const void* d_img, void* d_A, int B, int H, int W, int ps, int KP, void* stream);
 
 /* ---- measurement helpers (bench.py: HIP-event timing on the launch stream) ----------------------------- */
 int fp_timer_create(void** out);

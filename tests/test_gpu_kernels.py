@@ -291,6 +291,23 @@ def test_attention_forced_rescale(prescaled):
     assert (o[5] - v[250].float()).abs().max().item() < 0.02  # query 5 attends (almost) only to key 250
 
 
+@pytest.mark.parametrize("B,H,W,kp", [(2, 224, 224, 640), (3, 420, 420, 640), (2, 518, 518, 640), (1, 28, 70, 592)])
+def test_im2col_norm_bit_exact(B, H, W, kp):
+    """normalise + patch unfold vs the same two bf16 operations in torch (torchvision Normalize on a bf16 tensor: dino.py:12,16) and an
+    unfold: every element equal."""
+    from freepose_amd import ops
+    g = torch.Generator().manual_seed(77)
+    img = torch.rand((B, 3, H, W), generator=g).to(torch.bfloat16).cuda()
+    got = ops.im2col_norm(img, 14, kp)
+    mean = torch.tensor([0.485, 0.456, 0.406]).to(torch.bfloat16).cuda().view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).to(torch.bfloat16).cuda().view(1, 3, 1, 1)
+    x = (img - mean) / std                                           # two bf16 ops, each rounded
+    p = x.unfold(2, 14, 14).unfold(3, 14, 14).permute(0, 2, 3, 1, 4, 5).reshape(B * (H // 14) * (W // 14), 588)
+    ref = torch.zeros((p.shape[0], kp), dtype=torch.bfloat16, device="cuda")
+    ref[:, :588] = p
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("rows,D", [(5, 384), (1000, 1024), (33, 768)])
 def test_layernorm(rows, D):
     from freepose_amd import ops

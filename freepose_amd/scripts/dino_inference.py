@@ -108,9 +108,15 @@ def run(argv=None):
             scales = [float(np.clip(p["scale"], a_min=0.01, a_max=None)) for p in sp]
         elif args.depth_method.startswith("const-"):
             scales = [float(args.depth_method.split("-")[1])] * len(sp)
+        elif args.depth_method == "depthmap":             # reference :82-85: scale from the scene depth map under each proposal mask
+            from freepose_amd.src.pipeline.estimators.scale_estimators import depthmap_scale
+            if "depth" not in entry:
+                raise FileNotFoundError(f"--depth_method depthmap: scene {sid} frame {fid} has no depth map")
+            scales = [depthmap_scale(entry["depth"], entry["intrinsic"], rle_to_mask(p["segmentation"])) for p in sp]
+            for p, sc in zip(sp, scales):
+                p["scale"] = sc
         else:
-            raise NotImplementedError(f"depth_method {args.depth_method}: the depth-map scale estimator is upstream of "
-                                      "this path (SURVEY §2 row 14); supply scales in the proposals JSON")
+            raise ValueError(f"unknown --depth_method {args.depth_method} (depthmap | const-<metres> | zoedepth)")
         rows += proposal_rows(model, templates, entry["image"], entry["intrinsic"], sid, fid, sp, scales, args.layer,
                               args.batch_size, args.bbox_extend)
     pd.DataFrame(rows, columns=CSV_COLUMNS).to_csv(out_csv, index=False, header=True)

@@ -7,7 +7,8 @@ import sys
 _ALIASES = [
     "utils", "utils.bbox_utils", "pipeline", "pipeline.utils", "pipeline.retrieval", "pipeline.retrieval.dino",
     "pipeline.retrieval.renderer", "pipeline.estimators", "pipeline.estimators.pose_estimator",
-    "pipeline.estimators.online_pose_estimator", "pipeline.estimators.tracking_refiner", "pipeline.refiner_utils",
+    "pipeline.estimators.online_pose_estimator", "pipeline.estimators.tracking_refiner", "pipeline.estimators.scale_estimators",
+    "pipeline.refiner_utils",
     "dataloader", "dataloader.template", "dataloader.bop",
 ]
 

@@ -44,7 +44,8 @@ def _slow_rotation(R0, step_deg, k):
 
 
 def draw_frames(root: Path, n_frames: int, n_views: int, size=(480, 640), scales=(0.10, 0.08), seed=5, step_deg=3.0):
-    """-> (frames u8 [F,H,W,3], props: list per frame of per-object dicts, gt poses [F,n_obj,4,4], K)"""
+    """-> (frames u8 [F,H,W,3], props: list per frame of per-object dicts, gt poses [F,n_obj,4,4], K); the frames' z-buffers
+    (metres, 0 = background) are left in `draw_frames.depths` for write_bop(..., depths=...)"""
     from freepose_amd import ops
     from freepose_amd.mesh_io import device_mesh, load_obj
     from freepose_amd.src.pipeline.retrieval.renderer import grid_poses
@@ -57,7 +58,7 @@ def draw_frames(root: Path, n_frames: int, n_views: int, size=(480, 640), scales
     rng = np.random.Generator(np.random.PCG64(seed))
     centres = [(-0.16, -0.02, 0.85), (0.17, 0.05, 0.8)]
     start = [5 % n_views, 17 % n_views]
-    frames, props, gts = [], [], []
+    frames, props, gts, depths = [], [], [], []
     for fr in range(n_frames):
         img = rng.integers(0, 60, size=(H, W, 3), dtype=np.uint8)
         zbuf = np.full((H, W), np.inf, np.float32)
@@ -83,6 +84,8 @@ def draw_frames(root: Path, n_frames: int, n_views: int, size=(480, 640), scales
         frames.append(img)
         props.append(entries)
         gts.append(gt)
+        depths.append(np.where(np.isfinite(zbuf), zbuf, 0.0).astype(np.float32))
+    draw_frames.depths = depths
     return np.stack(frames), props, np.array(gts), K
 
 
@@ -97,13 +100,18 @@ def write_video(root: Path, video: str, frames, props, proposals_name="props.jso
     return rd / proposals_name
 
 
-def write_bop(root: Path, dataset: str, frames, props, K, scene=48, proposals_name="props.json"):
+def write_bop(root: Path, dataset: str, frames, props, K, scene=48, proposals_name="props.json", depths=None):
+    """BOP layout; `depths` (metres) are written as 16-bit PNGs in units of 0.1 mm, the unit the BOPDataset mirror assumes"""
     sd = root / "data" / "datasets" / dataset / "test" / f"{scene:06d}"
     (sd / "rgb").mkdir(parents=True, exist_ok=True)
+    if depths is not None:
+        (sd / "depth").mkdir(parents=True, exist_ok=True)
     cam = {}
     flat = []
     for i, fr in enumerate(frames):
         Image.fromarray(fr, "RGB").save(sd / "rgb" / f"{i + 1:06d}.png")
+        if depths is not None:
+            Image.fromarray(np.round(depths[i] * 10000.0).astype(np.uint16)).save(sd / "depth" / f"{i + 1:06d}.png")
         cam[str(i + 1)] = {"cam_K": [float(x) for x in K.reshape(-1)], "depth_scale": 1.0}
         for e in props[i]:
             flat.append(dict(e, scene_id=scene, image_id=i + 1))

@@ -2,6 +2,7 @@
 on-disk layout: scripts.render_templates -> scripts.extract_retrieval_features -> scripts.merge_features -> TemplateBank, and
 proposals JSON -> scripts.dino_inference / scripts.dino_inference_video -> pose CSV, with 1 rank and with 2 ranks sharing the
 GPU (gloo): identical CSVs, reference row order and format, poses close to the poses the frames were drawn from."""
+import json
 import os
 import subprocess
 import sys
@@ -27,7 +28,7 @@ def workspace(tmp_path_factory):
     assert tar.exists()
     frames, props, gts, K = sc.draw_frames(root, N_FRAMES, N_VIEWS)
     sc.write_video(root, "clip", frames, props)
-    sc.write_bop(root, "synth", frames[:2], props[:2], K)
+    sc.write_bop(root, "synth", frames[:2], props[:2], K, depths=sc.draw_frames.depths[:2])
     return root, gts, K
 
 
@@ -126,6 +127,22 @@ def test_image_driver_and_bank_build(workspace, monkeypatch):
         # t is written in millimetres (dino_inference.py:124); z within 20 % of the drawn pose
         assert abs(t_mm[2] / 1000.0 - gts[fr, o][2, 3]) < 0.2 * gts[fr, o][2, 3]
     text_1 = out.read_text()
+    # --depth_method depthmap (reference :82-85): the scale column is the depth-map estimate under each proposal mask — about the
+    # objects' drawn scales (0.10 m ball, 0.08 m cube: half the largest extent of the eroded visible surface)
+    out_d = dino_inference.run(argv + ["--depth_method", "depthmap"])
+    assert "depth_depthmap" in str(out_d)
+    dfd = pd.read_csv(out_d)
+    from freepose_amd.src.dataloader.bop import BOPDataset
+    from freepose_amd.src.pipeline.estimators.scale_estimators import depthmap_scale
+    from freepose_amd.src.pipeline.utils import rle_to_mask
+    props = json.loads((root / "data" / "results" / "synth" / "props.json").read_text())
+    ds = BOPDataset(str(root / "data" / "datasets" / "synth"), "test")
+    for i, row in dfd.iterrows():
+        entry = ds[int(row["im_id"]) - 1]
+        pr = [p for p in props if p["image_id"] == int(row["im_id"])][i % 2]
+        assert np.isclose(row["scale"], depthmap_scale(entry["depth"], entry["intrinsic"], rle_to_mask(pr["segmentation"])), rtol=1e-12, atol=0)
+        assert 0.5 * pr["scale"] < row["scale"] < 1.3 * pr["scale"], (row["scale"], pr["scale"])
+        assert abs(np.linalg.det(_pose(row)[0]) - 1) < 1e-6
     # two ranks: images are dealt round-robin, one CSV per rank; together they hold the same rows
     # the CLI's own launcher: `python -m scripts.dino_inference ... --gpus 2` with no torch.distributed.run around it
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}

@@ -1,0 +1,91 @@
+"""`--depth_method depthmap` (reference scripts/dino_inference.py:82-85 -> src/pipeline/estimators/scale_estimators.py:117-187): host-side
+numpy.  skimage (label / regionprops / isotropic_erosion) is not in this image, so the reference function cannot be executed here and
+this restatement is parity-unpinned for those two calls; what CAN be checked is checked: hand-computed answers on small
+scenes, the documented quirk, and the geometric properties the definition implies."""
+import numpy as np
+import pytest
+
+from freepose_amd.src.pipeline.estimators import scale_estimators as se
+
+K = np.array([[600.0, 0, 320.0], [0, 600.0, 240.0], [0, 0, 1]])
+
+
+def _scene(h=480, w=640):
+    return np.zeros((h, w), dtype=bool), np.zeros((h, w), dtype=np.float64)
+
+
+def test_largest_component_is_8_connected_and_first_maximum_wins():
+    m, _ = _scene(12, 12)
+    m[1, 1] = m[2, 2] = m[3, 3] = True                # one diagonal chain: a single component under 8-connectivity
+    m[8, 1:4] = True                                  # a second component of the same area, met later in scan order
+    m[10, 10] = True
+    got = se.largest_component(m)
+    assert got.sum() == 3 and got[1, 1] and got[3, 3] and not got[8, 2]
+    with pytest.raises(ValueError):
+        se.largest_component(np.zeros((4, 4), dtype=bool))
+
+
+def test_erosion_is_the_distance_transform_threshold():
+    m, _ = _scene(40, 40)
+    m[5:35, 5:35] = True                              # 30 x 30 square: pixels farther than 8 from the background = 14 x 14
+    e = se.eroded(m, 8)
+    assert e.sum() == 14 * 14 and e[13:27, 13:27].all()
+
+
+def test_tilted_plate_known_answer():
+    """a fronto-parallel-ish plate: 101 x 61 px at z = 1 m + a gentle tilt along x.  After the radius-8 erosion 85 x 45 px remain;
+    the outlier cut keeps the samples closest to the median depth (a band in x), whose extent gives the scale."""
+    m, d = _scene()
+    m[200:261, 250:351] = True
+    m[20:23, 20:23] = True                            # a small second blob: must be ignored
+    xs = np.arange(640)[None, :].repeat(480, 0)
+    d[:] = 1.0 + 0.0005 * (xs - 300)
+    pts = se.pointcloud_from_depth(d, K, m, align=False)
+    rows, cols = np.nonzero(se.eroded(se.largest_component(m), 8))
+    z = d[rows, cols]
+    far = np.abs(z - np.median(z))
+    thr = np.std(z) * 1.5
+    n_expected = int((far <= thr).sum())              # samples are sorted by `far`: the cut is the count of those within the threshold
+    assert pts.shape == (n_expected, 3)
+    assert np.isclose(pts[:, 2].max() - pts[:, 2].min(), 2 * far[far <= thr].max(), atol=1e-9)
+    s = se.depthmap_scale(d, K, m)
+    # the kept band: all 45 eroded rows (y extent 44 px ~ 44/600 m at z ~ 1), x extent set by the cut; the largest extent wins
+    x_ext = (pts[:, 0].max() - pts[:, 0].min())
+    assert np.isclose(se.extent_scale(pts), max(x_ext, pts[:, 1].max() - pts[:, 1].min(), pts[:, 2].max() - pts[:, 2].min()) / 2)
+    assert 0.02 < s < 0.09
+
+
+def test_no_outlier_quirk_keeps_only_min_vertices():
+    """constant depth: no sample exceeds 1.5 sigma, numpy's argmax of an all-False array is 0, so the reference keeps min_vertices
+    samples (scale_estimators.py:160-161) — reproduced, not fixed"""
+    m, d = _scene()
+    m[100:200, 100:200] = True
+    d[:] = 2.0
+    assert se.pointcloud_from_depth(d, K, m, align=False).shape == (25, 3)
+
+
+def test_tiny_mask_falls_back_to_the_uneroded_component():
+    m, d = _scene(60, 60)
+    m[10:14, 10:16] = True                            # 24 pixels: no erosion radius >= 1 leaves more than 25 -> the component itself
+    d[:] = 1.0 + 1e-3 * np.arange(60)[None, :]
+    Ks = np.array([[100.0, 0, 30], [0, 100.0, 30], [0, 0, 1]])
+    pts = se.pointcloud_from_depth(d, Ks, m, align=False)
+    assert pts.shape[0] == 25 or pts.shape[0] == 24   # max(cut, min_vertices) = 25 is clipped by the 24 available samples
+
+
+def test_scale_properties():
+    """depth x 2 (same pixels) doubles the scale; the principal-axis rotation makes it independent of an in-plane rotation of the
+    blob by 90 degrees"""
+    rng = np.random.Generator(np.random.PCG64(4))
+    m, d = _scene()
+    m[150:330, 200:300] = True
+    d[:] = 1.2 + 0.02 * rng.standard_normal(d.shape)
+    s1 = se.depthmap_scale(d, K, m)
+    s2 = se.depthmap_scale(2.0 * d, K, m)
+    assert np.isclose(s2, 2.0 * s1, rtol=1e-9)
+    Kt = K.copy()
+    Kt[0, 2], Kt[1, 2] = K[1, 2], K[0, 2]
+    s3 = se.depthmap_scale(d.T.copy(), Kt, m.T.copy())
+    assert np.isclose(s3, s1, rtol=1e-6)
+    import src.pipeline.estimators.scale_estimators as alias      # the reference's import path resolves
+    assert alias.depthmap_scale(d, K, m) == s1

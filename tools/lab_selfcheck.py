@@ -56,12 +56,34 @@ def main():
     ops.set_option("gemm_variant", -1)
     for a_, b_ in list(zip(outs[238 | 8192], outs[238 | 16384])) + list(zip(outs[238 | 8192], outs[238 | 65536])):
         assert torch.equal(a_, b_), "hand-scheduled tier differs from the 16-wave kernel"
+    # 2c. the 64x64 tier's K-tile ring: every depth cap (2 = the double buffer; 8 = deeper than the product ever picks) gives the same bits
+    #     — plain, LayerNorm-folded + GELU, row statistics; K = 1024 and the long K = 4096 walk
+    for (Ms, Ns, Ks) in ((1376, 1024, 1024), (300, 1024, 4096), (160, 2048, 384)):
+        xs = torch.randn((Ms, Ks), generator=g).to(torch.bfloat16)
+        ws = (torch.randn((Ns, Ks), generator=g) * 0.05).to(torch.bfloat16)
+        bs, gs = torch.randn((Ns,), generator=g).to(torch.bfloat16), torch.randn((Ns,), generator=g).to(torch.bfloat16)
+        rs = torch.randn((Ms, Ns), generator=g).to(torch.bfloat16)
+        gl, bl = torch.randn((Ks,), generator=g).to(torch.bfloat16), (torch.randn((Ks,), generator=g) * 0.3).to(torch.bfloat16)
+        outs = {}
+        for cap in (2, 3, 4, 6, 8):
+            ops.set_option("gemm_ring", cap)
+            so, sr = ops.gemm_stats(xs, ws, bs, gs, rs)
+            outs[cap] = [ops.gemm(xs, ws, bs, 0).cpu(), so.cpu(), sr.cpu()]
+            if Ks <= 1536:
+                outs[cap].append(ops.ln_linear(xs, gl, bl, ws, bs, mode=1).cpu())
+        ops.set_option("gemm_ring", -1)
+        for cap in (3, 4, 6, 8):
+            for a_, b_ in zip(outs[2], outs[cap]):
+                assert torch.equal(a_, b_), f"K-tile ring cap {cap} differs from the double buffer at {(Ms, Ns, Ks)}"
     # 3. attention: ring depths and the short-tail-off flavour agree to rounding (the exponent reference differs by tile order only)
     B, H, n_tok = 3, 16, 905
     npad = (n_tok + 15) // 16 * 16
     qk = (torch.randn((B * npad, 2 * H * 64), generator=g) * 0.5).to(torch.bfloat16)
     vt = torch.randn((B, H, 64, npad), generator=g).to(torch.bfloat16)
     base = ops.attention(qk, vt, n_tok).float().cpu()
+    ops.set_option("attn_variant", 128)          # packed FMAs (the form shipped until round 4): the same bits as the plain ones
+    assert torch.equal(ops.attention(qk, vt, n_tok).float().cpu(), base)
+    ops.set_option("attn_variant", -1)
     for name, val in (("attn_slots", 3), ("attn_slots", 4), ("attn_variant", 8), ("attn_variant", 32)):
         ops.set_option(name, val)
         o = ops.attention(qk, vt, n_tok).float().cpu()

@@ -209,7 +209,8 @@ def test_row_split_dispatch_is_invisible(M):
     assert torch.isfinite(res["split"]["stat_rows1024"]).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(49152 + 37, 1024, 4096), (50000, 1152, 2048)])   # LN-folded epilogues at long K: tools/lab_selfcheck.py (forced tier)
+# (ViT-L fc2, a ragged-column shape, ViT-B fc2)   LN-folded epilogues at long K: tools/lab_selfcheck.py (forced tier)
+@pytest.mark.parametrize("M,N,K", [(49152 + 37, 1024, 4096), (50000, 1152, 2048), (66000, 768, 3072)])
 def test_hand_scheduled_tier_gives_the_bits_of_the_small_tiers(M, N, K):
     """Long-K launches that fill the chip run the hand-scheduled one-wave-per-SIMD kernel (gemm_asm.hip: accumulators in the AGPR file,
     pipelined epilogue, descriptor-clipped ragged rows / columns).  Same K order, same init MFMA, same rounding points as every other

@@ -292,20 +292,22 @@ def test_attention_forced_rescale(prescaled):
     assert (o[5] - v[250].float()).abs().max().item() < 0.02  # query 5 attends (almost) only to key 250
 
 
-@pytest.mark.parametrize("B,H,W,kp", [(2, 224, 224, 640), (3, 420, 420, 640), (2, 518, 518, 640), (1, 28, 70, 592)])
-def test_im2col_norm_bit_exact(B, H, W, kp):
+@pytest.mark.parametrize("B,H,W,ps,kp", [(2, 224, 224, 14, 640), (3, 420, 420, 14, 640), (2, 518, 518, 14, 640), (1, 28, 70, 14, 592),
+                                         (2, 32, 48, 16, 768), (1, 35, 21, 7, 152)])
+def test_im2col_norm_bit_exact(B, H, W, ps, kp):
     """normalise + patch unfold vs the same two bf16 operations in torch (torchvision Normalize on a bf16 tensor: dino.py:12,16) and an
-    unfold: every element equal."""
+    unfold: every element equal, for the DINOv2 patch size and two others."""
     from freepose_amd import ops
     g = torch.Generator().manual_seed(77)
     img = torch.rand((B, 3, H, W), generator=g).to(torch.bfloat16).cuda()
-    got = ops.im2col_norm(img, 14, kp)
+    got = ops.im2col_norm(img, ps, kp)
     mean = torch.tensor([0.485, 0.456, 0.406]).to(torch.bfloat16).cuda().view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).to(torch.bfloat16).cuda().view(1, 3, 1, 1)
     x = (img - mean) / std                                           # two bf16 ops, each rounded
-    p = x.unfold(2, 14, 14).unfold(3, 14, 14).permute(0, 2, 3, 1, 4, 5).reshape(B * (H // 14) * (W // 14), 588)
+    K = 3 * ps * ps
+    p = x.unfold(2, ps, ps).unfold(3, ps, ps).permute(0, 2, 3, 1, 4, 5).reshape(B * (H // ps) * (W // ps), K)
     ref = torch.zeros((p.shape[0], kp), dtype=torch.bfloat16, device="cuda")
-    ref[:, :588] = p
+    ref[:, :K] = p
     assert torch.equal(got, ref)
 
 

@@ -9,11 +9,12 @@ here because it is a flag of the a12 CLI).  Restates src/pipeline/estimators/sca
   far, numpy's argmax of an all-False array is 0, so only `min_vertices` samples are kept) -> back-projection with the pinhole
   intrinsics -> rotation into the principal axes (right singular vectors of X^T X) -> half of the largest axis-aligned extent.
 
-skimage is not in this image, so its two calls are restated from their published definitions with scipy.ndimage —
-`skimage.measure.label` (default connectivity = ndim: 8-neighbourhood) + `regionprops(...).area` -> ndimage.label with a full 3x3
-structure + pixel counts (first maximum wins, like Python's max over regionprops in label order); `skimage.morphology.
-isotropic_erosion(mask, r)` -> `distance_transform_edt(mask) > r`.  PARITY UNPINNED for those two; the arithmetic after them
-is plain numpy on both sides.
+Connected components: the reference's `extract_largest_component` (src/pipeline/utils.py:8,71-84) labels with
+`scipy.ndimage.label(mask)` — default structure, i.e. 4-connectivity: parts that touch only diagonally stay separate — and this module
+makes exactly that call (scipy is in the image).  skimage is not, so its two calls are restated from their published definitions:
+`skimage.measure.regionprops(...).area` -> pixel counts per label (first maximum wins, like Python's max over regionprops in label
+order); `skimage.morphology.isotropic_erosion(mask, r)` -> `distance_transform_edt(mask) > r`.  PARITY UNPINNED for those two (DESIGN
+§5); the arithmetic after them is plain numpy on both sides.
 """
 from __future__ import annotations
 
@@ -22,8 +23,8 @@ from scipy import ndimage
 
 
 def largest_component(mask: np.ndarray) -> np.ndarray:
-    """reference src/pipeline/utils.py:71-84 (skimage label + regionprops)"""
-    lab, n = ndimage.label(np.asarray(mask).astype(bool), structure=np.ones((3, 3), dtype=bool))
+    """reference src/pipeline/utils.py:71-84: scipy.ndimage.label with its default (4-connected) structure + the largest regionprops area"""
+    lab, n = ndimage.label(np.asarray(mask).astype(bool))
     if n == 0:
         raise ValueError("depthmap scale: empty proposal mask")
     area = np.bincount(lab.ravel())[1:]

@@ -14,13 +14,20 @@ def _scene(h=480, w=640):
     return np.zeros((h, w), dtype=bool), np.zeros((h, w), dtype=np.float64)
 
 
-def test_largest_component_is_8_connected_and_first_maximum_wins():
+def test_largest_component_is_4_connected_and_first_maximum_wins():
+    """the reference labels with scipy.ndimage.label's default structure (src/pipeline/utils.py:8,73): a diagonal chain is NOT one
+    component, and among equal areas the first label in scan order wins (max over regionprops)"""
     m, _ = _scene(12, 12)
-    m[1, 1] = m[2, 2] = m[3, 3] = True                # one diagonal chain: a single component under 8-connectivity
-    m[8, 1:4] = True                                  # a second component of the same area, met later in scan order
-    m[10, 10] = True
+    m[1, 1] = m[2, 2] = m[3, 3] = m[4, 4] = True      # a diagonal chain: four single-pixel components under 4-connectivity
+    m[8, 1:4] = True                                  # a 3-pixel row: the largest component
+    m[10, 8:11] = True                                # a second component of the same area, met later in scan order
     got = se.largest_component(m)
-    assert got.sum() == 3 and got[1, 1] and got[3, 3] and not got[8, 2]
+    assert got.sum() == 3 and got[8, 1:4].all() and not got[1, 1] and not got[2, 2] and not got[10, 9]
+    m2, _ = _scene(8, 8)
+    m2[1, 1:3] = True                                 # two 2-pixel parts touching only at a corner: separate; the first one wins
+    m2[2, 3:5] = True
+    got2 = se.largest_component(m2)
+    assert got2.sum() == 2 and got2[1, 1] and got2[1, 2] and not got2[2, 3]
     with pytest.raises(ValueError):
         se.largest_component(np.zeros((4, 4), dtype=bool))
 

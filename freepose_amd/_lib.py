@@ -130,6 +130,8 @@ def load(path: os.PathLike | None = None):
     if hasattr(lib, "fp_lab_set_option"):   # lab build only
         lib.fp_lab_set_option.restype = c_int
         lib.fp_lab_set_option.argtypes = [c_char_p, c_int]
+        lib.fp_lab_read_scratch.restype = c_int
+        lib.fp_lab_read_scratch.argtypes = [c_void_p, c_void_p, c_size_t]
     if path is None:
         _lib = lib
     return lib

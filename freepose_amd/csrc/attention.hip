@@ -223,9 +223,11 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
     // (1374 tokens = 21 tiles + 30 keys, 905 = 14 tiles + 9): half the S^T MFMAs, exponentials and PV MFMAs of that tile.
     // A wave whose 32 queries all lie beyond the padded sequence (`idle`: the last query block of 1374 / 905 tokens holds 94 / 9
     // queries of 128) only takes part in the tile's DMA and barrier.
-    auto tile_body = [&](int t, auto slot_c, auto nks_c) {
+    // `first_c` (compile-time): the launch's first tile, peeled off the loop — it always moves the softmax reference (PRE)
+    auto tile_body = [&](int t, auto slot_c, auto nks_c, auto first_c) {
         const int slot = slot_c;
         constexpr int NKS = decltype(nks_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
         // tiles t+1 .. t+PF-1 may stay in flight (4 DMA instructions per tile per wave); near the end fewer are pending
         const int ahead = min(PF - 1, ntile - 1 - t);
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -311,22 +313,24 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
                 // accumulators are already (logit - reference) in log2 units: the lazy test is a compare with a constant.  The FIRST
                 // tile always moves the reference to its row maximum (from 0, which may sit far above every logit).
                 constexpr float THR2 = LAZY_THR * 1.4426950408889634f / 8.0f;
-                if (__builtin_amdgcn_ballot_w64(mx > THR2) != 0 || t == 0) {   // wave-uniform
+                if (FIRST || __builtin_amdgcn_ballot_w64(mx > THR2) != 0) {   // wave-uniform
                     mx = xlane_max16(mx);
                     mx = xlane_max32(mx);
-                    const float delta = vmax2(mx, t == 0 ? -3.0e38f : 0.f);   // how far the reference moves (>= 0 after the first tile)
-                    const float alpha = __builtin_amdgcn_exp2f(-vmax2(delta, 0.f));
+                    const float delta = FIRST ? mx : vmax2(mx, 0.f);   // how far the reference moves (>= 0 after the first tile)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) nref[fq][r] -= delta;
 #pragma unroll
                     for (int fk = 0; fk < 2 * NKS; ++fk)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) s[fk][fq][r] -= delta;
-                    lacc[fq][0] *= alpha;
+                    if constexpr (!FIRST) {   // (the first tile finds O and l at zero: nothing to rescale)
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        lacc[fq][0] *= alpha;
 #pragma unroll
-                    for (int fd = 0; fd < 4; ++fd)
+                        for (int fd = 0; fd < 4; ++fd)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[fd][fq][r] *= alpha;
+                            for (int r = 0; r < 4; ++r) o[fd][fq][r] *= alpha;
+                    }
                 }
             } else
             if (__builtin_amdgcn_ballot_w64(mx > mthr[fq]) != 0) {   // wave-uniform
@@ -438,22 +442,31 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
     };
     using full_c = std::integral_constant<int, 2>;
     using half_c = std::integral_constant<int, 1>;
+    using yes_c = std::true_type;
+    using no_c = std::false_type;
     if constexpr (SHORT) {
         static_assert(NSLOT == 2, "the short-tail prologue is written for the 2-slot ring");
-        tile_body(0, std::integral_constant<int, 0>{}, half_c{});
+        tile_body(0, std::integral_constant<int, 0>{}, half_c{}, yes_c{});
         for (int t = 1; t < ntile; t += 2) {
-            tile_body(t, std::integral_constant<int, 1>{}, full_c{});
-            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 0>{}, full_c{});
+            tile_body(t, std::integral_constant<int, 1>{}, full_c{}, no_c{});
+            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 0>{}, full_c{}, no_c{});
         }
-    } else if constexpr (NSLOT == 2) {
+    } else if constexpr (NSLOT == 2 && PRE) {
+        tile_body(0, std::integral_constant<int, 0>{}, full_c{}, yes_c{});
+        for (int t = 1; t < ntile; t += 2) {
+            tile_body(t, std::integral_constant<int, 1>{}, full_c{}, no_c{});
+            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 0>{}, full_c{}, no_c{});
+        }
+    } else if constexpr (NSLOT == 2) {   // (unscaled q: the running maximum starts at -1e30, the first tile needs no special case)
         for (int t = 0; t < ntile; t += 2) {
-            tile_body(t, std::integral_constant<int, 0>{}, full_c{});
-            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 1>{}, full_c{});
+            tile_body(t, std::integral_constant<int, 0>{}, full_c{}, no_c{});
+            if (t + 1 < ntile) tile_body(t + 1, std::integral_constant<int, 1>{}, full_c{}, no_c{});
         }
     } else {
-        int slot = 0;
-        for (int t = 0; t < ntile; ++t) {
-            tile_body(t, slot, full_c{});
+        tile_body(0, 0, full_c{}, yes_c{});
+        int slot = NSLOT > 1 ? 1 : 0;
+        for (int t = 1; t < ntile; ++t) {
+            tile_body(t, slot, full_c{}, no_c{});
             slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
     }

@@ -32,7 +32,16 @@ extern "C" int fp_lab_set_option(const char* name, int value) {
     else if (!strcmp(name, "attn_variant")) g_opts[FP_OPT_ATTN_VARIANT] = value;
     else if (!strcmp(name, "topk_select")) g_opts[FP_OPT_TOPK_SELECT] = value;
     else if (!strcmp(name, "gemm_ring")) g_opts[FP_OPT_GEMM_RING] = value;   // cap on the 64x64 tier's K-tile ring depth
+    else if (!strcmp(name, "gemm_sk")) g_opts[FP_OPT_GEMM_SK] = value;       // balanced tier: 1 never, 2 / 3 / 4 force a form (gemm_bf16.hip)
+    else if (!strcmp(name, "gemm_sk_grid")) g_opts[FP_OPT_GEMM_SK_GRID] = value;
     else { fp_set_error("lab_set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
+    return FP_OK;
+}
+// lab build only: copy the head of the balanced tier's scratch buffer to the host (gemm_dbg = 1024 leaves per-workgroup phase timestamps there)
+extern "C" int fp_lab_read_scratch(fp_ctx* ctx, void* host, size_t bytes) {
+    FP_REQUIRE(ctx && host && ctx->sk_ws && bytes <= fp_ctx::SK_WS_BYTES, "lab_read_scratch: no scratch");
+    FP_HIP(hipDeviceSynchronize());
+    FP_HIP(hipMemcpy(host, ctx->sk_ws, bytes, hipMemcpyDeviceToHost));
     return FP_OK;
 }
 #endif
@@ -42,6 +51,9 @@ extern "C" int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "ln_fused")) ctx->opt_ln_fused = value;
     else if (!strcmp(name, "raster_tiled")) ctx->opt_raster_tiled = value;
     else if (!strcmp(name, "gemm_row_split")) ctx->opt_row_split = value;
+#ifdef FP_LAB
+    else if (!strcmp(name, "gemm_stream_k")) ctx->opt_stream_k = value;   // lab: 0 = never lend the balanced tier its scratch
+#endif
     else { fp_set_error("ctx_set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
     return FP_OK;
 }
@@ -59,6 +71,23 @@ int fp_ctx::get(const char* name, size_t bytes, void** out) {
     *out = b.p;
     return FP_OK;
 }
+int fp_ctx::sk_scratch(FpGemmArgs& g, hipStream_t s) {
+    g.sk_mode = opt_stream_k == 0 ? 1 : 0;
+#ifndef FP_LAB
+    g.sk_mode = 1;   // the balanced tier is compiled into the lab build only (gemm_bf16.hip): the product lends no scratch
+    (void)s;
+#endif
+    if (g.sk_mode == 1) return FP_OK;
+    if (!sk_ws) {
+        FP_HIP(hipMalloc((void**)&sk_ws, SK_WS_BYTES));
+        FP_HIP(hipMalloc((void**)&sk_cnt, SK_CNT_N * sizeof(int)));
+        FP_HIP(hipMemsetAsync(sk_cnt, 0, SK_CNT_N * sizeof(int), s));   // the kernels leave the counters at zero
+        FP_HIP(hipStreamSynchronize(s));                                 // (other streams of this context may use them next)
+    }
+    g.sk_ws = sk_ws; g.sk_ws_bytes = SK_WS_BYTES;
+    g.sk_cnt = sk_cnt; g.sk_cnt_n = SK_CNT_N;
+    return FP_OK;
+}
 size_t fp_ctx::total() const {
     size_t t = 0;
     for (auto& kv : bufs) t += kv.second.bytes;
@@ -68,6 +97,10 @@ void fp_ctx::release() {
     for (auto& kv : bufs)
         if (kv.second.p) (void)hipFree(kv.second.p);
     bufs.clear();
+    if (sk_ws) (void)hipFree(sk_ws);
+    if (sk_cnt) (void)hipFree(sk_cnt);
+    sk_ws = nullptr;
+    sk_cnt = nullptr;
 }
 
 extern "C" int fp_ctx_create(int device, fp_ctx** out) {
@@ -364,7 +397,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
     }
     {
         ProfScope ps(v, s, &v->ms_gemm);
-        FpGemmArgs g{}; g.no_split = nosplit;
+        FpGemmArgs g{}; g.no_split = nosplit; if ((rc = v->ctx->sk_scratch(g, s))) return rc;
         g.X = A0; g.ldx = v->KP; g.W = v->pe_w; g.ldw = v->KP; g.C = X; g.ldc = D; g.bias = v->pe_b;
         g.M = B * P; g.N = D; g.K = v->KP; g.pos = pos_patch; g.P = P; g.npad = npad; g.tok_off = 1 + a.n_reg;
         if ((rc = fp_gemm_bf16(g, FP_EPI_PATCH, s))) return rc;
@@ -386,12 +419,12 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
-            FpGemmArgs g{}; g.no_split = nosplit;
+            FpGemmArgs g{}; g.no_split = nosplit; if ((rc = v->ctx->sk_scratch(g, s))) return rc;
             g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.qkvw : w.qkvw; g.ldw = D; g.C = QK; g.ldc = 2 * D; g.bias = w.qkvb;
             g.M = Mi; g.N = 2 * D; g.K = D; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = f.qkv_cb;
             if (lnf && i > 0 && fp_gemm_fuses_ln_part(Mi, (int)(2 * D))) { g.ln_part = part; g.ln_part_ld = Mi; g.ln_part_nb = (int)(D / 64); g.ln_eps = a.ln_eps; g.ln_inv_d = 1.0f / (float)D; }
             if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_BIAS : FP_EPI_BIAS, s))) return rc;
-            FpGemmArgs gv{}; gv.no_split = nosplit;
+            FpGemmArgs gv{}; gv.no_split = nosplit; if ((rc = v->ctx->sk_scratch(gv, s))) return rc;
             gv.X = lnf ? X : Y; gv.ldx = D; gv.W = (lnf ? f.qkvw : w.qkvw) + (size_t)2 * D * D; gv.ldw = D; gv.C = Vt; gv.ldc = 8;
             gv.bias = w.qkvb + 2 * D; gv.M = Mi; gv.N = D; gv.K = D; gv.npad = npad; gv.heads = a.heads;
             gv.ln_mfrag = stat; gv.ln_rstd = rstd; gv.ln_cfrag = lnf ? f.qkv_cb + 2 * D : nullptr;
@@ -404,7 +437,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
-            FpGemmArgs g{}; g.no_split = nosplit;
+            FpGemmArgs g{}; g.no_split = nosplit; if ((rc = v->ctx->sk_scratch(g, s))) return rc;
             g.X = AO; g.ldx = D; g.W = w.projw; g.ldw = D; g.C = X; g.ldc = D; g.bias = w.projb;
             g.gamma = w.ls1 ? w.ls1 : v->ones; g.resid = X; g.ldr = D; g.M = Mi; g.N = D; g.K = D; g.stat_part = part;
             if ((rc = fp_gemm_bf16(g, stats_out ? FP_EPI_LS_RES_STATS : FP_EPI_BIAS_LS_RES, s))) return rc;
@@ -418,12 +451,12 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         }
         {
             ProfScope ps(v, s, &v->ms_gemm);
-            FpGemmArgs g{}; g.no_split = nosplit;
+            FpGemmArgs g{}; g.no_split = nosplit; if ((rc = v->ctx->sk_scratch(g, s))) return rc;
             g.X = lnf ? X : Y; g.ldx = D; g.W = lnf ? f.fc1w : w.fc1w; g.ldw = D; g.C = H1; g.ldc = a.mlp_dim; g.bias = w.fc1b;
             g.M = Mi; g.N = a.mlp_dim; g.K = D; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = f.fc1_cb;
             if (lnf && fp_gemm_fuses_ln_part(Mi, (int)a.mlp_dim)) { g.ln_part = part; g.ln_part_ld = Mi; g.ln_part_nb = (int)(D / 64); g.ln_eps = a.ln_eps; g.ln_inv_d = 1.0f / (float)D; }
             if ((rc = fp_gemm_bf16(g, lnf ? FP_EPI_LN_GELU : FP_EPI_BIAS_GELU, s))) return rc;
-            FpGemmArgs g2{}; g2.no_split = nosplit;
+            FpGemmArgs g2{}; g2.no_split = nosplit; if ((rc = v->ctx->sk_scratch(g2, s))) return rc;
             g2.X = H1; g2.ldx = a.mlp_dim; g2.W = w.fc2w; g2.ldw = a.mlp_dim; g2.C = X; g2.ldc = D; g2.bias = w.fc2b;
             g2.gamma = w.ls2 ? w.ls2 : v->ones; g2.resid = X; g2.ldr = D; g2.M = Mi; g2.N = D; g2.K = a.mlp_dim; g2.stat_part = part;
             if ((rc = fp_gemm_bf16(g2, (stats_out && i + 1 < L) ? FP_EPI_LS_RES_STATS : FP_EPI_BIAS_LS_RES, s))) return rc;
@@ -568,6 +601,7 @@ extern "C" int fp_op_gemm(fp_ctx* ctx, const void* X, int ldx, const void* W, in
     g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Cc; g.ldc = ldc;
     g.bias = (const bf16_t*)bias; g.gamma = (const bf16_t*)gamma; g.resid = (const bf16_t*)resid; g.ldr = ldr;
     g.M = M; g.N = N; g.K = K; g.no_split = ctx->opt_row_split == 0;
+    { const int rc = ctx->sk_scratch(g, (hipStream_t)stream); if (rc) return rc; }
     return fp_gemm_bf16(g, epi, (hipStream_t)stream);
 }
 extern "C" int fp_op_gemm_vt(fp_ctx* ctx, const void* X, int ldx, const void* W, int ldw, void* Vt, const void* bias, int M, int N,
@@ -576,6 +610,7 @@ extern "C" int fp_op_gemm_vt(fp_ctx* ctx, const void* X, int ldx, const void* W,
     FpGemmArgs g{};
     g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Vt; g.ldc = 8;
     g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads;
+    { const int rc = ctx->sk_scratch(g, (hipStream_t)stream); if (rc) return rc; }
     return fp_gemm_bf16(g, FP_EPI_VT, (hipStream_t)stream);
 }
 // LayerNorm folded into a linear layer, as fp_vit_forward runs LN1 -> qkv and LN2 -> fc1 (kernel-level entry for the tests):
@@ -601,6 +636,7 @@ extern "C" int fp_op_ln_linear(fp_ctx* ctx, const void* X, int M, int K, const v
     g.X = (const bf16_t*)X; g.ldx = K; g.W = Wf; g.ldw = K; g.C = (bf16_t*)out; g.ldc = mode == 2 ? 8 : N;
     g.bias = (const bf16_t*)bias; g.M = M; g.N = N; g.K = K; g.npad = npad; g.heads = heads; g.ln_mfrag = stat; g.ln_rstd = rstd; g.ln_cfrag = cb;
     g.no_split = ctx->opt_row_split == 0;
+    if ((rc = ctx->sk_scratch(g, s))) return rc;
     return fp_gemm_bf16(g, mode == 0 ? FP_EPI_LN_BIAS : (mode == 1 ? FP_EPI_LN_GELU : FP_EPI_LN_VT), s);
 }
 // LayerScale + residual GEMM that also emits the row statistics of its OUTPUT (what the next LN-folded GEMM consumes):
@@ -620,6 +656,7 @@ extern "C" int fp_op_gemm_stats(fp_ctx* ctx, const void* X, int ldx, const void*
     g.X = (const bf16_t*)X; g.ldx = ldx; g.W = (const bf16_t*)W; g.ldw = ldw; g.C = (bf16_t*)Cc; g.ldc = ldc;
     g.bias = (const bf16_t*)bias; g.gamma = (const bf16_t*)gamma; g.resid = (const bf16_t*)resid; g.ldr = ldr;
     g.M = M; g.N = N; g.K = K; g.stat_part = part; g.no_split = ctx->opt_row_split == 0;
+    if ((rc = ctx->sk_scratch(g, (hipStream_t)stream))) return rc;
     if ((rc = fp_gemm_bf16(g, FP_EPI_LS_RES_STATS, (hipStream_t)stream))) return rc;
     if ((rc = fp_stats_finalize(part, ms, rstd, M, N, eps, (hipStream_t)stream))) return rc;
     // d_stat [M,6] = the row record's 4 words {sh|sl, sh|-mh, -ml|-mh, 0} reinterpreted as floats are NOT meaningful: hand back the raw

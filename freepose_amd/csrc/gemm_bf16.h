@@ -64,6 +64,14 @@ struct FpGemmArgs {
     int no_split;  // 1: never split this launch by rows between the tile tiers (set on the parts of a split; callers may set it too)
     int stat_ld;   // row stride of stat_part (= the whole problem's M; a row-split launch covers only part of it).  0 = M
     int ring;      // K-tile ring depth of the 64x64 tier (2 .. 8 buffers; chosen by the launcher from the grid size, gemm_bf16.hip)
+    // ---- balanced tier (stream-K, gemm_bf16.hip): a launch that would leave most of the chip idle, or fill its last round badly, is run
+    // by a grid of G workgroups that share the (tile, K step) units evenly; a tile whose K range is spread over several workgroups is
+    // completed by the LAST of them to arrive, which adds the fp32 partial tiles in K order (run-to-run deterministic).  The caller
+    // lends the scratch: sk_ws = 2 partial tiles per workgroup (fp32), sk_cnt = one zero-initialised arrival counter per tile (the
+    // kernel leaves them zero).  Null = the tier is not used.  sk_mode: 0 = the launcher decides, 1 = never.
+    float* sk_ws; size_t sk_ws_bytes;
+    int* sk_cnt; int sk_cnt_n;
+    int sk_mode;
 #ifdef FP_LAB
     int dbg;   // LAB BUILD ONLY (libfreepose_hip_lab.so, tools/): measurement bits with wrong numerics — 2 = LN-folded kernels start from
                // zero accumulators, 8 = persistent kernels skip the epilogue, 16 = epilogue without its stores, 32 = staggered start
@@ -103,10 +111,29 @@ __device__ __forceinline__ void fp_ln_finalize_row(const float2* __restrict__ pa
 // panels, so a strip's W slabs (<= 2 MB) stay in the XCD's 4 MB L2 for the whole sweep and each X panel is fetched once
 // per strip.  (rocprofv3, fc1 with N = 4096: the plain row-major order streamed the 8 MB weight matrix once per 2
 // row-panels — FETCH_SIZE 9x the algorithmic bytes.)
+// blockIdx -> logical id: workgroups are dealt to the 8 XCDs round-robin; the remap gives each XCD a CONTIGUOUS run of logical ids
+__device__ __forceinline__ int fp_gemm_xcd_remap(int block, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = block & 7, pos = block >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+// logical tile id -> (tile_m, tile_n) in column strips of SW n-tiles swept m-major
+template <int SW = 4>
+__device__ __forceinline__ void fp_gemm_tile_of_id(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int full = tiles_n / SW, tail = tiles_n - full * SW;
+    const int in_full = full * tiles_m * SW;
+    if (id < in_full) {
+        const int strip = id / (tiles_m * SW), rem = id - strip * (tiles_m * SW);
+        tm = rem / SW;
+        tn = strip * SW + (rem - tm * SW);
+    } else {
+        const int rem = id - in_full;
+        tm = rem / tail;
+        tn = full * SW + (rem - tm * tail);
+    }
+}
 template <int SW = 4>
 __device__ __forceinline__ void fp_gemm_tile(int block, int nblocks, int tiles_m, int tiles_n, int& tm, int& tn) {
-    const int q = nblocks >> 3, r = nblocks & 7, xcd = block & 7, pos = block >> 3;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    const int id = fp_gemm_xcd_remap(block, nblocks);
     const int full = tiles_n / SW, tail = tiles_n - full * SW;
     const int in_full = full * tiles_m * SW;
     if (id < in_full) {

@@ -77,6 +77,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+#ifdef FP_LAB
+    // lab build, gemm_dbg = 1024: phase timestamps (100 MHz wall clock) of every workgroup's wave 0 into the scratch buffer —
+    // entry, first K tile landed, K loop done, epilogue done (tools/step_ablate.py phases)
+    unsigned long long dbg_t[4] = {0, 0, 0, 0}, dbg_c0 = 0;
+    if (FP_GEMM_DBG_BIT(p, 1024)) { dbg_t[0] = wall_clock64(); dbg_c0 = __builtin_amdgcn_s_memtime(); }
+#endif
     // The epilogue's row-coalescing slabs are a STATIC shared array of their own: the K-tile buffers are filled by LDS-DMA, and for LDS
     // accesses that may alias a DMA destination hipcc waits until the copy has landed (vmcnt(0)) — carved out of the same dynamic
     // array, the slabs made the first ds_write of every epilogue wait for the next tile's prefetch.  Distinct LDS variables carry
@@ -103,6 +109,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     // ---- XCD-aware tile order (bijective for any grid size).  PERSIST: a resident grid walks the tiles t = block,
     // block + grid, ...; the grid is a multiple of 8, so a workgroup's tiles keep its XCD under the same remap.
     constexpr bool PERSIST = (VAR & 32) != 0;
+    // SK (VAR bit 2048): the balanced tier.  The grid's G workgroups share the launch's U = ntiles x (K / 64) units evenly: workgroup w
+    // (in XCD-contiguous logical order) walks the units [u, u1) of the sequence "tile 0's K steps, tile 1's K steps, ..." — whole tiles
+    // end in the ordinary epilogue, a tile whose K range it shares with its neighbours goes through fp32 partial tiles (below).
+    constexpr bool SK = (VAR & 2048) != 0;
+    static_assert(!SK || ((VAR & 2) != 0 && !PERSIST), "the balanced tier is built on the software-pipelined loop");
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
     int m0, n0;
@@ -111,7 +122,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     uint32_t offX[IX], offW[IW];
     auto set_tile = [&](int t, int& tm0, int& tn0) {
         int tile_m, tile_n;
-        fp_gemm_tile<(VAR & 512) ? 8 : 4>(t, ntiles, tiles_m, tiles_n, tile_m, tile_n);
+        if constexpr (SK) fp_gemm_tile_of_id<4>(t, tiles_m, tiles_n, tile_m, tile_n);   // t is already a logical tile id
+        else fp_gemm_tile<(VAR & 512) ? 8 : 4>(t, ntiles, tiles_m, tiles_n, tile_m, tile_n);
         tm0 = tile_m * BM;
         tn0 = tile_n * BN;
 #pragma unroll
@@ -141,7 +153,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
             for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
         }
     }
-    set_tile(tile, m0, n0);
+    int sk_w = 0, sk_base = 0, sk_rem = 0, sk_u = 0, sk_u1 = 0;
+    if constexpr (SK) {
+        const int G = gridDim.x, U = ntiles * (p.K / BK);
+        sk_w = fp_gemm_xcd_remap(blockIdx.x, G);
+        sk_base = U / G;
+        sk_rem = U - sk_base * G;
+        sk_u = sk_w * sk_base + min(sk_w, sk_rem);
+        sk_u1 = sk_u + sk_base + (sk_w < sk_rem ? 1 : 0);
+        if (sk_u >= sk_u1) return;                        // (the launcher never asks for more workgroups than units)
+    } else {
+        set_tile(tile, m0, n0);
+    }
     const char* gX = (const char*)p.X;
     const char* gW = (const char*)p.W;
 
@@ -247,11 +270,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     constexpr bool RING = (VAR & 2) && (VAR & 1024);          // K-tile ring of run-time depth (software-pipelined loop, 64x64 tier)
     int last_slot = (nkt - 1) & 1;                            // ring slot the last K step read (RELOC slabs live there)
     const int NS = RING ? p.ring : 2;                         // ring depth of the software-pipelined loop
+    // K range of the current segment: the whole tile, or (SK) the part of a tile inside this workgroup's unit range
+    int kt0 = 0, nk = nkt, sk_tile = 0;
+    bool sk_more = false;
+    do {
+    if constexpr (SK) {
+        sk_tile = sk_u / nkt;
+        kt0 = sk_u - sk_tile * nkt;
+        nk = min(nkt - kt0, sk_u1 - sk_u);
+        if (sk_more) __syncthreads();                     // every wave is done with the previous segment's K tiles and slabs
+        set_tile(sk_tile, m0, n0);
+    }
     if constexpr ((VAR & 2) != 0 && !PERSIST) {
         // the software-pipelined loop's first NS K tiles go out before anything else: they stream in while the row statistics are
         // finalised and the accumulators initialised below
         for (int s = 0; s < NS; ++s)
-            if (s < nkt) stage(s, s);
+            if (s < nk) stage(s, kt0 + s);
     }
     if constexpr (LNF && !TRANS && !PERSIST) {
         // Small tiers, row statistics not finalised yet (FpGemmArgs::ln_part): this tile's rows are finalised here — the arithmetic of
@@ -272,7 +306,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
             __syncthreads();
         }
     }
-    init_acc(m0, n0);
+    if (SK && kt0 > 0) {
+        // a later K slice of a shared tile: its partial sum starts from zero (the slice that holds K step 0 carries the bias / LayerNorm init)
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TR; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    } else {
+        init_acc(m0, n0);
+    }
 
     auto load_frags = [&](const char* sb, int kk, bf16x8_t (&fr)[TR], bf16x8_t (&fc)[TC]) {
         const int slotR = (((kk << 2) | lg) ^ keyR) << 4;
@@ -398,11 +440,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
         };
         // (the first NS stages were issued at the top of the kernel) stage 0 has landed when at most the later stages' instructions are
         // outstanding; any vector-memory operation issued since (row statistics, init records) only makes this wait stricter
-        if (RING) wait_stages(nkt >= NS ? NS - 1 : 0, std::false_type{});
-        else if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
+        if (RING) wait_stages(nk >= NS ? NS - 1 : 0, std::false_type{});
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef FP_LAB
+        if (FP_GEMM_DBG_BIT(p, 1024)) dbg_t[1] = wall_clock64();
+#endif
         // `settle`: pass a fragment set through an empty asm.  hipcc cannot count LDS reads across the loop back-edge
         // and would otherwise emit lgkmcnt(0) AFTER the prefetch reads are issued (waiting for the prefetch itself);
         // with the settle placed BEFORE the prefetch its wait covers only reads issued a whole MFMA block earlier.
@@ -412,31 +457,164 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
 #pragma unroll
             for (int f = 0; f < TC; ++f) asm volatile("" : "+v"(fc[f]));
         };
+        constexpr bool SPREAD = (VAR & 4096) != 0;
+        // second half of a K step, interleaved: MFMA block B (TC x TR) with [DMA: the IPS pieces of stage `kt_dma` into slot `dslot`] and
+        // the TR + TC fragment reads of the next step's first half (from `nsb`)
+        auto spread_half = [&](auto dma_c, int dslot, int kt_dma, const char* nsb) {
+            constexpr bool DMA = decltype(dma_c)::value;
+            constexpr int NM = TC * TR, NP = IX + IW, NR = TR + TC;
+            char* db = smem + dslot * STAGE;
+            const size_t kb = (size_t)kt_dma * ROWB;
+            const int slotR = ((0 | lg) ^ keyR) << 4, slotC = ((0 | lg) ^ keyC) << 4;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int i = m / TR, j = m % TR;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frB[j], fcB[i], acc[i][j], 0, 0, 0);
+                if constexpr (DMA) {
+                    if ((m * NP) / NM != ((m + 1) * NP) / NM) {          // piece q goes out behind MFMA m
+                        const int q = (m * NP) / NM;
+                        if (q < IX) glds16(gX + offX[q] + kb, db + (q * NW + wave) * 1024);
+                        else glds16(gW + offW[q - IX] + kb, db + BM * ROWB + ((q - IX) * NW + wave) * 1024);
+                    }
+                }
+                if ((m * NR) / NM != ((m + 1) * NR) / NM) {              // fragment read f behind MFMA m
+                    const int f = (m * NR) / NM;
+                    if (f < TR) frA[f] = *(const bf16x8_t*)(nsb + baseR + f * 4 * ROWB + slotR);
+                    else fcA[f - TR] = *(const bf16x8_t*)(nsb + baseC + (f - TR) * 16 * ROWB + slotC);
+                }
+            }
+            // pin the order: per MFMA at most one DMA piece and one fragment read behind it
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (DMA && (m * NP) / NM != ((m + 1) * NP) / NM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if ((m * NR) / NM != ((m + 1) * NR) / NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
         load_frags(smem, 0, frA, fcA);
         int cur = 0;   // ring slot of stage kt
-        for (int kt = 0; kt < nkt; ++kt) {
+        // (lab build, gemm_dbg: 64 = no DMA in the steady state, 128 = no MFMAs, 256 = no fragment reads, 512 = no barrier — wrong results,
+        //  what a K step of the small tiers is made of: profiles/r05_ab.md)
+        for (int kt = 0; kt < nk; ++kt) {
             const char* sb = smem + cur * STAGE;
             const int nxt = cur + 1 == NS ? 0 : cur + 1;
+#ifdef FP_LAB
+            // lab build, gemm_dbg = 2048: shader-clock stamps inside K step 8 (wave 0 of every workgroup) — where the wave waits
+            const bool stamp = FP_GEMM_DBG_BIT(p, 2048) && kt == 8 && p.sk_ws;
+            unsigned long long st[8];
+#define FP_STAMP(i) if (stamp) { asm volatile("" ::: "memory"); st[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); }
+#else
+#define FP_STAMP(i)
+#endif
+            FP_STAMP(0)
             settle(frA, fcA);
-            load_frags(sb, 1, frB, fcB);
-            mma_block(frA, fcA);
-            if (kt + 1 < nkt) {
+            FP_STAMP(1)
+            if (!FP_GEMM_DBG_BIT(p, 256)) load_frags(sb, 1, frB, fcB);
+            if (!FP_GEMM_DBG_BIT(p, 128)) mma_block(frA, fcA);
+            FP_STAMP(2)
+            if (kt + 1 < nk) {
                 // stage kt+1 must have landed; stages kt+2 .. kt+NS-1 may stay in flight (near the end of K fewer were issued: drain)
-                wait_stages(kt + NS - 1 < nkt ? NS - 2 : 0, std::true_type{});
-                __builtin_amdgcn_s_barrier();
+                wait_stages(kt + NS - 1 < nk ? NS - 2 : 0, std::true_type{});
+                FP_STAMP(3)
+                if (!FP_GEMM_DBG_BIT(p, 512)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (kt + NS < nkt) stage(cur, kt + NS);   // every wave is done reading stage kt: its slot takes stage kt + NS
+                FP_STAMP(4)
+                if constexpr (SPREAD) {
+                    // SPREAD (VAR bit 4096): the second half of the step as ONE interleaved stream — an LDS-DMA piece holds its issuing wave
+                    // for ~50 clocks (profiles/r05_ab.md: 8 pieces in a row = 400 of a step's 1670 clocks with the matrix pipe idle), so
+                    // each piece goes out behind a pair of MFMAs of block B, the next step's first fragment reads between them
+                    settle(frB, fcB);
+                    if (kt + NS < nk) spread_half(std::true_type{}, cur, kt0 + kt + NS, smem + nxt * STAGE);
+                    else spread_half(std::false_type{}, cur, 0, smem + nxt * STAGE);
+                    cur = nxt;
+                    continue;
+                }
+                if (kt + NS < nk && !FP_GEMM_DBG_BIT(p, 64)) stage(cur, kt0 + kt + NS);   // every wave is done reading stage kt: its slot takes stage kt + NS
+                FP_STAMP(5)
                 settle(frB, fcB);
-                load_frags(smem + nxt * STAGE, 0, frA, fcA);
+                FP_STAMP(6)
+                if (!FP_GEMM_DBG_BIT(p, 256)) load_frags(smem + nxt * STAGE, 0, frA, fcA);
             }
-            mma_block(frB, fcB);
+            if (!FP_GEMM_DBG_BIT(p, 128)) mma_block(frB, fcB);
+            FP_STAMP(7)
+#ifdef FP_LAB
+            if (stamp && tid == 0) {
+                unsigned long long* o = (unsigned long long*)p.sk_ws + 65536 + (size_t)blockIdx.x * 8;
+                for (int i = 0; i < 8; ++i) o[i] = st[i];
+            }
+#endif
+#undef FP_STAMP
             cur = nxt;
         }
-        last_slot = (nkt - 1) % NS;
+        last_slot = (nk - 1) % NS;
+#ifdef FP_LAB
+        if (FP_GEMM_DBG_BIT(p, 1024)) dbg_t[2] = wall_clock64();
+#endif
     }
 
-    if constexpr (RELOC) epi_stage = reloc_stage(last_slot);
-    fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage, smem_raw);
+    bool finish = true;                                   // this workgroup runs the tile's epilogue
+    if constexpr (SK) {
+        if (nk < nkt) {
+            // ---- a K slice of a tile shared with neighbouring workgroups.  Every slice writes its fp32 partial tile (agent-coherent
+            // stores: the workgroups sit on different XCDs, whose L2s are not coherent with each other) to one of its two scratch slots
+            // and counts itself in; the LAST to arrive adds the slices IN K ORDER — slice 0 carries the bias / LayerNorm init — so the
+            // sum does not depend on who that is, and runs the epilogue.  Nobody waits for anybody.
+            typedef fp_gemm::u32x4_t u32x4;
+            constexpr int TILE_F = BM * BN;                // floats per partial tile
+            const int ut0 = sk_tile * nkt;
+            const int cut = sk_rem * (sk_base + 1);
+            auto wg_of = [&](int u) { return u < cut ? u / (sk_base + 1) : sk_rem + (u - cut) / sk_base; };
+            const int w_first = wg_of(ut0), nsl = wg_of(ut0 + nkt - 1) - w_first + 1;
+            const int voff = (wave * 64 + lane) * 16;      // fragment f of the lane sits at voff + f * NW * 1024
+            {
+                const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(p.sk_ws + (size_t)(2 * sk_w + (kt0 > 0 ? 0 : 1)) * TILE_F), 0, TILE_F * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TR; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rw, voff + (i * TR + j) * NW * 1024, 0, 16);   // sc1
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* const flag = (int*)(smem + NS * STAGE);   // 16 spare bytes behind the K-tile ring (launch_cfg)
+            if (tid == 0) *flag = __hip_atomic_fetch_add(p.sk_cnt + sk_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            finish = *flag == nsl - 1;
+            if (finish) {
+                if (tid == 0) __hip_atomic_store(p.sk_cnt + sk_tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                for (int sl = 0; sl < nsl; ++sl) {
+                    const int w = w_first + sl;
+                    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(p.sk_ws + (size_t)(2 * w + (sl == 0 ? 1 : 0)) * TILE_F), 0, TILE_F * 4, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+#pragma unroll
+                        for (int j = 0; j < TR; ++j) {
+                            const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rr, voff + (i * TR + j) * NW * 1024, 0, 16));
+                            acc[i][j] = sl == 0 ? v : acc[i][j] + v;
+                        }
+                }
+            }
+        }
+    }
+    if (finish) {
+        if constexpr (RELOC) epi_stage = reloc_stage(last_slot);
+        fp_gemm::epilogue<BM, BN, WM, WN, EPI, VAR, TC, TR>(p, acc, m0, n0, wm, wn, li, lg, epi_stage, smem_raw);
+    }
+#ifdef FP_LAB
+    if (FP_GEMM_DBG_BIT(p, 1024) && p.sk_ws && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg_t[3] = wall_clock64();
+        unsigned long long* o = (unsigned long long*)p.sk_ws + (size_t)blockIdx.x * 5;
+        o[0] = dbg_t[0]; o[1] = dbg_t[1]; o[2] = dbg_t[2]; o[3] = dbg_t[3]; o[4] = __builtin_amdgcn_s_memtime() - dbg_c0;   // shader clocks
+    }
+#endif
+    if constexpr (SK) {
+        sk_u += nk;
+        sk_more = sk_u < sk_u1;
+    }
+    } while (SK && sk_more);
 }
 
 // bf16(gelu_erf(x)) for the 8192 input patterns of the table window, evaluated with the device expression of the direct variant
@@ -453,16 +631,24 @@ __global__ void gelu_direct_kernel(const bf16_t* x, bf16_t* y, size_t n) {
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR>
-int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
+int launch_cfg(const FpGemmArgs& a, hipStream_t stream, int sk_grid = 0) {
     constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr bool SK = (VAR & 2048) != 0;                   // balanced tier: sk_grid workgroups share the (tile, K step) units
     constexpr bool LUT = FpEpiTraits<EPI>::GELU && (VAR & 4) != 0;
     constexpr bool RING = (VAR & 2) && (VAR & 1024);
     constexpr int TABB = LUT ? fp_gemm::GELU_TAB_BYTES : 0;
-    constexpr int SMEM_MAX = TABB + (RING ? 8 : 2) * STAGE;   // dynamic part; the slabs are static (see the kernel)
-    static_assert(SMEM_MAX + (LUT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES) <= 160 * 1024, "LDS budget");
+    constexpr int SLABS = LUT ? 0 : WM * WN * fp_gemm::EPI_STAGE_BYTES;
+    constexpr int RMAX = RING ? ((160 * 1024 - TABB - SLABS - 16) / STAGE < 8 ? (160 * 1024 - TABB - SLABS - 16) / STAGE : 8) : 2;   // deepest ring that fits
+    constexpr int SMEM_MAX = TABB + RMAX * STAGE + (SK ? 16 : 0);   // dynamic part; the slabs are static (see the kernel)
+    static_assert(SMEM_MAX + SLABS <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, EPI, VAR>;
     FP_DYN_LDS_ONCE(kern, SMEM_MAX);
     int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    if constexpr (SK) {
+        FP_REQUIRE(sk_grid > 0 && sk_grid <= tiles * (a.K / BK) && a.sk_ws && a.sk_cnt && tiles <= a.sk_cnt_n &&
+                       (size_t)sk_grid * 2 * BM * BN * 4 <= a.sk_ws_bytes, "gemm: balanced tier without scratch (grid %d, %d tiles)", sk_grid, tiles);
+        tiles = sk_grid;
+    }
     FpGemmArgs ar = a;
     ar.ring = 2;
     if constexpr (RING) {
@@ -477,12 +663,12 @@ int launch_cfg(const FpGemmArgs& a, hipStream_t stream) {
         cap = fp_opt_get(FP_OPT_GEMM_RING, 4);   // lab: up to 8
 #endif
         for (const int r : {8, 6, 4, 3}) {
-            if ((r - 1) * IPS > 63 || r > nkt || r > cap) continue;
+            if ((r - 1) * IPS > 63 || r > nkt || r > cap || r > RMAX) continue;
             const long resident = (long)ncu_r * ((160 * 1024) / (FIXED + r * STAGE));
             if (tiles <= resident) { ar.ring = r; break; }
         }
     }
-    const int SMEM = TABB + ar.ring * STAGE;
+    const int SMEM = TABB + ar.ring * STAGE + (SK ? 16 : 0);
     if constexpr ((VAR & 32) != 0) {   // one resident workgroup per CU (128 KiB of LDS each)
         static int ncu = [] { int dev = 0, n = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n & ~7; }();
         tiles = tiles < ncu ? tiles : ncu;
@@ -593,6 +779,28 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
             }
         }
     }
+#ifdef FP_LAB
+    // BALANCED TIER (round 5, LAB BUILD ONLY — measured and not shipped, profiles/r05_ab.md §1): G workgroups share the launch's (tile, K
+    // step) units evenly (stream-K); a tile whose K range is spread over several workgroups is completed by the last of them to arrive,
+    // which adds the fp32 partial tiles in K order.  Forms: gemm_sk = 2 / 3 / 4 -> 128x128 / 64x64 / 128x128-on-a-ring units,
+    // gemm_sk_grid = G.
+    if constexpr (EPI != FP_EPI_PATCH) {
+        int sk_tier = 0, sk_grid = 0;
+        const int f = fp_opt_get(FP_OPT_GEMM_SK, 0), g = fp_opt_get(FP_OPT_GEMM_SK_GRID, 0);
+        if (f >= 2 && f <= 4 && !big && a.sk_ws && a.sk_cnt && a.sk_mode != 1) {
+            sk_tier = f - 1;
+            const long units = (long)cdiv(a.M, f == 3 ? 64 : 128) * cdiv(a.N, f == 3 ? 64 : 128) * (a.K / BK);
+            sk_grid = (int)std::min<long>(units, g > 0 ? g : (f == 3 ? 4L : f == 4 ? 1L : 2L) * ncu);
+            sk_grid = (int)std::min<long>(sk_grid, (long)(a.sk_ws_bytes / (f == 3 ? 2 * 64 * 64 * 4 : 2 * 128 * 128 * 4)));
+        }
+        if (sk_tier == 1) return launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL | 2048>(a, stream, sk_grid);
+        if (sk_tier == 2) {
+            if constexpr (FpEpiTraits<EPI>::TRANS) return launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_TINY | 2048>(a, stream, sk_grid);
+            else return launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_TINY | 2048>(a, stream, sk_grid);
+        }
+        if (sk_tier == 3) return launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL | 1024 | 2048>(a, stream, sk_grid);
+    }
+#endif
     // A launch that cannot even give every CU one 128x128 tile (a single 518^2 crop: 88 tiles for N = 1024) runs one-wave
     // 64x64 tiles instead — 4x the workgroups, all CUs busy (bit 2048, A/B only: keep the 128x128 kernel).
     const long tiles_mid = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
@@ -635,13 +843,21 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // tiny tier: 64x64 tiles.  Row-major epilogues split the tile over TWO waves (32 x 64 each): a launch that cannot fill the chip is
     // bound by one wave's walk along K, and per K step a lone wave issues 16 LDS-DMA pieces for 32 MFMAs — two waves halve both
     // (ViT-L B = 1 @518^2: see profiles/r04_ab.md §4).  The transposed V store needs 64-token wave tiles and keeps one wave.
-    if constexpr (FpEpiTraits<EPI>::TRANS)
+    if constexpr (FpEpiTraits<EPI>::TRANS) {
+#ifdef FP_LAB
+        if (!big && !tiny && (var & 524288)) return (var & 262144) ? launch_cfg<128, 128, 2, 4, EPI, FP_GEMM_VAR_SMALL | 4096>(a, stream) : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL | 4096>(a, stream);   // lab A/B: spread DMA issue
+        if (!big && tiny && (var & 524288)) return launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_TINY | 4096>(a, stream);
+        if (!big && !tiny && (var & 262144)) return launch_cfg<128, 128, 2, 4, EPI, FP_GEMM_VAR_SMALL>(a, stream);   // lab A/B: 128x128 tier on 8 waves
+#endif
         return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
              : tiny ? launch_cfg<64, 64, 1, 1, EPI, FP_GEMM_VAR_TINY>(a, stream)
                     : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);
-    else {
+    } else {
 #ifdef FP_LAB
         if (!big && tiny && (var & 131072)) return launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_SMALL>(a, stream);   // lab A/B: two K-tile buffers
+        if (!big && !tiny && (var & 524288)) return (var & 262144) ? launch_cfg<128, 128, 4, 2, EPI, FP_GEMM_VAR_SMALL | 4096>(a, stream) : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL | 4096>(a, stream);   // lab A/B: spread DMA issue
+        if (!big && tiny && (var & 524288)) return launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_TINY | 4096>(a, stream);
+        if (!big && !tiny && (var & 262144)) return launch_cfg<128, 128, 4, 2, EPI, FP_GEMM_VAR_SMALL>(a, stream);   // lab A/B: 128x128 tier on 8 waves
 #endif
         return big ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
              : tiny ? launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_TINY>(a, stream)

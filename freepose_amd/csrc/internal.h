@@ -21,6 +21,14 @@ struct fp_ctx {
     int opt_ln_fused = -1;       // 1 (default): LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward; 0: separate kernel
     int opt_raster_tiled = -1;   // default: by triangle count / image size; 1 / 0 force the LDS-tiled / global-buffer strategy
     int opt_row_split = -1;      // 1 (default): GEMM launches between the tile tiers are split by rows; 0: never
+    int opt_stream_k = -1;       // 1 (default): small GEMM launches may run on the balanced tier (K slices summed in K order: results depend
+                                 // on the launch size in the last place); 0: never — every tier then gives the same bits for a row
+    // scratch of the balanced GEMM tier (gemm_bf16.h FpGemmArgs::sk_*): fp32 partial tiles + zero-initialised arrival counters
+    float* sk_ws = nullptr;
+    int* sk_cnt = nullptr;
+    static constexpr size_t SK_WS_BYTES = (size_t)64 << 20;
+    static constexpr int SK_CNT_N = 16384;
+    int sk_scratch(FpGemmArgs& g, hipStream_t s);   // lends the scratch to a launch (allocates on first use)
     size_t total() const;
     void release();
 };

@@ -28,13 +28,18 @@ Fillers follow the MFMAs at a fixed rate (one per two MFMAs in phase 0, one per 
 """
 from __future__ import annotations
 
-# Two geometries are generated (macros FP_GASM4_* and FP_GASM8_*):
-#   4 waves (2 x 2, one per SIMD):   wave tile 128 x 128, 256 accumulator registers, fragments / addresses in v[64:215]
-#   8 waves (2 x 4, two per SIMD):   wave tile 128 x 64,  128 accumulator registers, everything else in v[16:127] (256 registers per
-#                                    wave in total); the loop is 1-2 % slower (1.5x the fragment reads per flop) but two waves share
-#                                    each SIMD's vector ALU in the epilogue
-TC = 8
-TR = PCS = NACC = NW = LDS_SHIFT = STORES = 0
+# Three geometries are generated (macros FP_GASM4_*, FP_GASM8_* and FP_GASMS_*):
+#   "4": 256x256 tile, 4 waves (2 x 2, one per SIMD): wave tile 128 x 128, 256 accumulator registers, fragments / addresses in v[64:215]
+#   "8": 256x256 tile, 8 waves (2 x 4, two per SIMD): wave tile 128 x 64,  128 accumulator registers, everything else in v[16:127] (256
+#        registers per wave in total); the loop is 1-2 % slower (1.5x the fragment reads per flop) but two waves share each SIMD's
+#        vector ALU in the epilogue
+#   "S": 128x128 tile, 4 waves (2 x 2), wave tile 64 x 64, 64 accumulator registers, everything else in v[64:143] — the SMALL tier
+#        (round 5): launches below the 256x256 tier run one or two workgroups per CU, i.e. one or two waves per SIMD, where hipcc's
+#        schedule of the same loop leaves every phase of a K step (fragment reads, MFMAs, barrier, DMA issue) serial:
+#        1670 clocks per step against 512 of MFMA time (profiles/r05_ab.md §2).  Same step structure as the big geometries at a quarter
+#        of the size: per wave and step 32 MFMAs, 16 fragment reads, 8 DMA pieces.
+TC = TR = PCS = NACC = NW = LDS_SHIFT = STORES = XTILE = 0
+RATE0 = RATE1 = 1.0
 S_RSX, S_RSW = 36, 40        # buffer descriptors of the tile being LOADED
 S_DK, S_CNT, S_LX0, S_LW0, S_LX1, S_LW1 = 44, 45, 46, 47, 48, 49
 S_LAST = 49
@@ -42,15 +47,21 @@ V_SETA_X = V_SETA_W = V_SETB_X = V_SETB_W = V_XP = V_WP = V_LAST = 0
 V_AX, V_AW = {}, {}
 
 
-def set_geometry(nw):
-    global TR, PCS, NACC, NW, LDS_SHIFT, STORES, V_SETA_X, V_SETA_W, V_SETB_X, V_SETB_W, V_XP, V_WP, V_LAST
+def set_geometry(geo):
+    global TC, TR, PCS, NACC, NW, LDS_SHIFT, STORES, XTILE, RATE0, RATE1, V_SETA_X, V_SETA_W, V_SETB_X, V_SETB_W, V_XP, V_WP, V_LAST
+    nw = {"4": 4, "8": 8, "S": 4}[geo]
     NW = nw
-    TR = 8 if nw == 4 else 4
-    PCS = 32 // nw                      # DMA pieces per operand, wave and stage
+    bt = 128 if geo == "S" else 256     # tile edge
+    TC = bt // 2 // 16                  # X fragments per wave (two wave rows)
+    TR = bt // (nw // 2) // 16          # W fragments per wave
+    PCS = bt // 8 // nw                 # DMA pieces per operand, wave and stage
     NACC = 4 * TC * TR
-    LDS_SHIFT = 13 if nw == 4 else 12   # log2 of a wave's bytes per operand and stage
+    LDS_SHIFT = {128: 12, 256: 13}[bt * 4 // nw]   # log2 of a wave's bytes per operand and stage (bt / nw rows of 128 B)
+    XTILE = bt * 128                    # bytes of one operand tile; a stage is X tile + W tile
     STORES = 2 * TC * (TR // 4)         # output stores per wave and tile (two per 16 x 64 block): the entry wait's count
-    v0 = 64 if nw == 4 else 16
+    RATE0 = 0.5 if nw == 4 else 0.4     # fillers per MFMA in phase 0 (fragment reads) ...
+    RATE1 = {"4": 1.0, "8": 1.2, "S": 1.6}[geo]   # ... and in phase 1 (DMA pieces + fragment reads; "S": 25 fillers behind 16 MFMAs)
+    v0 = 16 if geo == "8" else 64
     V_SETA_X = v0
     V_SETA_W = V_SETA_X + 4 * TC
     V_SETB_X = V_SETA_W + 4 * TR
@@ -110,7 +121,7 @@ def interleave(mfmas, fillers, rate):
 def step(buf, preload_next=True):
     L = []
     m0 = [mfma(i, jj, V_SETA_X, V_SETA_W) for i in range(TC) for jj in range(TR)]
-    L += interleave(m0, frag_reads(buf, 1, V_SETB_X, V_SETB_W), 0.5 if NW == 4 else 0.4)
+    L += interleave(m0, frag_reads(buf, 1, V_SETB_X, V_SETB_W), RATE0)
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
     m1 = [mfma(i, jj, V_SETB_X, V_SETB_W) for i in range(TC) for jj in range(TR)]
     groups = dma_groups(buf)
@@ -121,7 +132,7 @@ def step(buf, preload_next=True):
         fill += groups[q]
         fill += reads[q * nrd // (2 * PCS):(q + 1) * nrd // (2 * PCS)]
     fill.append(f"s_add_u32 s{S_DK}, s{S_DK}, 0x80")
-    L += interleave(m1, fill, (1.0 if preload_next else 0.6) * (1.0 if NW == 4 else 1.2))
+    L += interleave(m1, fill, (1.0 if preload_next else 0.6) * RATE1)
     L += ["s_waitcnt lgkmcnt(0)"]
     return L
 
@@ -140,8 +151,8 @@ def setup_pieces(vx0, vw0, sx8, sw8):
 
 
 def setup_lds(lds_base, wave):
-    return [f"s_lshl_b32 s{S_LX0}, {wave}, {LDS_SHIFT}", f"s_add_u32 s{S_LX0}, s{S_LX0}, {lds_base}", f"s_add_u32 s{S_LW0}, s{S_LX0}, 0x8000",
-            f"s_add_u32 s{S_LX1}, s{S_LX0}, 0x10000", f"s_add_u32 s{S_LW1}, s{S_LW0}, 0x10000"]
+    return [f"s_lshl_b32 s{S_LX0}, {wave}, {LDS_SHIFT}", f"s_add_u32 s{S_LX0}, s{S_LX0}, {lds_base}", f"s_add_u32 s{S_LW0}, s{S_LX0}, {hex(XTILE)}",
+            f"s_add_u32 s{S_LX1}, s{S_LX0}, {hex(2 * XTILE)}", f"s_add_u32 s{S_LW1}, s{S_LW0}, {hex(2 * XTILE)}"]
 
 
 def descriptors(xlo, xhi, xrec, wlo, whi, wrec):
@@ -162,7 +173,7 @@ def prologue_stmt():
 
 
 def init_stmt():
-    # operands: 0..TR-1 the W-side records (A operand, fragment jj), TR..TR+7 the X-side records (fragment i)
+    # operands: 0..TR-1 the W-side records (A operand, fragment jj), TR..TR+TC-1 the X-side records (fragment i)
     L = ["s_nop 1"]
     for i in range(TC):
         for jj in range(TR):
@@ -181,9 +192,9 @@ def tile_stmt():
     L = ["s_nop 4"]
     L += descriptors("%0", "%1", "%2", "%3", "%4", "%5") + setup_pieces("%17", "%18", "%12", "%13") + setup_lds("%14", "%15")
     L += [f"v_mov_b32 v{V_AX[(0, 0)]}, %19", f"v_xor_b32 v{V_AX[(0, 1)]}, 64, v{V_AX[(0, 0)]}",
-          f"v_add_u32 v{V_AX[(1, 0)]}, 0x10000, v{V_AX[(0, 0)]}", f"v_add_u32 v{V_AX[(1, 1)]}, 0x10000, v{V_AX[(0, 1)]}",
+          f"v_add_u32 v{V_AX[(1, 0)]}, {hex(2 * XTILE)}, v{V_AX[(0, 0)]}", f"v_add_u32 v{V_AX[(1, 1)]}, {hex(2 * XTILE)}, v{V_AX[(0, 1)]}",
           f"v_mov_b32 v{V_AW[(0, 0)]}, %20", f"v_xor_b32 v{V_AW[(0, 1)]}, 64, v{V_AW[(0, 0)]}",
-          f"v_add_u32 v{V_AW[(1, 0)]}, 0x10000, v{V_AW[(0, 0)]}", f"v_add_u32 v{V_AW[(1, 1)]}, 0x10000, v{V_AW[(0, 1)]}"]
+          f"v_add_u32 v{V_AW[(1, 0)]}, {hex(2 * XTILE)}, v{V_AW[(0, 0)]}", f"v_add_u32 v{V_AW[(1, 1)]}, {hex(2 * XTILE)}, v{V_AW[(0, 1)]}"]
     L += ["s_cmp_eq_u32 %21, 0", "s_cbranch_scc1 L_nodrain_%=", "s_waitcnt vmcnt(0)", "L_nodrain_%=:", f"s_waitcnt vmcnt({STORES})", "s_barrier"]
     L += frag_reads(0, 0, V_SETA_X, V_SETA_W)
     L += ["s_waitcnt lgkmcnt(0)", f"s_mov_b32 s{S_DK}, 0x100", f"s_mov_b32 s{S_CNT}, %16"]
@@ -210,9 +221,9 @@ def clob(vlo, vhi, slo, shi, acc):
 
 def main():
     print("// generated by freepose_amd/csrc/gemm_asm_gen.py — do not edit (the generator documents the loop)")
-    for nw in (4, 8):
-        set_geometry(nw)
-        p = f"FP_GASM{nw}"
+    for geo in ("4", "8", "S"):
+        set_geometry(geo)
+        p = f"FP_GASM{geo}"
         emit(f"{p}_PROLOGUE_TEXT", prologue_stmt())
         print(f"#define {p}_PROLOGUE_CLOBBERS " + clob(V_XP, V_WP + PCS - 1, S_RSX, S_LAST, False))
         emit(f"{p}_INIT_TEXT", init_stmt())

@@ -51,8 +51,8 @@ struct FpGemmArgs {
     const uint16_t* gelu_tab;
     // FP_EPI_LN_*: init-MFMA operand records, 8 bf16 (16 bytes) each — per row   {sh, sl, sh, -mh, -ml, -mh, 0, 0}  (sigma, mean),
     // per feature {b'h, b'h, b'l, ch, ch, cl, 0, 0}  (b', colsum(W')) — and rstd = 1/sigma [M] fp32 for the epilogue
-    const uint4* ln_mfrag;
-    const float* ln_rstd;
+    uint4* ln_mfrag;     // (written by a small-tier launch that finalises FpGemmArgs::ln_part in its prologue, read-only otherwise)
+    float* ln_rstd;
     const uint4* ln_cfrag;
     // optional (row-major LN epilogues): the producing GEMM's partial row statistics [D/64][ln_part_ld] (sum, sum of squares).  When set,
     // the row records are not there yet: a launch that runs on the small tile tiers finalises the rows of each tile in the kernel's
@@ -158,6 +158,9 @@ int fp_gemm_gelu_table(const uint16_t** out);
 bool fp_gemm_asm_supported(const FpGemmArgs& a, int epi);
 bool fp_gemm_asm_preferred(const FpGemmArgs& a, int epi);   // supported AND measured faster than the 16-wave kernel
 int fp_gemm_asm(const FpGemmArgs& a, int epi, int waves, hipStream_t stream);   // waves: 4 (one per SIMD) or 8 (two per SIMD)
+// the hand-scheduled 128x128 kernel (gemm_asm.hip, geometry "S"): the small tier of the row-major epilogues
+bool fp_gemm_asm_small_supported(const FpGemmArgs& a, int epi);
+int fp_gemm_asm_small(const FpGemmArgs& a, int epi, hipStream_t stream);
 // y[i] = bf16(gelu_erf(x[i])): the direct expression, elementwise (test entry fp_op_gelu)
 int fp_gemm_gelu_direct(const bf16_t* x, bf16_t* y, size_t n, hipStream_t stream);
 // name of the kernel variant used for (epi) — for profiles / bench bookkeeping

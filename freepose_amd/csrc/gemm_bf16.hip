@@ -36,6 +36,7 @@
 namespace {
 
 constexpr int BK = 64;         // bf16 per K stage  (128-byte LDS rows)
+constexpr long BIG_MIN_TILES = 192;   // fewer 256x256 tiles than this never run on the big tier (launch_epi, fp_gemm_fuses_ln_part)
 constexpr int ROWB = BK * 2;   // bytes per LDS row
 
 __device__ __forceinline__ int key_plain(int row) { return (row >> 1) & 7; }
@@ -298,8 +299,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
                     uint4 rec;
                     float rstd;
                     fp_ln_finalize_row(p.ln_part, (size_t)p.ln_part_ld, p.ln_part_nb, row, p.ln_inv_d, p.ln_eps, rec, rstd);
-                    const_cast<uint4*>(p.ln_mfrag)[row] = rec;
-                    const_cast<float*>(p.ln_rstd)[row] = rstd;
+                    p.ln_mfrag[row] = rec;
+                    p.ln_rstd[row] = rstd;
                 }
             }
             __threadfence_block();
@@ -704,7 +705,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
         // big tier (or is a transposed store) gets them from the finalisation kernel first
         if (a.ln_part && (FpEpiTraits<EPI>::TRANS || !fp_gemm_fuses_ln_part(a.M, a.N))) {
             FP_REQUIRE(a.ln_part_nb > 0 && a.ln_part_ld >= a.M, "gemm: ln_part needs ln_part_nb and ln_part_ld");
-            const int rc = fp_stats_finalize(a.ln_part, const_cast<uint4*>(a.ln_mfrag), const_cast<float*>(a.ln_rstd), a.M, a.ln_part_nb * 64,
+            const int rc = fp_stats_finalize(a.ln_part, a.ln_mfrag, a.ln_rstd, a.M, a.ln_part_nb * 64,
                                              a.ln_eps, stream, a.ln_part_ld);
             if (rc != FP_OK) return rc;
             FpGemmArgs b = a;
@@ -713,7 +714,20 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
         }
     }
     const bool filled = tiles_big * 4 >= rounds_big * ncu * 3;          // >= 75 % of the big-tile rounds are real work
-    bool big = tiles_big >= 192 && filled && !(var & 256);              // bit 256 (A/B only): force the 128x128 kernel
+    bool big = tiles_big >= BIG_MIN_TILES && filled && !(var & 256);    // bit 256 (A/B only): force the 128x128 kernel
+    // (fp_gemm_fuses_ln_part shares BIG_MIN_TILES: a launch that still carries partial sums was promised the small tiers, which finalise
+    //  them in their prologue — the 256x256 kernels would read stale records)
+    FP_REQUIRE(!(big && a.ln_part), "gemm: partial row statistics on the big tier (M=%d N=%d)", a.M, a.N);
+    // The hand-scheduled 128x128 kernel (gemm_asm.hip, geometry "S": a persistent walk over two resident workgroups per CU, so no second
+    // row split below) as the small tier of the row-major epilogues: LAB BUILD ONLY — +8 ... 30 % on isolated launches with a resident X,
+    // -4 ... +17 % on ViT forwards (profiles/r05_ab.md §3), not shipped.  gemm_variant bit 1048576 = on; with it bit 2097152 = only where
+    // the launch gives every CU a 128x128 tile, bit 4194304 = only for K >= 2048.
+    bool asm_small = false;
+#ifdef FP_LAB
+    asm_small = !FpEpiTraits<EPI>::TRANS && (var & 1048576) && fp_gemm_asm_small_supported(a, EPI);
+    if ((var & 2097152) && (long)cdiv(a.M, 128) * cdiv(a.N, 128) < ncu) asm_small = false;
+    if ((var & 4194304) && a.K < 2048) asm_small = false;
+#endif
     // ROW SPLIT (round 3): whole rounds of the resident grid on 256x256 tiles, the remaining rows on the finer tiers — for the launch
     // sizes in between (the video path's ~20-crop batches: 600 qk tiles = 2.34 rounds, 300 proj / fc2 tiles = 1.17) where the big
     // tile wastes most of a round and the small tile, ~0.56 of a big round per round of 2 tiles per CU at half the work, pays its
@@ -724,8 +738,8 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
         const long tiles_n = cdiv(a.N, 256);
         const long full = tiles_big / ncu;                               // whole rounds
         const long rb = full * ncu / tiles_n;                            // 256-row blocks they cover
-        if (!(var & (256 | 4096)) && !a.no_split && full >= 1 && rb * 256 < a.M && tiles_big >= 192) {
-            const double r_small = 0.56;
+        if (!(var & (256 | 4096)) && !a.no_split && full >= 1 && rb * 256 < a.M && tiles_big >= BIG_MIN_TILES) {
+            const double r_small = asm_small ? 0.45 : 0.56;   // a round of two 128x128 tiles per CU in units of a big round (half its work)
             auto small_cost = [&](long rows) { return (double)cdiv(cdiv(rows, 128) * cdiv((long)a.N, 128), 2L * ncu) * r_small; };
             const double t_big = (double)rounds_big, t_small = small_cost(a.M);
             const double t_now = big ? t_big : t_small;
@@ -756,7 +770,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
         const long tn = cdiv(a.N, 128), slots = 2L * ncu, tiles_mid_all = (long)cdiv(a.M, 128) * tn;
         const long fullm = tiles_mid_all / slots;
         const long rbm = fullm * slots / tn;                              // 128-row blocks the whole rounds cover
-        if (!big && !(var & (256 | 4096)) && !a.no_split && fullm >= 1 && rbm * 128 < a.M) {
+        if (!big && !asm_small && !(var & (256 | 4096)) && !a.no_split && fullm >= 1 && rbm * 128 < a.M) {
             const long rem_rows = a.M - rbm * 128, rem_mid = cdiv(rem_rows, 128L) * tn;
             const double t_now = (double)cdiv(tiles_mid_all, slots);
             const double t_rem = rem_mid < ncu ? 0.5 * (double)cdiv(cdiv(rem_rows, 64L) * cdiv((long)a.N, 64L), 4L * ncu) : (double)cdiv(rem_mid, slots);
@@ -799,6 +813,11 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
             else return launch_cfg<64, 64, 2, 1, EPI, FP_GEMM_VAR_TINY | 2048>(a, stream, sk_grid);
         }
         if (sk_tier == 3) return launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL | 1024 | 2048>(a, stream, sk_grid);
+    }
+#endif
+#ifdef FP_LAB
+    if constexpr (!FpEpiTraits<EPI>::TRANS) {
+        if (!big && asm_small) return fp_gemm_asm_small(a, EPI, stream);
     }
 #endif
     // A launch that cannot even give every CU one 128x128 tile (a single 518^2 crop: 88 tiles for N = 1024) runs one-wave
@@ -867,7 +886,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-bool fp_gemm_fuses_ln_part(int M, int N) { return (long)cdiv(M, 256) * cdiv(N, 256) < 192; }
+bool fp_gemm_fuses_ln_part(int M, int N) { return (long)cdiv(M, 256) * cdiv(N, 256) < BIG_MIN_TILES; }
 
 // Per-device GELU table (16 KiB), built on first use; fp_ctx_create calls this so that no launch path ever allocates.
 int fp_gemm_gelu_table(const uint16_t** out) {

@@ -75,6 +75,39 @@ def main():
         for cap in (3, 4, 6, 8):
             for a_, b_ in zip(outs[2], outs[cap]):
                 assert torch.equal(a_, b_), f"K-tile ring cap {cap} differs from the double buffer at {(Ms, Ns, Ks)}"
+    # 2d. round 5's small-tier forms (profiles/r05_ab.md): the 128x128 tier on 8 waves, the spread DMA issue and the hand-scheduled
+    #     128x128 kernel walk K in the product's order -> the product's bits; the balanced (stream-K) forms add fp32 partial tiles in K
+    #     order -> run-to-run identical, within the fp32 summation-order distance of the product (<= 1 bf16 ulp of each rounding point)
+    for (Ms, Ns, Ks) in ((4560, 1024, 4096), (1376, 2048, 1024), (2768, 1024, 1024)):
+        xs = torch.randn((Ms, Ks), generator=g).to(torch.bfloat16)
+        ws = (torch.randn((Ns, Ks), generator=g) * 0.05).to(torch.bfloat16)
+        bs, gs = torch.randn((Ns,), generator=g).to(torch.bfloat16), torch.randn((Ns,), generator=g).to(torch.bfloat16)
+        rs = torch.randn((Ms, Ns), generator=g).to(torch.bfloat16)
+        gl, bl = torch.randn((Ks,), generator=g).to(torch.bfloat16), (torch.randn((Ks,), generator=g) * 0.3).to(torch.bfloat16)
+
+        def run():
+            so, sr = ops.gemm_stats(xs, ws, bs, gs, rs)
+            r = [ops.gemm(xs, ws, bs, 0).cpu(), ops.gemm(xs, ws, bs, 2, gamma=gs, resid=rs).cpu(), so.cpu(), sr.cpu()]
+            if Ks <= 1536:
+                r += [ops.ln_linear(xs, gl, bl, ws, bs, mode=0).cpu(), ops.ln_linear(xs, gl, bl, ws, bs, mode=1).cpu()]
+            return r
+        ref = run()
+        for var in (238 | 262144, 238 | 524288, 238 | 524288 | 262144, 238 | 1048576, 238 | 1048576 | 4096):
+            ops.set_option("gemm_variant", var)
+            for a_, b_ in zip(ref, run()):
+                assert torch.equal(a_, b_), f"gemm_variant {var} differs from the product at {(Ms, Ns, Ks)}"
+        ops.set_option("gemm_variant", -1)
+        for mode, grid in ((2, 256), (2, 512), (3, 1024), (4, 256)):
+            ops.set_option("gemm_sk", mode)
+            ops.set_option("gemm_sk_grid", grid)
+            o1, o2 = run(), run()
+            for i, (a_, b_, c_) in enumerate(zip(ref, o1, o2)):
+                assert torch.equal(b_, c_), f"balanced tier {mode}/{grid} is not run-to-run deterministic at {(Ms, Ns, Ks)}"
+                if i != 3:      # (row statistics: compared through the outputs they are computed from)
+                    tol = (a_.float().abs() + (rs.float().abs() if i in (1, 2) else 0.0)) * 2.0 ** -6 + 1e-3
+                    assert ((b_.float() - a_.float()).abs() <= tol).all(), f"balanced tier {mode}/{grid} off at {(Ms, Ns, Ks)} output {i}"
+        ops.set_option("gemm_sk", -1)
+        ops.set_option("gemm_sk_grid", -1)
     # 3. attention: ring depths and the short-tail-off flavour agree to rounding (the exponent reference differs by tile order only)
     B, H, n_tok = 3, 16, 905
     npad = (n_tok + 15) // 16 * 16

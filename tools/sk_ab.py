@@ -36,6 +36,8 @@ def forms(M, N, K):
     if os.environ.get("SK_FORMS") == "asm":        # the hand-scheduled one-wave-per-SIMD 256x256 kernel on part-filled grids
         return [("plain", 1, 0, -1, False), ("no split", 1, 0, -1, False, 238 | 4096), ("asm, no split", 1, 0, -1, False, 238 | 4096 | 16384),
                 ("asm", 1, 0, -1, False, 238 | 16384)]
+    if os.environ.get("SK_FORMS") == "asms":       # the hand-scheduled 128x128 kernel below the big tier
+        return [("plain", 1, 0, -1, False), ("asm 128x128", 1, 0, -1, False, 238 | 1048576), ("asm 128x128, no split", 1, 0, -1, False, 238 | 1048576 | 4096)]
     f = [("plain", 1, 0, -1, False)]
     for g in (256, 512):
         f.append((f"sk128/{g}", 2, g, -1, False))

@@ -420,6 +420,111 @@ def config_legs(args, vit, bank):
     return out
 
 
+def cli_legs(args, vit, in_memory_meshes_per_s=None):
+    """BASELINE configs 2 and 3 THROUGH THE CLI LOOPS, files on disk (secondary, rank 0): a synthetic workspace in the reference's layout
+    (tests/_synth_scene.py: two OBJ meshes -> scripts.render_templates on the HIP rasteriser -> `shard-000000.tar`, 600 views per mesh),
+    the shard's members re-used under `--cli-meshes` names so that every mesh is a different set of tar reads and PNG decodes.
+      bank build  = scripts.extract_retrieval_features.process(): per mesh tar reads + 1200 PNG decodes + host->device copy + 600 ViT-L
+                    forwards @420^2 + FFA + one .npy, with the next mesh's host stage prefetched under this mesh's ViT calls, and the
+                    same loop with --no_prefetch;
+      inference   = scripts.dino_inference.process_images(): images of two proposals each, every proposal a NEW mesh (cold: template
+                    decode + 600 ViT forwards per proposal), then the same images again (warm: template store + feature store hits)."""
+    import io
+    import shutil
+    import tarfile
+    import tempfile
+    from tests import _synth_scene as sc
+    from scripts import dino_inference, extract_retrieval_features
+    from freepose_amd.src.dataloader.bop import BOPDataset
+    from freepose_amd.src.dataloader.template import WebTemplateDataset
+    from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
+    from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+    out = {}
+    root = Path(tempfile.mkdtemp(prefix="fp_bench_ws_"))
+    cwd = os.getcwd()
+    n_meshes, T = max(2, min(10, args.cli_meshes)), 600
+    try:
+        os.chdir(root)
+        sc.write_meshes(root)
+        tar_path = sc.render_shards(root, T)
+        names = [f"m{i:02d}{sc.MESH_IDS[i % 2]}" for i in range(n_meshes)]
+        with tarfile.open(tar_path) as src:
+            blobs = {m.name: src.extractfile(m).read() for m in src.getmembers()}
+        tar_path.unlink()
+        for side in tar_path.parent.glob("*.npy"):
+            side.unlink()
+        with tarfile.open(tar_path, "w") as dst:
+            for i, nm in enumerate(names):
+                base = sc.MESH_IDS[i % 2]
+                for k in range(T):
+                    for suffix in ("rgb.png", "depth.png"):
+                        b = blobs[f"{base}_{k}.{suffix}"]
+                        info = tarfile.TarInfo(f"{nm}_{k}.{suffix}")
+                        info.size = len(b)
+                        dst.addfile(info, io.BytesIO(b))
+        (root / "data" / "mesh_cache.csv").write_text("model_name\n" + "\n".join(names) + "\n")
+        del blobs
+        fe = DINOv2FeatureExtractor.__new__(DINOv2FeatureExtractor)      # share the already-resident ViT-L
+        torch.nn.Module.__init__(fe)
+        fe.model_name, fe.model, fe.num_register_tokens = "dinov2_vitl14_reg", vit, vit.n_reg
+        shards = root / "data" / "datasets" / "objaverse_shards"
+        # ---- bank build -----------------------------------------------------------------------------------------------------
+        res = {}
+        for mode in ("prefetch", "no_prefetch"):
+            a = extract_retrieval_features.build_parser().parse_args(["--batch_size", "256", "--n_views", str(T)] + (["--no_prefetch"] if mode == "no_prefetch" else []))
+            fdir = root / "data" / "datasets" / f"feat_{mode}"
+            fdir.mkdir(parents=True, exist_ok=True)
+            ds = WebTemplateDataset(shards.as_posix(), (root / "data" / "mesh_cache.csv").as_posix(), crop=False, n_views=T, cache_meshes=0)
+            extract_retrieval_features.process(fe, ds, [0], a, fdir, quiet=True)          # warm-up: pinned buffers, index, first touches
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            stamps = []
+            done = extract_retrieval_features.process(fe, ds, list(range(n_meshes)), a, fdir, quiet=True, stamps=stamps)
+            torch.cuda.synchronize()
+            sec = time.perf_counter() - t0
+            steady = float(np.median(np.diff(stamps))) if len(stamps) > 2 else None      # the first mesh's host stage has nothing to hide under
+            res[mode] = {"meshes": done, "seconds": sec, "meshes_per_s": done / sec, "host_stage_s_per_mesh": ds.decode_seconds / (done + 1),
+                         "steady_state_s_per_mesh": steady, "steady_state_meshes_per_s": None if not steady else 1.0 / steady}
+        same = all((root / "data" / "datasets" / "feat_prefetch" / f"{n}.npy").read_bytes() ==
+                   (root / "data" / "datasets" / "feat_no_prefetch" / f"{n}.npy").read_bytes() for n in names)
+        out["config2_bank_build_cli"] = {
+            "metric": "meshes/s (scripts.extract_retrieval_features loop on shards on disk: tar reads + 1200 PNG decodes + H2D + 600 ViT-L forwards @420^2 + FFA + .npy per mesh)",
+            "value": res["prefetch"]["meshes_per_s"], "unit": "meshes/s", "meshes": n_meshes, "views_per_mesh": T,
+            "prefetch": res["prefetch"], "no_prefetch": res["no_prefetch"], "outputs_byte_identical": bool(same),
+            "in_memory_meshes_per_s": in_memory_meshes_per_s,
+            "vs_in_memory": None if not in_memory_meshes_per_s else res["prefetch"]["meshes_per_s"] / in_memory_meshes_per_s,
+            "steady_state_vs_in_memory": None if not (in_memory_meshes_per_s and res["prefetch"]["steady_state_meshes_per_s"]) else res["prefetch"]["steady_state_meshes_per_s"] / in_memory_meshes_per_s,
+            "host_threads": os.cpu_count()}
+        # ---- inference: cold and warm ---------------------------------------------------------------------------------------
+        n_img = n_meshes // 2
+        frames, props, gts, K = sc.draw_frames(root, n_img, T)
+        for fr in range(n_img):                                           # every proposal of every image names a mesh of its own
+            for o, e in enumerate(props[fr]):
+                e["mesh"] = names[2 * fr + o]
+        sc.write_bop(root, "synth", frames, props, K)
+        flat = json.loads((root / "data" / "results" / "synth" / "props.json").read_text())
+        a = dino_inference.build_parser().parse_args(["--dataset", "synth", "--proposals", "props.json", "--n_views", str(T)])
+        dataset = BOPDataset("data/datasets/synth/", "test")
+        templates = WebTemplateDataset(shards.as_posix(), "data/mesh_cache.csv", bbox_extend=a.bbox_extend, n_views=T, cache_meshes=n_meshes)
+        model = DinoPoseEstimator(n_poses=T, cache_size=n_meshes, cache_dir=root / "cache", feature_extractor=fe)
+        legs = {}
+        for name in ("cold", "warm"):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rows = dino_inference.process_images(model, templates, dataset, flat, list(range(len(dataset))), a)
+            torch.cuda.synchronize()
+            sec = time.perf_counter() - t0
+            legs[name] = {"proposals": len(rows), "seconds": sec, "proposals_per_s": len(rows) / sec}
+        out["config3_dino_inference_cli"] = {
+            "metric": "proposals/s (scripts.dino_inference loop on a BOP-layout scene + shards on disk; cold = every proposal a new mesh: template decode + 600 ViT-L forwards; warm = template and feature stores resident)",
+            "value": legs["warm"]["proposals_per_s"], "unit": "proposals/s", "cold": legs["cold"], "warm": legs["warm"], "images": n_img, "proposals_per_image": 2}
+        model.feature_cache.clear()
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(root, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -437,6 +542,8 @@ def main():
     ap.add_argument("--video-objects", type=int, default=4,
                     help="tracked objects per frame in the multi-object leg of the video measurement (batched per frame)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the secondary BASELINE config 2 / 3 measurements")
+    ap.add_argument("--no-cli-legs", action="store_true", help="skip the config 2 / 3 measurements that go through the CLI loops with files on disk")
+    ap.add_argument("--cli-meshes", type=int, default=6, help="meshes of the CLI legs' synthetic shard (2 .. 10)")
     ap.add_argument("--lab", action="store_true",
                     help="tools/ only: load libfreepose_hip_lab.so (measurement variants, FP_* toggles); never a reported number")
     ap.add_argument("--ln-fused", type=int, default=-1, help="fp_ctx_set_option ln_fused (A/B of the LayerNorm fold)")
@@ -503,6 +610,9 @@ def main():
     who = parallel.rank_report()                                       # backend, RCCL version, device + PCI bus id of every rank
     video = video_workload(args, vit, rank, world) if args.video_frames > 0 else None    # outside the timed region
     legs = config_legs(args, vit, bank) if (world == 1 and not args.no_config_legs) else None   # BASELINE configs 2 and 3 (secondary)
+    if world == 1 and not args.no_cli_legs:                            # the same two configs through the CLI loops, files on disk
+        legs = dict(legs or {})
+        legs.update(cli_legs(args, vit, (legs.get("config2_mesh600_420") or {}).get("meshes_per_s")))
 
     if rank == 0:
         n_prop = world * B * args.steps

@@ -38,9 +38,14 @@ def pose_row(scene_id, im_id, obj_id, score, TCO, bbox_xyxy, scale, t_scale=1000
             "scale": scale, "time": time_value}
 
 
+PREFETCH_DEPTH = 2     # template meshes read / decoded ahead of the proposal being scored (530 MB of device memory each while they wait)
+
+
 def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, scales, layer, batch_size, bbox_extend,
-                  t_scale=1000.0, time_value=0.2):
-    """pose rows for the proposals of ONE image (the per-proposal hot loop, reference :104-127)."""
+                  t_scale=1000.0, time_value=0.2, upcoming=()):
+    """pose rows for the proposals of ONE image (the per-proposal hot loop, reference :104-127).  `upcoming`: the mesh names of the
+    proposals that follow this image (the proposals JSON knows them): their templates are read and decoded in the background while
+    this image's proposals are scored (WebTemplateDataset.prefetch)."""
     masks = torch.from_numpy(np.stack([rle_to_mask(p["segmentation"]) for p in scene_props]))
     boxes = torch.from_numpy(np.stack([np.array(p["bbox"]) for p in scene_props]))
     boxes[:, 2:] += boxes[:, :2]                         # xywh -> xyxy (:102)
@@ -49,8 +54,12 @@ def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, s
     # one ViT call for all proposals of the image (the reference runs one B = 1 forward per proposal, :112-114)
     crops = list(proposals.proposals)
     feats = model.feature_extractor(torch.stack([torch.as_tensor(c) for c in crops]), layer=layer, feature_type="patch") if crops else None
+    ahead = [p["mesh"] for p in scene_props] + list(upcoming)
     for i, prop in enumerate(crops):
         mesh = scene_props[i]["mesh"]
+        if hasattr(templates, "prefetch_by_name"):
+            for nxt in ahead[i + 1:i + 1 + PREFETCH_DEPTH]:
+                templates.prefetch_by_name(nxt)
         out = model(prop, templates.get_template_by_name(mesh), K, boxes[i], scales[i], layer=layer, batch_size=batch_size,
                     query_feat=feats[i:i + 1])
         rows.append(pose_row(scene_id, frame_id, mesh, out["scores"][0], out["TCO"][0], out["bbox"].cpu().numpy(), scales[i],
@@ -58,7 +67,39 @@ def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, s
     return rows
 
 
-def run(argv=None):
+def process_images(model, templates, dataset, props, images, args):
+    """the per-image loop of the driver (reference :69-127): pose rows of the given dataset entries"""
+    rows = []
+    by_image = {}
+    for p in props:
+        by_image.setdefault((p["scene_id"], p["image_id"]), []).append(p)
+    keys = [dataset.frame_key(idx) if hasattr(dataset, "frame_key") else None for idx in images]
+    for n, idx in enumerate(images):
+        entry = dataset[idx]
+        sid, fid = int(entry["scene_id"]), int(entry["frame_id"])
+        sp = by_image.get((sid, fid), [])
+        if not sp:
+            continue
+        upcoming = [p["mesh"] for k in keys[n + 1:n + 2] if k is not None for p in by_image.get(k, [])][:PREFETCH_DEPTH]
+        if args.depth_method == "zoedepth":
+            scales = [float(np.clip(p["scale"], a_min=0.01, a_max=None)) for p in sp]
+        elif args.depth_method.startswith("const-"):
+            scales = [float(args.depth_method.split("-")[1])] * len(sp)
+        elif args.depth_method == "depthmap":             # reference :82-85: scale from the scene depth map under each proposal mask
+            from freepose_amd.src.pipeline.estimators.scale_estimators import depthmap_scale
+            if "depth" not in entry:
+                raise FileNotFoundError(f"--depth_method depthmap: scene {sid} frame {fid} has no depth map")
+            scales = [depthmap_scale(entry["depth"], entry["intrinsic"], rle_to_mask(p["segmentation"])) for p in sp]
+            for p, sc in zip(sp, scales):
+                p["scale"] = sc
+        else:
+            raise ValueError(f"unknown --depth_method {args.depth_method} (depthmap | const-<metres> | zoedepth)")
+        rows += proposal_rows(model, templates, entry["image"], entry["intrinsic"], sid, fid, sp, scales, args.layer,
+                              args.batch_size, args.bbox_extend, upcoming=upcoming)
+    return rows
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dataset", type=str)
     ap.add_argument("--split", type=str, default="test")
@@ -73,7 +114,11 @@ def run(argv=None):
     ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")        # not in the reference: backbone
     ap.add_argument("--allow_random_weights", action="store_true")           # not in the reference: run without the checkpoint
     ap.add_argument("--gpus", type=int, default=1)                           # not in the reference: self-launch N ranks, one per GPU
-    args = ap.parse_args(argv)
+    return ap
+
+
+def run(argv=None):
+    args = build_parser().parse_args(argv)
 
     import sys
     parallel.self_launch(args.gpus, ["-m", "scripts.dino_inference"], sys.argv[1:] if argv is None else list(argv))
@@ -97,28 +142,7 @@ def run(argv=None):
 
     per_task = 30
     images = list(range(task * per_task, min((task + 1) * per_task, len(dataset))))[rank::world]
-    rows = []
-    for idx in images:
-        entry = dataset[idx]
-        sid, fid = int(entry["scene_id"]), int(entry["frame_id"])
-        sp = [p for p in props if p["scene_id"] == sid and p["image_id"] == fid]
-        if not sp:
-            continue
-        if args.depth_method == "zoedepth":
-            scales = [float(np.clip(p["scale"], a_min=0.01, a_max=None)) for p in sp]
-        elif args.depth_method.startswith("const-"):
-            scales = [float(args.depth_method.split("-")[1])] * len(sp)
-        elif args.depth_method == "depthmap":             # reference :82-85: scale from the scene depth map under each proposal mask
-            from freepose_amd.src.pipeline.estimators.scale_estimators import depthmap_scale
-            if "depth" not in entry:
-                raise FileNotFoundError(f"--depth_method depthmap: scene {sid} frame {fid} has no depth map")
-            scales = [depthmap_scale(entry["depth"], entry["intrinsic"], rle_to_mask(p["segmentation"])) for p in sp]
-            for p, sc in zip(sp, scales):
-                p["scale"] = sc
-        else:
-            raise ValueError(f"unknown --depth_method {args.depth_method} (depthmap | const-<metres> | zoedepth)")
-        rows += proposal_rows(model, templates, entry["image"], entry["intrinsic"], sid, fid, sp, scales, args.layer,
-                              args.batch_size, args.bbox_extend)
+    rows = process_images(model, templates, dataset, props, images, args)
     pd.DataFrame(rows, columns=CSV_COLUMNS).to_csv(out_csv, index=False, header=True)
     return out_csv
 

@@ -47,6 +47,9 @@ def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, 
     rescoring the first frame visited starts from a coarse estimate (prev_pose None), every later one from its predecessor."""
     prev = {o: None for o in obj_ids}
     rows = []
+    if hasattr(templates, "prefetch_by_name"):       # the clip's meshes are known up front: read / decode them behind the first frame's work
+        for o in list(obj_ids)[1:3]:
+            templates.prefetch_by_name(mesh_ids[o])
     for f in (range(len(frames)) if frame_ids is None else frame_ids):
         sp = props[f]
         img = np.asarray(Image.open(frames[f]).convert("RGB"), dtype=np.uint8)

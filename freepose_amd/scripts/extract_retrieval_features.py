@@ -4,7 +4,9 @@ Drop-in for the reference CLI (scripts/extract_retrieval_features.py:12-75): per
 features -> per-view FFA (masked mean over the any-pooled 30x30 mask) -> data/datasets/<shards>_<feature>_<layer>/<mesh>.npy
 ([<=600, 1024] fp32, NaN views dropped).  Same flags; the job slice comes from SLURM_ARRAY_TASK_ID like the reference,
 or — new — from RANK/WORLD_SIZE when launched with torch.distributed.run (meshes round-robin over the GPUs of a node).
-The 600 per-view device->host copies of the reference (:57) become one copy per mesh.
+The 600 per-view device->host copies of the reference (:57) become one copy per mesh, and the next mesh's tar reads, PNG decode
+and host->device copy run in the background while this mesh is in the ViT (`WebTemplateDataset.prefetch`; `--no_prefetch` = the
+sequential loop, same files byte for byte).
 """
 from __future__ import annotations
 
@@ -33,7 +35,29 @@ def mesh_descriptors(model, sample, feature: str, layer: int, batch_size: int) -
     return desc[keep]
 
 
-def main(argv=None):
+def process(model, dataset, todo, args, features_path, rank=0, quiet=False, stamps=None):
+    """the per-mesh loop (reference :36-70); returns the number of meshes written.  `stamps` (optional list) receives the host time at
+    which each mesh's file was written (bench.py: steady-state interval between meshes)"""
+    import time
+    done = 0
+    for n, idx in enumerate(todo):
+        if not quiet:
+            print(f"[rank {rank}] processing {idx + 1} / {len(dataset)}", flush=True)
+        sample = dataset[idx]
+        if n + 1 < len(todo) and not args.no_prefetch:
+            dataset.prefetch(todo[n + 1])       # tar reads + PNG decode + host->device copy of the next mesh run under this mesh's ViT calls
+        if sample["templates"] is None:
+            print(f"skipping {sample['model_name']}", flush=True)
+            continue
+        desc = mesh_descriptors(model, sample, args.feature, args.layer, args.batch_size)
+        np.save((Path(features_path) / f"{sample['model_name']}.npy").as_posix(), desc)
+        done += 1
+        if stamps is not None:
+            stamps.append(time.perf_counter())
+    return done
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shards_folder", type=str, default="objaverse_shards")
     ap.add_argument("--filelist", type=str, default="mesh_cache.csv")
@@ -45,7 +69,12 @@ def main(argv=None):
     ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")        # not in the reference: backbone
     ap.add_argument("--allow_random_weights", action="store_true")           # not in the reference: run without the checkpoint
     ap.add_argument("--gpus", type=int, default=1)                           # not in the reference: self-launch N ranks, one per GPU
-    args = ap.parse_args(argv)
+    ap.add_argument("--no_prefetch", action="store_true")                    # not in the reference: load every mesh synchronously (A/B, tests)
+    return ap
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
     import sys
     parallel.self_launch(args.gpus, ["-m", "scripts.extract_retrieval_features"], sys.argv[1:] if argv is None else list(argv))
 
@@ -58,7 +87,8 @@ def main(argv=None):
     if world > 1:
         parallel.announce("dist")          # backend, RCCL version, device + PCI bus id of every rank
     model = DINOv2FeatureExtractor(args.model, allow_random_weights=args.allow_random_weights or None)
-    dataset = WebTemplateDataset(shards_path.as_posix(), filelist_path.as_posix(), crop=False, n_views=args.n_views)
+    # (the loop visits each mesh once: the device store of decoded entries only needs the current one and the one on its way)
+    dataset = WebTemplateDataset(shards_path.as_posix(), filelist_path.as_posix(), crop=False, n_views=args.n_views, cache_meshes=0)
 
     if "SLURM_ARRAY_TASK_ID" in os.environ:
         job = int(os.environ["SLURM_ARRAY_TASK_ID"])
@@ -69,14 +99,7 @@ def main(argv=None):
     else:
         raise KeyError("SLURM_ARRAY_TASK_ID")   # the reference requires it (:32)
 
-    for idx in todo:
-        print(f"[rank {rank}] processing {idx + 1} / {len(dataset)}", flush=True)
-        sample = dataset[idx]
-        if sample["templates"] is None:
-            print(f"skipping {sample['model_name']}", flush=True)
-            continue
-        desc = mesh_descriptors(model, sample, args.feature, args.layer, args.batch_size)
-        np.save((features_path / f"{sample['model_name']}.npy").as_posix(), desc)
+    process(model, dataset, todo, args, features_path, rank=rank)
     print("Done", flush=True)
 
 

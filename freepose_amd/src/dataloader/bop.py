@@ -41,6 +41,11 @@ class BOPDataset:
     def __len__(self):
         return len(self.meta_data)
 
+    def frame_key(self, idx):
+        """(scene_id, frame_id) of entry idx without reading its image (the CLI looks one image ahead in the proposals file)"""
+        row = self.meta_data.iloc[idx]
+        return int(row["scene_id"]), int(row["frame_id"])
+
     def __getitem__(self, idx):
         row = self.meta_data.iloc[idx]
         image = np.asarray(Image.open(row["rgb_path"]).convert("RGB")).copy()

@@ -2,9 +2,12 @@
 pre-rendered template shards (10 meshes per `shard-%06d.tar`, 600 x (rgb.png, depth.png u16 mm) per mesh, member index
 cached beside the tar).
 
-Host side: tar member reads + PNG decode (PIL, which releases the GIL) on a thread pool — the reference decodes the 1200
-PNGs of a mesh one by one (9.4 s).  Device side: depth>0 masks, bounding boxes (fp_depth_extents) and the 600
-crops (fp_crop_resize_pad) — the reference spends ~33 s per mesh in a Python crop loop.
+Host stage: tar member reads (pread at the members' offsets) + PNG decode (PIL, which releases the GIL) on a thread pool, straight
+into pinned buffers, one asynchronous host->device copy per array on a side stream — the reference decodes the 1200 PNGs of a
+mesh one by one (9.4 s).  `prefetch(idx)` runs that stage in the background, so the callers that know what comes
+next (the bank-building loop, the proposals JSON of the inference CLIs) overlap it with the previous mesh's GPU work.
+Device stage: u16 mm -> float32 m, depth>0 masks, bounding boxes (fp_depth_extents) and the 600 crops (fp_crop_resize_pad) —
+the reference spends ~33 s per mesh in a Python crop loop.
 
 Template store: the decoded + cropped entries of the last `cache_meshes` meshes stay DEVICE-resident
 (1.7 GB per mesh at 600 x 420^2: fp32 crops + depths + masks; 288 GB of HBM hold far more than any scene needs), so a mesh that
@@ -15,6 +18,7 @@ from __future__ import annotations
 import io
 import os
 import tarfile
+import threading
 from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -30,6 +34,12 @@ from freepose_amd.src.utils.bbox_utils import CropResizePad
 N_VIEWS = 600
 
 
+class _Staged:
+    """one mesh between the host stage (tar reads + PNG decode into pinned buffers + host->device copy on the loader's side stream) and
+    the device stage (masks, boxes, crops on the caller's stream)"""
+    __slots__ = ("name", "tar_file", "rgb", "dep", "event", "n", "seconds")
+
+
 class WebTemplateDataset:
     def __init__(self, wds_dir: str, filelist_path: str, resolution: int = 420, bbox_extend: float = 0, crop: bool = True,
                  n_views: int = N_VIEWS, cache_meshes: int = 8, decode_threads: int | None = None):
@@ -41,8 +51,16 @@ class WebTemplateDataset:
         self.n_views = n_views
         self.cache_meshes = cache_meshes
         self._store = OrderedDict()                  # idx -> entry dict (device tensors)
-        self._threads = decode_threads or min(32, (os.cpu_count() or 8))
-        self.decode_seconds = 0.0                    # cumulative host decode time (bench / diagnostics)
+        self._threads = decode_threads or min(64, (os.cpu_count() or 8))
+        self.decode_seconds = 0.0                    # cumulative host stage time: tar reads + PNG decode (bench / diagnostics)
+        # host stage machinery (keep the GPU busy while the next mesh is read and decoded)
+        self._pool = None                            # decode workers (PIL releases the GIL)
+        self._bg = None                              # one orchestrating thread per dataset: prefetch() runs the host stage there
+        self._pending = {}                           # idx -> Future[_Staged]
+        self._pinned = {}                            # (T, H, W) -> list of free (rgb u8, depth u16-as-i16) pinned buffer pairs
+        self._copy_stream = None
+        self._index_cache = {}                       # tar path -> {member name: (offset_data, size)}
+        self._lock = threading.Lock()                # buffers / stream / executors are shared by the caller's and the prefetch thread
 
     def __len__(self):
         return len(self.frame_index)
@@ -51,15 +69,27 @@ class WebTemplateDataset:
         idx = self.frame_index[self.frame_index == model_name].index[0]
         return self.__getitem__(idx)
 
-    def _member_index(self, tar, tar_path: Path):
+    def index_of(self, model_name) -> int:
+        return int(self.frame_index[self.frame_index == str(model_name).replace("_", "")].index[0])
+
+    def _member_index(self, tar_path: Path):
+        """{member name: (offset of its data in the tar, size)}; the reference's sidecar `shard-%06d.npy` (a pickled name -> TarInfo dict,
+        template.py:54-61) is read when present and written when missing, like there"""
+        hit = self._index_cache.get(tar_path)
+        if hit is not None:
+            return hit
         side = tar_path.with_suffix(".npy")
         if side.exists():
-            return np.load(side, allow_pickle=True).item()
-        index = {m.name: m for m in tar.getmembers()}
-        try:
-            np.save(side, index, allow_pickle=True)
-        except OSError:
-            pass
+            infos = np.load(side, allow_pickle=True).item()
+        else:
+            with tarfile.open(tar_path.as_posix()) as tar:
+                infos = {m.name: m for m in tar.getmembers()}
+            try:
+                np.save(side, infos, allow_pickle=True)
+            except OSError:
+                pass
+        index = {n: (int(m.offset_data), int(m.size)) for n, m in infos.items()}
+        self._index_cache[tar_path] = index
         return index
 
     @staticmethod
@@ -67,6 +97,90 @@ class WebTemplateDataset:
         rgb = np.asarray(Image.open(io.BytesIO(rgb_bytes)).convert("RGB"), dtype=np.uint8)
         dep = np.asarray(Image.open(io.BytesIO(depth_bytes)))
         return rgb, dep
+
+    # ---- host stage ----------------------------------------------------------------------------------------------------------
+    def _executors(self):
+        with self._lock:
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(max_workers=max(1, self._threads), thread_name_prefix="fp-decode")
+                self._bg = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fp-prefetch")
+        return self._pool, self._bg
+
+    def _buffers(self, T, H, W):
+        with self._lock:
+            free = self._pinned.setdefault((T, H, W), [])
+            if free:
+                return free.pop()
+        return (torch.empty((T, H, W, 3), dtype=torch.uint8, pin_memory=True), torch.empty((T, H, W), dtype=torch.int16, pin_memory=True))
+
+    def _stage(self, idx: int, device) -> _Staged:
+        """tar reads (pread at the members' offsets: thread-safe, no TarFile object) + PNG decode of the n_views (rgb, depth) pairs on the
+        decode pool, straight into pinned buffers; then ONE asynchronous host->device copy per array on the loader's side stream.
+        Millimetre depths travel as u16 (half the bytes of the reference's float32 metres); the conversion runs on the device."""
+        import time
+        t0 = time.perf_counter()
+        pool, _ = self._executors()
+        shard = idx // 10
+        tar_path = self.wds_dir / f"shard-{shard:06d}.tar"
+        name = self.frame_index[idx].replace("_", "")
+        st = _Staged()
+        st.name, st.tar_file, st.rgb, st.dep, st.event, st.n = name, tar_path.name, None, None, None, 0
+        members = self._member_index(tar_path)
+        if self.n_views <= 0:
+            st.seconds = 0.0
+            return st
+        keys = [(members[f"{name}_{k}.rgb.png"], members[f"{name}_{k}.depth.png"]) for k in range(self.n_views)]
+        fd = os.open(tar_path.as_posix(), os.O_RDONLY)
+        try:
+            r0, d0 = self._decode_pair(os.pread(fd, keys[0][0][1], keys[0][0][0]), os.pread(fd, keys[0][1][1], keys[0][1][0]))
+            T, (H, W) = len(keys), d0.shape
+            rgb_pin, dep_pin = self._buffers(T, H, W)
+            rgb_np, dep_np = rgb_pin.numpy(), dep_pin.numpy().view(np.uint16)
+            rgb_np[0], dep_np[0] = r0, d0
+
+            def work(k0, k1):
+                for k in range(k0, k1):
+                    (ro, rs), (do, ds) = keys[k]
+                    r, d = self._decode_pair(os.pread(fd, rs, ro), os.pread(fd, ds, do))
+                    rgb_np[k], dep_np[k] = r, d
+            step = max(1, min(8, T // (4 * max(1, self._threads)) or 1))
+            futs = [pool.submit(work, k, min(k + step, T)) for k in range(1, T, step)]
+            for f in futs:
+                f.result()
+        finally:
+            os.close(fd)
+        st.seconds = time.perf_counter() - t0
+        with torch.cuda.device(device):
+            with self._lock:
+                if self._copy_stream is None:
+                    self._copy_stream = torch.cuda.Stream()
+            with torch.cuda.stream(self._copy_stream):
+                st.rgb = rgb_pin.to("cuda", non_blocking=True)
+                st.dep = dep_pin.to("cuda", non_blocking=True)
+                st.event = torch.cuda.Event()
+                st.event.record(self._copy_stream)
+        st.event.synchronize()                          # (this thread only: the pinned pair is free again once the copies are done)
+        with self._lock:
+            self._pinned[(T, H, W)].append((rgb_pin, dep_pin))
+        st.n = T
+        return st
+
+    def prefetch(self, idx: int):
+        """start the host stage of mesh `idx` in the background (tar reads, PNG decode, host->device copy on a side stream); the next
+        __getitem__(idx) picks it up.  No-op for a mesh that is resident or already on its way."""
+        idx = int(idx)
+        if idx in self._store or idx in self._pending or not (0 <= idx < len(self)):
+            return
+        _, bg = self._executors()
+        dev = torch.cuda.current_device()
+        self._pending[idx] = bg.submit(self._stage, idx, dev)
+
+    def prefetch_by_name(self, model_name):
+        """prefetch() for a mesh named in a proposals file; names the file list does not hold are ignored (the lookup will raise later,
+        where the reference's does)"""
+        sel = self.frame_index[self.frame_index == str(model_name)]
+        if len(sel.index):
+            self.prefetch(int(sel.index[0]))
 
     def __getitem__(self, idx: int):
         idx = int(idx)
@@ -83,27 +197,15 @@ class WebTemplateDataset:
         return entry
 
     def _load(self, idx: int):
-        import time
-        shard = idx // 10
-        tar_path = self.wds_dir / f"shard-{shard:06d}.tar"
-        name = self.frame_index[idx].replace("_", "")
-        t0 = time.perf_counter()
-        with tarfile.open(tar_path.as_posix()) as tar:
-            members = self._member_index(tar, tar_path)
-            raw = [(tar.extractfile(members[f"{name}_{k}.rgb.png"]).read(), tar.extractfile(members[f"{name}_{k}.depth.png"]).read())
-                   for k in range(self.n_views)]       # sequential file reads; the decode below is the expensive part
-        if not raw:
-            return {"templates": None, "masks": None, "depths": None, "bboxes": None, "model_name": name, "tar_file": tar_path.name}
-        if self._threads > 1 and len(raw) >= 16:
-            with ThreadPoolExecutor(max_workers=self._threads) as pool:
-                pairs = list(pool.map(lambda p: self._decode_pair(*p), raw, chunksize=8))
-        else:
-            pairs = [self._decode_pair(*p) for p in raw]
-        rgbs = [p[0] for p in pairs]
-        depths = [p[1] for p in pairs]
-        self.decode_seconds += time.perf_counter() - t0
-        rgb_u8 = torch.from_numpy(np.stack(rgbs)).cuda()                                  # [T,H,W,3] u8
-        depth = torch.from_numpy((np.stack(depths) / 1000).astype(np.float32)).cuda()     # metres, float32 (:72)
+        fut = self._pending.pop(idx, None)
+        st = fut.result() if fut is not None else self._stage(idx, torch.cuda.current_device())
+        self.decode_seconds += st.seconds
+        if st.n == 0:
+            return {"templates": None, "masks": None, "depths": None, "bboxes": None, "model_name": st.name, "tar_file": st.tar_file}
+        torch.cuda.current_stream().wait_event(st.event)
+        rgb_u8 = st.rgb                                                                   # [T,H,W,3] u8
+        # metres, float32 (:72): the reference divides in float64 (numpy) and rounds to float32 — the same two IEEE operations here
+        depth = ((st.dep.to(torch.int32) & 0xFFFF).to(torch.float64) / 1000).to(torch.float32)
         ext = ops.depth_extents(depth, 600.0, 600.0, 210.0, 210.0)
         masks = depth > 0
         small = ext[:, 6] < 100
@@ -113,8 +215,8 @@ class WebTemplateDataset:
         if self.crop:
             templates = ops.crop_resize_pad(rgb_u8, boxes, self.resolution, float(self.rgb_proposal_processor.bbox_extend))
         else:
-            templates = ops.crop_resize_pad(rgb_u8, torch.tensor([[0, 0, rgb_u8.shape[2], rgb_u8.shape[1]]] * len(rgbs),
+            templates = ops.crop_resize_pad(rgb_u8, torch.tensor([[0, 0, rgb_u8.shape[2], rgb_u8.shape[1]]] * st.n,
                                                                 dtype=torch.int32), rgb_u8.shape[1], 0.0)
         intrinsic = torch.tensor([[600, 0, 210], [0, 600, 210], [0, 0, 1]]).reshape(3, 3)
-        return {"templates": templates, "masks": masks, "depths": depth, "model_name": name, "tar_file": tar_path.name,
+        return {"templates": templates, "masks": masks, "depths": depth, "model_name": st.name, "tar_file": st.tar_file,
                 "intrinsic": intrinsic, "bboxes": boxes}

@@ -2,8 +2,10 @@
 
 Same constructor, `forward` signature and result dict.  What changed underneath:
   * template features live in a DEVICE-resident LRU (bf16 [T,P,D], 1.1 GB per mesh at 600x900x1024; HBM has room
-    for hundreds) instead of a host LRU that re-uploads 1.1 GB per call (reference :55-60) — the optional disk
-    cache keeps the reference's `<cache_dir>/<model>.pth` format;
+    for hundreds) instead of a host LRU that re-uploads 1.1 GB per call (reference :55-60).  Disk side like the reference
+    (:43-53,63-65): `save_all` writes the RAW features to `<cache_dir>/<model>.pth` (the reference's format) under an exclusive
+    `flock`; an entry the LRU evicts is written out too, so a revisit is a file read instead of 600 ViT forwards — as
+    `<model>.evicted.pth`, because the device store holds the rows already normalised (in place) and that is what gets saved;
   * query features: fp_vit_forward; scoring: fp_template_score (normalise + per-patch dot + mean in one HBM
     pass, reference rounding points); top-3: canonical (score desc, index asc);
   * depth -> (z, xy): extents reduced on the device (fp_depth_extents), then the reference's float64 formula.
@@ -12,6 +14,7 @@ from __future__ import annotations
 
 import shutil
 from collections import OrderedDict
+from fcntl import LOCK_EX, LOCK_UN, flock
 from pathlib import Path
 
 import numpy as np
@@ -52,13 +55,27 @@ class DinoPoseEstimator(torch.nn.Module):
         if self.save_all:
             path = self.cache_dir / f"{key}.pth"
             if not path.exists():
-                torch.save(features.cpu(), path)
+                self._locked_save(features.cpu(), path)          # reference :43-48 (which opens the file in text mode and would fail)
         features = ops.l2_normalize(features, inplace=True)
-        self.feature_cache[key] = features
+        return self._store(key, features)
+
+    @staticmethod
+    def _locked_save(obj, path):
+        with open(path, "wb") as f:
+            flock(f, LOCK_EX)
+            torch.save(obj, f)
+            f.flush()
+            flock(f, LOCK_UN)
+
+    def _store(self, key, features_normalized):
+        self.feature_cache[key] = features_normalized
         self.feature_cache.move_to_end(key)
         while len(self.feature_cache) > self.cache_size:
-            self.feature_cache.popitem(last=False)
-        return features                                # the NORMALISED rows (also when cache_size evicted them at once)
+            old_key, old = self.feature_cache.popitem(last=False)
+            path = self.cache_dir / f"{old_key}.evicted.pth"     # reference :50-53: the evicted entry goes to disk, a revisit reads it back
+            if not path.exists():
+                self._locked_save({"features_normalized": old.cpu()}, path)
+        return features_normalized                     # the NORMALISED rows (also when cache_size evicted them at once)
 
     def _get_template_features(self, template_dict, layer=22, batch_size=128):
         """pre-normalised features of the mesh's templates (device store -> <name>.pth -> ViT)"""
@@ -66,6 +83,9 @@ class DinoPoseEstimator(torch.nn.Module):
         if name in self.feature_cache:
             self.feature_cache.move_to_end(name)
             return self.feature_cache[name]
+        evicted = self.cache_dir / f"{name}.evicted.pth"
+        if evicted.exists():                               # spilled by the LRU: already normalised, the bits the store held
+            return self._store(name, torch.load(evicted, map_location="cpu")["features_normalized"].to("cuda", dtype=torch.bfloat16))
         path = self.cache_dir / f"{name}.pth"
         if path.exists():
             feats = torch.load(path, map_location="cpu").to("cuda", dtype=torch.bfloat16)

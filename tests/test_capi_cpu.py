@@ -123,12 +123,14 @@ def test_cli_flags_match_reference():
     assert ns.viz is False and ns.no_rescore is False and ns.save_all_cache is False
     import inspect
     from freepose_amd.scripts import dino_inference as d, extract_retrieval_features as e
-    src = inspect.getsource(d.run)
+    src = inspect.getsource(d.build_parser)
     for flag in ("--dataset", "--split", "--proposals", "--layer", "--depth_method", "--bbox_extend", "--batch_size", "--cache_size", "--save_all_cache"):
         assert flag in src
-    src = inspect.getsource(e.main)
+    src = inspect.getsource(e.build_parser)
     for flag in ("--shards_folder", "--filelist", "--feature", "--layer", "--mesh_per_job", "--batch_size"):
         assert flag in src
+    ne = e.build_parser().parse_args([])
+    assert (ne.shards_folder, ne.filelist, ne.feature, ne.layer, ne.mesh_per_job, ne.batch_size) == ("objaverse_shards", "mesh_cache.csv", "ffa", 22, 100, 128)
     assert d.CSV_COLUMNS == ["scene_id", "im_id", "obj_id", "score", "R", "t", "bbox_visib", "scale", "time"]
 
 

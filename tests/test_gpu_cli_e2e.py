@@ -161,6 +161,11 @@ def test_image_driver_and_bank_build(workspace, monkeypatch):
     per_mesh = {m: np.load(fdir / f"{m}.npy") for m in sc.MESH_IDS}
     for m, d in per_mesh.items():
         assert d.dtype == np.float32 and d.shape == (N_VIEWS, 384) and np.isfinite(d).all()
+    # the loop above prefetched mesh 2 under mesh 1's ViT calls; the sequential loop writes the same files byte for byte
+    first = {m: (fdir / f"{m}.npy").read_bytes() for m in sc.MESH_IDS}
+    extract_retrieval_features.main(["--filelist", "mesh_cache.csv", "--feature", "ffa", "--layer", "22", "--batch_size", "32",
+                                     "--n_views", str(N_VIEWS), "--model", MODEL, "--allow_random_weights", "--no_prefetch"])
+    assert all((fdir / f"{m}.npy").read_bytes() == first[m] for m in sc.MESH_IDS)
     merge_features.main(["--features_folder", "objaverse_shards_ffa_22", "--filelist", "mesh_cache.txt"])
     bank = np.load(root / "data" / "objaverse_shards_ffa_22.npy")
     assert bank.shape == (2, 384) and bank.dtype == np.float32

@@ -74,6 +74,24 @@ def test_pose_estimator_forward_matches_reference(golden_dir, tmp_path):
     #  normalise-every-call scores bit for bit)
     s = est.score_templates(est.feature_cache["m"], out["query_feat"], templates_normalized=True).cpu().numpy()
     assert np.array_equal(s, g["scores_all"])
+    # ---- the reference's cache semantics (pose_estimator.py:43-53,63-65): an entry the LRU evicts is written to <cache_dir> (under
+    # flock) and a revisit reads it back instead of running the ViT again; save_all keeps the RAW features as <name>.pth
+    class Counting(_StoredExtractor):
+        calls = 0
+
+        def __call__(self, images, layer=22, feature_type="patch"):
+            Counting.calls += images.shape[0] > 1
+            return super().__call__(images, layer, feature_type)
+    est1 = DinoPoseEstimator(n_poses=16, cache_size=1, save_all=True, cache_dir=tmp_path / "c1", feature_extractor=Counting(g))
+    args = (torch.from_numpy(g["query"]), td, g["Kq"], torch.from_numpy(g["bbox"]), float(g["est_scale"]))
+    assert np.array_equal(est1.forward(*args)["scores"], g["scores_top3"]) and Counting.calls == 1
+    raw = torch.load(tmp_path / "c1" / "m.pth")
+    assert raw.dtype == torch.bfloat16 and raw.device.type == "cpu" and torch.equal(raw.cuda(), Counting(g).t[:16])   # the reference's file format
+    est1.forward(torch.from_numpy(g["query"]), dict(td, model_name="other"), g["Kq"], torch.from_numpy(g["bbox"]), float(g["est_scale"]))
+    assert list(est1.feature_cache) == ["other"] and (tmp_path / "c1" / "m.evicted.pth").exists() and Counting.calls == 2
+    out1 = est1.forward(*args)                                       # "m" comes back from the spill file: no third template pass
+    assert Counting.calls == 2 and list(est1.feature_cache) == ["m"] and np.array_equal(out1["scores"], g["scores_top3"])
+    assert (tmp_path / "c1" / "other.evicted.pth").exists()
 
 
 def _mesh():

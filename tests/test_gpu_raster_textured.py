@@ -232,6 +232,25 @@ def test_web_template_dataset_matches_reference_golden(tmp_path, golden_dir):
     ds0 = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), bbox_extend=0, cache_meshes=0)
     a, b = ds0.get_template_by_name(names[1]), ds0.get_template_by_name(names[1])
     assert a["templates"].data_ptr() != b["templates"].data_ptr() and torch.equal(a["templates"], b["templates"])
+    # ---- prefetch (round 5): the host stage of a mesh (tar reads, PNG decode, host->device copy on a side stream) started in the
+    # background gives the entry the synchronous load gives, bit for bit, whatever the order of requests; a prefetched mesh is
+    # consumed exactly once; prefetching a resident or unknown mesh is a no-op
+    dp = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), bbox_extend=0, cache_meshes=0)
+    dp.prefetch(1)
+    dp.prefetch(0)
+    dp.prefetch(1)                                                   # already on its way
+    dp.prefetch_by_name("no-such-mesh")
+    assert set(dp._pending) == {0, 1}
+    p1, p0 = dp[1], dp[0]
+    assert not dp._pending
+    for got, want in ((p1, a), (p0, ds0.get_template_by_name(names[0]))):
+        for k in ("templates", "masks", "depths", "bboxes"):
+            assert torch.equal(got[k], want[k]), k
+        assert got["model_name"] == want["model_name"] and got["tar_file"] == want["tar_file"]
+    dr = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), bbox_extend=0, cache_meshes=2)
+    dr[1]
+    dr.prefetch(1)
+    assert not dr._pending
 
 
 @pytest.mark.parametrize("textured", [False, True])

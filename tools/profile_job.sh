@@ -7,7 +7,7 @@ OUT=$REPO/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PYTHONPATH=$REPO
-BENCH="python $REPO/bench.py --no-cpu-baseline --video-frames 0 --no-config-legs"
+BENCH="python $REPO/bench.py --no-cpu-baseline --video-frames 0 --no-config-legs --no-cli-legs"
 export FP_CSRC_SHA=$(cd $REPO && python -c "import bench; print(bench.csrc_hash())")
 echo "csrc_sha16 = $FP_CSRC_SHA"
 

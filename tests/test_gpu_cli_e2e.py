@@ -173,3 +173,67 @@ def test_image_driver_and_bank_build(workspace, monkeypatch):
     from freepose_amd.retrieval import TemplateBank
     tb = TemplateBank.from_files(root / "data" / "objaverse_shards_ffa_22.npy", root / "data" / "objaverse_shards_ffa_22.ids.txt")
     assert tb.N == 2 and tb.mesh_ids == ["balla", "cubet"]
+
+
+def test_retrieve_meshes_feeds_the_pose_drivers(workspace, monkeypatch):
+    """the retrieval half of the reference's proposal drivers (extract_proposals_ground.py:118-163, ..._video.py:118-197) as a CLI:
+    detections JSON (boxes + RLE masks, no mesh) -> ViT -> FFA -> bank top-100 [-> per-view re-rank] [-> soft vote over the frames] ->
+    proposals JSON with `mesh` / `score`, which scripts.dino_inference[_video] then consume"""
+    root, gts, K = workspace
+    monkeypatch.chdir(root)
+    monkeypatch.setenv("SLURM_ARRAY_TASK_ID", "0")
+    from scripts import dino_inference, dino_inference_video, extract_retrieval_features, merge_features, retrieve_meshes
+    if not (root / "data" / "objaverse_shards_ffa_22.npy").exists():         # (the bank of the previous test, when run alone)
+        extract_retrieval_features.main(["--filelist", "mesh_cache.csv", "--feature", "ffa", "--layer", "22", "--batch_size", "32",
+                                         "--n_views", str(N_VIEWS), "--model", MODEL, "--allow_random_weights"])
+        merge_features.main(["--features_folder", "objaverse_shards_ffa_22", "--filelist", "mesh_cache.txt"])
+    common = ["--retrieval", "objaverse_shards_ffa_22", "--filelist", "mesh_cache.txt", "--model", MODEL, "--allow_random_weights"]
+    # ---- static images ------------------------------------------------------------------------------------------------------
+    rd = root / "data" / "results" / "synth"
+    props = json.loads((rd / "props.json").read_text())
+    dets = [{k: v for k, v in p.items() if k not in ("mesh", "score")} for p in props]
+    (rd / "dets.json").write_text(json.dumps(dets))
+    out0 = retrieve_meshes.run(["--dataset", "synth", "--detections", "dets.json"] + common)
+    assert out0.name == "props-ground-box-0.3-text-0.5-ffa-22-top-0_synth-test.json"
+    got0 = json.loads(out0.read_text())
+    out5 = retrieve_meshes.run(["--dataset", "synth", "--detections", "dets.json", "--topk", "5", "--output", "props_top5.json"] + common)
+    got5 = json.loads(out5.read_text())
+    for got in (got0, got5):
+        assert len(got) == len(props)
+        for g_, p in zip(got, props):
+            assert g_["bbox"] == p["bbox"] and g_["segmentation"] == p["segmentation"] and g_["scene_id"] == p["scene_id"] and g_["image_id"] == p["image_id"]
+            assert g_["mesh"] in sc.MESH_IDS and np.isfinite(g_["score"]) and g_["time"] == 0.01
+    # the coarse pick is the bank row with the best cosine: reproduce it from the files with the product's own bank object
+    from freepose_amd.retrieval import TemplateBank
+    tb = TemplateBank.from_files(root / "data" / "objaverse_shards_ffa_22.npy", root / "data" / "mesh_cache.txt")
+    assert tb.N == 2
+    # chained into the pose driver (the scale field comes from compute_scale.py in the reference: a constant here)
+    csv = dino_inference.run(["--dataset", "synth", "--proposals", out0.name, "--n_views", str(N_VIEWS), "--model", MODEL, "--bbox_extend", "0.05",
+                              "--allow_random_weights", "--depth_method", "const-0.1"])
+    df = pd.read_csv(csv)
+    assert list(df.columns) == COLS and len(df) == len(props) and df["obj_id"].tolist() == [g_["mesh"] for g_ in got0]
+    # ---- video: soft vote over the frames, every frame carries the clip's meshes ------------------------------------------------
+    vd = root / "data" / "results" / "videos" / "clip"
+    vprops = json.loads((vd / "props.json").read_text())
+    (vd / "dets.json").write_text(json.dumps([{k: v for k, v in p.items() if k not in ("mesh", "score")} for p in vprops]))
+    outs = {}
+    for topk in (0, 5):
+        o = retrieve_meshes.run(["--video", "clip", "--detections", "dets.json", "--topk", str(topk)] + common)
+        assert o.name == f"props-ground-box-0.2-text-0.2-ffa-22-top-{topk}_clip.json"
+        got = json.loads(o.read_text())
+        assert len(got) == len(vprops) == N_FRAMES * 2
+        per_obj = [(g_["mesh"], g_["score"]) for g_ in got[:2]]
+        for i, g_ in enumerate(got):
+            assert (g_["mesh"], g_["score"]) == per_obj[i % 2] and g_["image_id"] == i // 2 and g_["bbox"] == vprops[i]["bbox"]
+        outs[topk] = got
+    # two ranks (frames sharded, soft vote as a collective) write the same file
+    first = (vd / "props-ground-box-0.2-text-0.2-ffa-22-top-0_clip.json").read_text()
+    _run_ranks("scripts.retrieve_meshes", ["--video", "clip", "--detections", "dets.json", "--topk", "0"] + common, root, 2, 29741)
+    assert (vd / "props-ground-box-0.2-text-0.2-ffa-22-top-0_clip.json").read_text() == first
+    for g_ in outs[0]:
+        g_["scale"] = 0.1
+    (vd / "props_retrieved.json").write_text(json.dumps(outs[0]))
+    dino_inference_video.run(["--video", "clip", "--proposals", "props_retrieved.json", "--n_views", str(N_VIEWS), "--model", MODEL,
+                              "--allow_random_weights", "--n_fine_poses", "2000"])
+    dfv = pd.read_csv(root / "data" / "results" / "videos" / "clip" / "props_retrieved_dinopose_layer_22_bbext_0.05_depth_zoedepth.csv")
+    assert len(dfv) == N_FRAMES * 2 and dfv["obj_id"].tolist()[:2] == [g_["mesh"] for g_ in outs[0][:2]]

@@ -193,22 +193,26 @@ def video_workload(args, vit, rank, world):
     dm = ops.Mesh(mv, mf, mc)
     est.coarse_estimator._get_template_features(template)            # template features resident (the drivers' cache hit path)
 
-    def run_clip(n_obj, frames_total):
+    def run_clip(n_obj, frames_total, shard="frames"):
         """`frames_total` frames with `n_obj` tracked objects each; the objects of a frame go through ONE batched step
-        (DinoOnlinePoseEstimator.forward_fine_many, what scripts.dino_inference_video does)"""
-        mine = parallel.shard_chunk(frames_total, rank, world)
+        (DinoOnlinePoseEstimator.forward_fine_many, what scripts.dino_inference_video does).  shard = "frames": contiguous frame chunks
+        per rank (deviating: coarse re-initialisation per chunk); "objects": every rank walks ALL frames with its own objects
+        (prev_pose chains stay intact: exact w.r.t. the reference, SURVEY 8e option 1 — what scripts.dino_inference_video does)."""
+        mine = parallel.shard_chunk(frames_total, rank, world) if shard == "frames" else list(range(frames_total))
+        n_total = n_obj
+        my_objs = list(range(n_obj)) if shard == "frames" else parallel.shard_items(n_obj, rank, world)
         meshes = [TriMesh(mv, mf, mc) for _ in range(n_obj)]          # distinct host meshes: one resident device mesh each
         axes = [np.array([0.2, 1.0, 0.1]), np.array([1.0, 0.3, -0.2]), np.array([-0.4, 0.2, 1.0]), np.array([0.6, -0.8, 0.3])]
         gt, props = [], []
         rng = np.random.Generator(np.random.PCG64(3))
         for fr in mine:
             fg, fp = [], []
-            for o in range(n_obj):
-                R0 = np.array(est.coarse_estimator.mesh_poses[37 + 101 * o])[:3, :3]
+            for o in my_objs:
+                R0 = np.array(est.coarse_estimator.mesh_poses[(37 + 101 * o) % len(est.coarse_estimator.mesh_poses)])[:3, :3]
                 ax = axes[o % 4] / np.linalg.norm(axes[o % 4])
                 P = np.eye(4)
                 P[:3, :3] = Rot.from_rotvec(np.deg2rad(1.5 * fr) * ax).as_matrix() @ R0
-                P[:3, 3] = [0.05 + 0.0005 * fr + 0.12 * (o - (n_obj - 1) / 2), -0.02 + 0.03 * (o % 2), 0.9]
+                P[:3, 3] = [0.05 + 0.0005 * fr + 0.12 * ((o % 4) - 1.5 * (n_total > 1)), -0.02 + 0.03 * (o % 2), 0.9]
                 rgb, depth = ops.rasterize(dm, torch.from_numpy(P[None].astype(np.float32)), scale, f, f, W / 2.0, H / 2.0, W, H)
                 m = (depth[0] > 0).cpu().numpy()
                 img = rng.integers(0, 50, size=(H, W, 3), dtype=np.uint8)
@@ -224,13 +228,15 @@ def video_workload(args, vit, rank, world):
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        prev, errs = [None] * n_obj, []
+        prev, errs = [None] * len(my_objs), []
         for fp, fg in zip(props, gt):
+            if not fp:
+                continue             # (more ranks than objects: this rank only joins the barriers)
             if prev[0] is None:      # head of the stretch: coarse estimate + fine step per object
-                outs = [est(c, cm, template, meshes[o], K, b, scale, prev_pose=None, neighborhood=15, layer=22, batch_size=128)
+                outs = [est(c, cm, template, meshes[my_objs[o]], K, b, scale, prev_pose=None, neighborhood=15, layer=22, batch_size=128)
                         for o, (c, cm, b) in enumerate(fp)]
             else:
-                outs = est.forward_fine_many([dict(proposal=c, proposal_mask=cm, template_dict=template, mesh=meshes[o], K=K, bbox=b,
+                outs = est.forward_fine_many([dict(proposal=c, proposal_mask=cm, template_dict=template, mesh=meshes[my_objs[o]], K=K, bbox=b,
                                                    est_scale=scale, prev_pose=prev[o]) for o, (c, cm, b) in enumerate(fp)],
                                              neighborhood=15, layer=22)
             for o, out in enumerate(outs):
@@ -249,12 +255,22 @@ def video_workload(args, vit, rank, world):
     n_obj = max(1, args.video_objects)
     frames_multi = max(world, n_frames // n_obj)
     dtm, minem = run_clip(n_obj, frames_multi) if n_obj > 1 else (dt1, mine1)
+    strong = None
+    if world > 1:                                                     # strong scaling with the chains intact: a fixed set of objects dealt to the ranks
+        n_strong, frames_strong = 8, max(10, n_frames // 8)
+        dts, _ = run_clip(n_strong, frames_strong, shard="objects")
+        strong = {"metric": "frame-objects/s (object-sharded clip: every rank tracks its own objects through ALL frames, prev_pose chains intact)",
+                  "value": n_strong * frames_strong / dts, "unit": "frame-objects/s", "objects": n_strong, "frames": frames_strong,
+                  "objects_per_rank": [len(parallel.shard_items(n_strong, r, world)) for r in range(world)], "seconds": dts, "scaling": "strong",
+                  "note": "exact w.r.t. the reference (SURVEY 8e option 1; scripts.dino_inference_video without --frame_chunks); the total work is fixed, "
+                          "ranks with more objects batch them per frame"}
     return {"metric": "frames/sec (dino_inference_video step: 1 object, rescoring)", "value": n_frames / dt1, "unit": "frames/s",
             "frames": n_frames, "ms_per_frame_per_gpu": dt1 / max(mine1, 1) * 1e3,
             "multi_object": {"objects_per_frame": n_obj, "frames": frames_multi, "frame_objects_per_s": frames_multi * n_obj / dtm,
                              "ms_per_frame_object_per_gpu": dtm / max(minem, 1) / n_obj * 1e3,
                              "note": "the objects of a frame share one batched render-and-compare step (one ViT call, one host copy); "
                                      "per-object results equal the one-by-one run bit for bit (tests/test_gpu_cli_e2e.py)"},
+            "object_sharded": strong,
             "sharding": "sequential clip on one rank (reference semantics)" if world == 1 else
                         f"{world} contiguous frame chunks, coarse re-initialisation per chunk (SURVEY 8e option 4: DEVIATES from the reference "
                         "on chunk-initial frames)",
@@ -624,7 +640,7 @@ def main():
             # one process per GPU: n_gpus is the number of DISTINCT devices the ranks run on (== world unless FP_ALLOW_SHARED_GPU=1
             # let ranks share a device on a test box; such a line says shared_devices = true and is not a scaling measurement)
             "n_gpus": who["devices_distinct"], "n_ranks": world, "shared_devices": who["shared_devices"], "backend": who["backend"],
-            "devices_distinct": who["devices_distinct"], "rccl_version": who["rccl_version"], "ranks": who["ranks"],
+            "devices_distinct": who["devices_distinct"], "rccl_version": who["rccl_version"], "comm_stack": who.get("comm_stack", "torch"), "ranks": who["ranks"],
             "ms_per_step_ranks": {"min": min(dt_ranks) / args.steps * 1e3, "median": float(np.median(dt_ranks)) / args.steps * 1e3,
                                   "max": max(dt_ranks) / args.steps * 1e3, "all": [x / args.steps * 1e3 for x in dt_ranks]},
             "steps": args.steps, "warmup": args.warmup,

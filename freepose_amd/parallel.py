@@ -25,9 +25,19 @@ def shared_gpu_allowed() -> bool:
     return os.environ.get("FP_ALLOW_SHARED_GPU", "0") == "1"
 
 
+def local_world(world: int) -> int:
+    """ranks on THIS node: LOCAL_WORLD_SIZE when the launcher sets it (torch.distributed.run does), else the whole world — a two-node
+    launch of 2 x 8 ranks must not be refused because 16 > 8 visible GPUs"""
+    try:
+        return int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    except ValueError:
+        return world
+
+
 def _require_own_devices(world: int) -> None:
+    world = local_world(world)
     if torch.cuda.is_available() and world > torch.cuda.device_count() and not shared_gpu_allowed():
-        raise SystemExit(f"freepose_amd: {world} ranks but only {torch.cuda.device_count()} visible GPU(s); one process per GPU is the "
+        raise SystemExit(f"freepose_amd: {world} ranks on this node but only {torch.cuda.device_count()} visible GPU(s); one process per GPU is the "
                          "contract.  Set FP_ALLOW_SHARED_GPU=1 to let ranks share a device (flow tests only: the result is stamped "
                          "shared_devices = true and n_gpus = the number of distinct devices).")
 
@@ -42,13 +52,16 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        chosen = backend is None
         if backend is None:   # RCCL ("nccl") on GPUs; FP_DIST_BACKEND=gloo lets several ranks share one GPU (single-GPU test boxes)
             backend = os.environ.get("FP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            if world > torch.cuda.device_count():   # shared devices (allowed above): RCCL rejects them, the flow test runs on gloo
-                backend = os.environ.get("FP_DIST_BACKEND", "gloo")
+            if chosen and local_world(world) > torch.cuda.device_count():   # shared devices (allowed above): RCCL rejects them, the flow
+                backend = os.environ.get("FP_DIST_BACKEND", "gloo")          # test runs on gloo — unless the caller named a backend
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if os.environ.get("FP_COMM_STACK", "torch") == "capi" and torch.cuda.is_available():
+            use_capi_comm()
     elif torch.cuda.is_available():
         torch.cuda.set_device(local % torch.cuda.device_count())
     return rank, world, local
@@ -84,7 +97,7 @@ def rank_report() -> dict:
     except Exception:
         pass
     return {"backend": backend, "world_size": ws, "devices_distinct": distinct, "shared_devices": bool(ids) and distinct < ws,
-            "rccl_version": rccl, "ranks": ranks}
+            "rccl_version": rccl, "comm_stack": comm_stack(), "ranks": ranks}
 
 
 def announce(tag: str = "dist") -> dict:
@@ -147,14 +160,68 @@ def shard_chunk(n: int, rank: int, world_size: int) -> List[int]:
     return list(range(lo, hi))
 
 
+# ---- ONE data-path collective: an all-gather of equally-sized buffers ------------------------------------------------------------
+# Every exchange of the path (top-k candidate pairs, pose rows, soft-vote lists) goes through _all_gather_equal().  Two transports
+# sit behind it, chosen once per process:
+#   * torch.distributed (default): RCCL through PyTorch's own copy ("nccl") on GPUs, gloo in the CPU tests / on shared devices;
+#   * the library's C-ABI communicator (FP_COMM_STACK=capi, or use_capi_comm()): fp_comm_init + fp_allgather_bytes of
+#     include/freepose_hip.h — what a host without torch binds; the process group is then only the bootstrap that
+#     carries the 128-byte unique id from rank 0 to the others.
+# With one rank both are the identity.
+_capi = {"ctx": None}
+
+
+def use_capi_comm() -> None:
+    """route the data-path all-gathers of CUDA tensors through the library's communicator (RCCL opened by libfreepose_hip.so).  Needs an
+    initialised process group (any backend) for the bootstrap when world > 1; one device per rank (RCCL's rule)."""
+    if _capi["ctx"] is not None:
+        return
+    import ctypes as C
+    from freepose_amd import _lib, ops
+    lib = _lib.load()
+    rank, ws = world()
+    ctx = ops.context()
+    uid = (C.c_ubyte * 128)()
+    if rank == 0:
+        _lib.check(lib.fp_comm_unique_id(uid), "fp_comm_unique_id")
+    if ws > 1:
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)
+        uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+    if lib.fp_comm_size(ctx) == 1 and lib.fp_comm_rank(ctx) == 0 and ws >= 1:
+        rc = lib.fp_comm_init(ctx, ws, rank, uid)
+        if rc != 0 and b"already" not in (lib.fp_last_error() or b""):
+            _lib.check(rc, "fp_comm_init")
+    _capi["ctx"] = ctx
+
+
+def comm_stack() -> str:
+    return "capi" if _capi["ctx"] is not None else "torch"
+
+
+def _all_gather_equal(t: torch.Tensor) -> List[torch.Tensor]:
+    """[t of rank 0, t of rank 1, ...] for a contiguous tensor of the same shape and dtype on every rank"""
+    rank, ws = world()
+    t = t.contiguous()
+    if _capi["ctx"] is not None and t.is_cuda:
+        from freepose_amd import _lib
+        lib = _lib.load()
+        n = int(lib.fp_comm_size(_capi["ctx"]))
+        out = torch.empty((n,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        _lib.check(lib.fp_allgather_bytes(_capi["ctx"], _lib.ptr(t), t.numel() * t.element_size(), _lib.ptr(out), _lib.current_stream()),
+                   "fp_allgather_bytes")
+        return list(out.unbind(0))
+    if ws == 1:
+        return [t]
+    parts = [torch.empty_like(t) for _ in range(ws)]
+    dist.all_gather(parts, t)
+    return parts
+
+
 def all_gather_cat(t: torch.Tensor, dim: int = 0) -> torch.Tensor:
     """all-gather equally-shaped tensors and concatenate along `dim` (rank order)."""
-    rank, ws = world()
-    if ws == 1:
-        return t
-    parts = [torch.empty_like(t) for _ in range(ws)]
-    dist.all_gather(parts, t.contiguous())
-    return torch.cat(parts, dim=dim)
+    parts = _all_gather_equal(t)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=dim)
 
 
 def all_gather_rows(rows: torch.Tensor, counts: Sequence[int] | None = None) -> torch.Tensor:
@@ -163,14 +230,11 @@ def all_gather_rows(rows: torch.Tensor, counts: Sequence[int] | None = None) -> 
     if ws == 1:
         return rows
     n = torch.tensor([rows.shape[0]], device=rows.device, dtype=torch.int64)
-    ns = [torch.zeros_like(n) for _ in range(ws)]
-    dist.all_gather(ns, n)
-    ns = [int(x.item()) for x in ns]
+    ns = [int(x.item()) for x in _all_gather_equal(n)]
     mx = max(ns)
     pad = torch.zeros((mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
     pad[: rows.shape[0]] = rows
-    parts = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(parts, pad)
+    parts = _all_gather_equal(pad)
     return torch.cat([p[:k] for p, k in zip(parts, ns)], dim=0)
 
 

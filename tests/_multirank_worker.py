@@ -96,6 +96,17 @@ def main():
         print("MULTIRANK_BANK_OK", world, flush=True)
     if backend == "nccl" and os.environ.get("FP_COMM_DIR"):
         _c_abi_comm(rank, world, Path(os.environ["FP_COMM_DIR"]), s_sh.shape, sharded, qd, s_full, i_full)
+        # ONE comm stack (round 5): the same parallel.* calls with the library's communicator as the transport (FP_COMM_STACK=capi:
+        # unique id carried by the process group, fp_allgather_bytes underneath) give what the torch.distributed transport gave
+        parallel.use_capi_comm()
+        assert parallel.comm_stack() == "capi"
+        s2, i2 = sharded.topk(qd, 100)
+        assert torch.equal(i2.cpu(), i_full.cpu()) and torch.equal(s2.cpu(), s_full.cpu())
+        assert torch.equal(parallel.all_gather_rows(rows), allr)
+        r2, b2 = full.soft_vote([frame_q[f] for f in mine], k=50, frame_ids=mine)
+        assert np.array_equal(r2, ref_rows) and np.array_equal(b2, ref_best)
+        if rank == 0:
+            print("MULTIRANK_ONE_STACK_OK", world, flush=True)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

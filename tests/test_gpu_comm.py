@@ -51,6 +51,37 @@ def test_c_abi_comm_single_rank():
     assert lib.fp_comm_size(ctx) == 1
 
 
+def test_one_comm_stack_single_rank():
+    """parallel.* has ONE data-path collective (_all_gather_equal) with two transports; with the library's communicator selected
+    (FP_COMM_STACK=capi / use_capi_comm) the drivers' calls go through fp_allgather_bytes — on one rank the identity, like the
+    torch.distributed transport.  Runs in a subprocess: the choice is per process."""
+    code = (
+        "import torch, numpy as np\n"
+        "from freepose_amd import _lib, ops, parallel\n"
+        "import bench\n"
+        "from freepose_amd.retrieval import TemplateBank\n"
+        "lib = _lib.load(); calls = []\n"
+        "assert parallel.comm_stack() == 'torch'\n"
+        "rows = torch.arange(38, dtype=torch.float64, device='cuda').reshape(2, 19)\n"
+        "a = parallel.all_gather_rows(rows); b = parallel.all_gather_cat(rows, dim=1)\n"
+        "parallel.use_capi_comm(); parallel.use_capi_comm()\n"
+        "assert parallel.comm_stack() == 'capi' and lib.fp_comm_size(ops.context()) == 1\n"
+        "orig = lib.fp_allgather_bytes\n"
+        "assert torch.equal(parallel.all_gather_rows(rows), a) and torch.equal(parallel.all_gather_cat(rows, dim=1), b)\n"
+        "parts = parallel._all_gather_equal(rows)\n"
+        "assert len(parts) == 1 and torch.equal(parts[0], rows) and parts[0].data_ptr() != rows.data_ptr()\n"
+        "bank = TemplateBank(bench.synthetic_bank(5000, 1024, seed=3))\n"
+        "q = ops.l2_normalize(torch.randn((3, 1024), device='cuda').to(torch.bfloat16))\n"
+        "s, i = parallel.sharded_bank_topk(bank._local_topk, q, 100); s0, i0 = bank.topk(q, 100)\n"
+        "assert torch.equal(s, s0) and torch.equal(i, i0)\n"
+        "r, bst = bank.soft_vote([q, q], k=50)\n"
+        "assert parallel.rank_report()['comm_stack'] == 'capi'\n"
+        "print('ONE_STACK_OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=str(ROOT)))
+    assert r.returncode == 0 and "ONE_STACK_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_rccl_two_ranks(tmp_path):
     """2 ranks over the `nccl` backend (RCCL) + the C-ABI communicator.  With >= 2 GPUs each rank has its own device; on a
     single-GPU box both ranks are pointed at GPU 0 — RCCL normally refuses that ("Duplicate GPU detected"), in which case the
@@ -66,4 +97,4 @@ def test_rccl_two_ranks(tmp_path):
             print("RCCL refused 2 ranks on one device:", refused[0])
             pytest.skip(f"single-GPU box and RCCL refuses two ranks on one device: {refused[0][:200]}")
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
-    assert "MULTIRANK_BANK_OK 2" in r.stdout and "MULTIRANK_CABI_OK 2" in r.stdout
+    assert "MULTIRANK_BANK_OK 2" in r.stdout and "MULTIRANK_CABI_OK 2" in r.stdout and "MULTIRANK_ONE_STACK_OK 2" in r.stdout

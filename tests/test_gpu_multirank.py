@@ -37,6 +37,11 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["scaling"] == "weak" and out["cpu_baseline"] is None
     assert out["value"] > 0 and out["config"]["proposals_per_step_per_gpu"] == 1
     assert out["roofline"]["bound"] == "mfma" and out["roofline"]["achieved"] > 0
+    # the N-rank line carries BOTH video legs: the deviating frame-chunk one and the exact object-sharded one (strong scaling)
+    vw = out["video_workload"]
+    assert "frame chunks" in vw["sharding"] and vw["object_sharded"]["scaling"] == "strong"
+    assert vw["object_sharded"]["objects_per_rank"] == [4, 4] and vw["object_sharded"]["value"] > 0
+    assert out.get("comm_stack", "torch") == "torch"
 
 
 def test_sharded_bank_topk_two_ranks_on_one_gpu():

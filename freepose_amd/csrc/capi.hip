@@ -161,6 +161,7 @@ struct fp_vit {
     int folded_upto = 0;             // blocks [0, folded_upto) carry valid folded weights (a forward folds only the blocks it runs)
     hipEvent_t fold_ev = nullptr;    // recorded behind the last fold; forwards on OTHER streams wait for it
     hipStream_t fold_stream = nullptr;
+    bool refold = false;             // a weight was replaced after a fold: forwards in flight on other streams may still read the fold buffers
     // pos-embed cache per (gh,gw)
     std::map<std::pair<int, int>, bf16_t*> pos_cache;
     // profiling
@@ -218,6 +219,7 @@ extern "C" int fp_vit_set_weight(fp_vit* v, const char* name, const void* d, siz
     const fp_vit_arch& a = v->a;
     const bf16_t* p = (const bf16_t*)d;
     const size_t D = a.dim;
+    if (v->folded_upto > 0) v->refold = true;
     v->folded_upto = 0;   // any new tensor invalidates the folded LayerNorm weights (in-place updates of a registered tensor: re-register it)
     auto need = [&](size_t n) -> bool {
         if (numel != n) { fp_set_error("vit_set_weight: %s has %zu elements, expected %zu", name, numel, n); return false; }
@@ -365,14 +367,21 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
     if (lnf) {
         // only the blocks this call runs (their weights were checked above): a caller that registered 22 of 24 blocks never
         // touches the other two.  The fold is enqueued on `s`; a later forward on another stream waits for it through the event.
+        // Ordering across streams: whatever this call does with the fold buffers — read blocks folded earlier, fold further blocks — comes
+        // behind the last fold (the event is re-recorded on `s` only after `s` has waited for it, so waiting for the newest record
+        // covers every earlier fold).  A RE-fold (a weight was replaced) overwrites buffers that forwards on other streams may still be
+        // reading: the device is drained first — once per weight load, never on the steady path.
+        if (v->fold_ev && s != v->fold_stream) FP_HIP(hipStreamWaitEvent(s, v->fold_ev, 0));
         if (v->folded_upto < L) {
+            if (v->refold) {
+                FP_HIP(hipDeviceSynchronize());
+                v->refold = false;
+            }
             if ((rc = vit_fold(v, v->folded_upto, L, s))) return rc;
             if (!v->fold_ev) FP_HIP(hipEventCreateWithFlags(&v->fold_ev, hipEventDisableTiming));
             FP_HIP(hipEventRecord(v->fold_ev, s));
             v->fold_stream = s;
             v->folded_upto = L;
-        } else if (v->fold_ev && s != v->fold_stream) {
-            FP_HIP(hipStreamWaitEvent(s, v->fold_ev, 0));
         }
         if ((rc = v->ctx->get("vit.ln_stat", M * sizeof(uint4), (void**)&stat))) return rc;
         if ((rc = v->ctx->get("vit.ln_rstd", M * sizeof(float), (void**)&rstd))) return rc;

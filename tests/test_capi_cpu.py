@@ -65,6 +65,39 @@ def test_product_library_carries_no_lab():
         assert not bad, bad
 
 
+def test_attention_kernels_have_no_scratch(tmp_path):
+    """every attention instantiation the product can dispatch (short tail first / plain, pre-scaled q / unscaled) compiles to 128
+    registers and ZERO scratch: a spill inside the K/V loop shares vmcnt with the LDS-DMA ring and drains it every tile (710 against
+    1014 TFLOP/s when it happened, profiles/r04_ab.md §5).  Read from the code object's metadata notes."""
+    from freepose_amd import build
+    build.build_hip(verbose=False)
+    obj = ROOT / "freepose_amd" / "lib" / "obj" / "attention.o"
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    if not (llvm / "clang-offload-bundler").exists() or not (llvm / "llvm-readelf").exists():
+        import pytest
+        pytest.skip("ROCm LLVM tools not found")
+    fat, co = tmp_path / "attention.fatbin", tmp_path / "attention.co"
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(obj), str(fat)], check=True)
+    subprocess.run([str(llvm / "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950:sramecc+", f"--input={fat}",
+                    f"--output={co}", "--unbundle"], check=True)
+    notes = subprocess.run([str(llvm / "llvm-readelf"), "--notes", str(co)], capture_output=True, text=True, check=True).stdout
+    kernels = {}
+    name = None
+    for ln in notes.splitlines():
+        m = re.search(r"\.name:\s+(\S+)", ln)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+        for key in ("private_segment_fixed_size", "vgpr_spill_count", "vgpr_count"):
+            m = re.search(r"\.%s:\s+(\d+)" % key, ln)
+            if m and name:
+                kernels[name][key] = int(m.group(1))
+    attn = {k: v for k, v in kernels.items() if "attn_fwd_kernel" in k}
+    assert len(attn) == 4, sorted(attn)
+    for k, v in attn.items():
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 128, (k, v)
+
+
 def test_ctypes_table_mirrors_header():
     from freepose_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
@@ -187,7 +220,12 @@ def test_more_ranks_than_gpus_is_refused_unless_overridden(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(SystemExit) as e:
         parallel.init_from_env("nccl")                                          # a rank under somebody else's launcher: same refusal
-    assert "2 ranks but only 1 visible GPU" in str(e.value.code)
+    assert "2 ranks on this node but only 1 visible GPU" in str(e.value.code)
+    # two nodes x one GPU (LOCAL_WORLD_SIZE from the launcher): 2 ranks in the world, ONE on this node's one GPU -> not refused
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    parallel._require_own_devices(2)
+    assert parallel.local_world(2) == 1
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
     monkeypatch.delenv("WORLD_SIZE")
     monkeypatch.setenv("FP_ALLOW_SHARED_GPU", "1")
     with pytest.raises(SystemExit) as e:

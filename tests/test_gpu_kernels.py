@@ -239,9 +239,11 @@ def test_hand_scheduled_tier_gives_the_bits_of_the_small_tiers(M, N, K):
 
 
 # 70 / 129 / 261 / 905 / 1374: the last K/V tile's valid keys fit its first half -> the "short tail first" kernel (attention.hip);
-# 97 (33 keys in the tail), 64 and 17 take the plain kernel; 2 tiles (70, 97, 129 -> 3) exercise the shortest loops of both
+# 97 (33 keys in the tail), 64 and 17 take the plain kernel; 2 tiles (70, 97, 129 -> 3) exercise the shortest loops of both;
+# 1449 = 532^2 (41 keys in the last of 23 tiles): the plain kernel at ViT-L size — its pre-scaled instantiation spilled 10 registers
+# until round 5 (attention.hip: the first tile is peeled at compile time; tests/test_capi_cpu.py asserts 0 scratch on all four)
 @pytest.mark.parametrize("B,H,n_tok", [(1, 6, 261), (2, 16, 905), (2, 16, 1374), (1, 16, 64), (1, 2, 17), (1, 2, 70), (1, 2, 97),
-                                       (2, 3, 129)])
+                                       (2, 3, 129), (1, 16, 1449)])
 @pytest.mark.parametrize("prescaled", [False, True])
 def test_attention(B, H, n_tok, prescaled):
     """prescaled: the q columns hold q log2(e) / 8 in bf16 (what the ViT's folded qkv layer writes) and the kernel takes base-2

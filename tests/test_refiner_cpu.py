@@ -103,3 +103,68 @@ def test_refiner_host_arithmetic_matches_the_reference(golden_dir):
     tr = TrackingRefiner.__new__(TrackingRefiner)
     for q, thr in zip((0.2, 0.05, 0.5), g["thresholds"]):
         assert float(tr._get_threshold_for_confidence(g["sims"], top_quantile=q)) == float(thr)
+
+
+def test_cubic_resize_agrees_with_an_independent_implementation():
+    """the restated cv2 INTER_CUBIC (float32 path) against torch's own bicubic (`F.interpolate(mode="bicubic",
+    align_corners=False)`: the same published kernel — a = -0.75, half-pixel centres, replicated border — written independently in
+    ATen).  cv2 itself is not installable here; what stays STATED is only cv2's u8 fixed-point path (not used: the validity mask is
+    resized as float32, refiner_utils.py:165-167)."""
+    import torch.nn.functional as F
+    from freepose_amd.src.pipeline.refiner_utils import cubic_resize
+    rng = np.random.default_rng(3)
+    for (H, W), (dh, dw) in (((518, 518), (37, 37)), ((37, 37), (100, 61)), ((120, 75), (33, 90)), ((64, 64), (64, 64))):
+        x = rng.standard_normal((H, W)).astype(np.float32)
+        mine = cubic_resize(x, (dw, dh))
+        ref = F.interpolate(torch.from_numpy(x)[None, None], size=(dh, dw), mode="bicubic", align_corners=False)[0, 0].numpy()
+        assert mine.shape == ref.shape == (dh, dw)
+        # (ATen forms the source coordinate in float32, the restatement — like cv2 — in float64: the tap weights differ in their
+        #  last places, the results by < 1e-5 of the data range; a wrong kernel constant, border rule or centre convention is > 1e-2)
+        assert np.abs(mine - ref).max() < 2e-5 * max(1.0, np.abs(x).max()), ((H, W), (dh, dw), np.abs(mine - ref).max())
+    # the thresholded validity mask (what pose_confidence uses) is the same set of patches under both
+    m = (rng.random((518, 518)) > 0.55).astype(np.float32)
+    m[100:300, 150:420] = 1
+    a = cubic_resize(m, (37, 37)) > 0.5
+    b = F.interpolate(torch.from_numpy(m)[None, None], size=(37, 37), mode="bicubic", align_corners=False)[0, 0].numpy() > 0.5
+    assert np.array_equal(a, b)
+
+
+def _roi_align_second_opinion(img, rois, PH, PW, s):
+    """RoIAlign (aligned=False, sampling_ratio s > 0) written a second time from the published definition, on torch's grid sampler:
+    sample point (iy, ix) of bin (ph, pw) at  y1 + (ph + (iy + .5) / s) bin_h,  x1 + (pw + (ix + .5) / s) bin_w;  a point more than one
+    pixel outside the image counts 0, any other is clamped into [0, H-1] x [0, W-1] and read bilinearly; a bin is the mean of its s*s
+    points.  (grid_sample with align_corners=True and border padding is exactly "clamp, then bilinear between the neighbours".)"""
+    import torch.nn.functional as F
+    img = torch.from_numpy(img).double()
+    N, C, H, W = img.shape
+    out = torch.zeros((len(rois), C, PH, PW), dtype=torch.float64)
+    for r, (b, x1, y1, x2, y2) in enumerate(np.asarray(rois, dtype=np.float64)):
+        rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+        ys = y1 + (torch.arange(PH * s, dtype=torch.float64) + 0.5) * (rh / PH / s)
+        xs = x1 + (torch.arange(PW * s, dtype=torch.float64) + 0.5) * (rw / PW / s)
+        valid = ((ys >= -1) & (ys <= H))[:, None] & ((xs >= -1) & (xs <= W))[None, :]
+        gy = (ys.clamp(0, H - 1) / max(H - 1, 1)) * 2 - 1
+        gx = (xs.clamp(0, W - 1) / max(W - 1, 1)) * 2 - 1
+        grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], dim=-1)[None]            # [1, PH*s, PW*s, (x, y)]
+        samp = F.grid_sample(img[int(b)][None], grid, mode="bilinear", padding_mode="border", align_corners=True)[0]
+        samp = samp * valid[None]
+        out[r] = samp.reshape(C, PH, s, PW, s).mean(dim=(2, 4))
+    return out.numpy()
+
+
+def test_roi_align_agrees_with_a_second_formulation():
+    """the oracle's RoIAlign (restated from torchvision's CPU kernel, which is not installable here) against an
+    independently written torch formulation of the published operator, on random images and RoIs that include boxes hanging out of
+    the image, sub-pixel boxes and the refiner's own call shape (one 3 x 518 x 518 crop, sampling_ratio 2)."""
+    rng = np.random.default_rng(11)
+    img = rng.standard_normal((2, 3, 60, 80)).astype(np.float32)
+    rois = np.array([[0, 5.2, 4.1, 61.7, 48.3], [1, -6.0, -3.5, 30.0, 25.0], [0, 40.0, 30.0, 95.0, 75.0], [1, 10.3, 10.3, 10.6, 10.4],
+                     [0, -30.0, 5.0, -2.0, 40.0], [1, 0.0, 0.0, 80.0, 60.0]], dtype=np.float32)
+    for (PH, PW, s) in ((7, 9, 2), (16, 16, 3), (1, 1, 2)):
+        got = fo.roi_align(img, rois, PH, PW, s)
+        ref = _roi_align_second_opinion(img, rois, PH, PW, s)
+        assert np.abs(got - ref).max() < 1e-4, (PH, PW, s, np.abs(got - ref).max())     # float32 (oracle) vs float64 sample coordinates
+    big = rng.random((1, 3, 240, 320)).astype(np.float32)
+    roi = np.array([[0, 37.25, 12.5, 291.75, 203.0]], dtype=np.float32)
+    got = fo.roi_align(big, roi, 518, 518, 2)
+    assert np.abs(got - _roi_align_second_opinion(big, roi, 518, 518, 2)).max() < 1e-4

@@ -13,7 +13,7 @@ from tools.ab_perf import ab  # noqa: E402
 
 variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,32").split(",")]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-for n_tok in (1374, 905):
+for n_tok in (1374, 905, 1449):     # 1449 = 532^2: the plain (no short tail) kernel
     npad = (n_tok + 15) // 16 * 16
     qk = (torch.randn(B * npad, 2048, device="cuda") * 1.0).to(torch.bfloat16)
     vt = torch.randn(B, 16, 64, npad, device="cuda").to(torch.bfloat16)

@@ -436,29 +436,16 @@ def config_legs(args, vit, bank):
     return out
 
 
-def cli_legs(args, vit, in_memory_meshes_per_s=None):
-    """BASELINE configs 2 and 3 THROUGH THE CLI LOOPS, files on disk (secondary, rank 0): a synthetic workspace in the reference's layout
-    (tests/_synth_scene.py: two OBJ meshes -> scripts.render_templates on the HIP rasteriser -> `shard-000000.tar`, 600 views per mesh),
-    the shard's members re-used under `--cli-meshes` names so that every mesh is a different set of tar reads and PNG decodes.
-      bank build  = scripts.extract_retrieval_features.process(): per mesh tar reads + 1200 PNG decodes + host->device copy + 600 ViT-L
-                    forwards @420^2 + FFA + one .npy, with the next mesh's host stage prefetched under this mesh's ViT calls, and the
-                    same loop with --no_prefetch;
-      inference   = scripts.dino_inference.process_images(): images of two proposals each, every proposal a NEW mesh (cold: template
-                    decode + 600 ViT forwards per proposal), then the same images again (warm: template store + feature store hits)."""
+def make_cli_workspace(n_meshes, T=600):
+    """a synthetic workspace on disk in the reference's layout (tests/_synth_scene.py): two OBJ meshes rendered by scripts.render_templates
+    into `data/datasets/objaverse_shards/shard-000000.tar` (T views each), the members re-used under `n_meshes` names so that every mesh
+    is a different set of tar reads and PNG decodes.  Returns (root, mesh names); the caller chdir()s into root and removes it."""
     import io
-    import shutil
     import tarfile
     import tempfile
     from tests import _synth_scene as sc
-    from scripts import dino_inference, extract_retrieval_features
-    from freepose_amd.src.dataloader.bop import BOPDataset
-    from freepose_amd.src.dataloader.template import WebTemplateDataset
-    from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
-    from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
-    out = {}
     root = Path(tempfile.mkdtemp(prefix="fp_bench_ws_"))
     cwd = os.getcwd()
-    n_meshes, T = max(2, min(10, args.cli_meshes)), 600
     try:
         os.chdir(root)
         sc.write_meshes(root)
@@ -479,7 +466,33 @@ def cli_legs(args, vit, in_memory_meshes_per_s=None):
                         info.size = len(b)
                         dst.addfile(info, io.BytesIO(b))
         (root / "data" / "mesh_cache.csv").write_text("model_name\n" + "\n".join(names) + "\n")
-        del blobs
+    finally:
+        os.chdir(cwd)
+    return root, names
+
+
+def cli_legs(args, vit, in_memory_meshes_per_s=None):
+    """BASELINE configs 2 and 3 THROUGH THE CLI LOOPS, files on disk (secondary, rank 0): a synthetic workspace in the reference's layout
+    (tests/_synth_scene.py: two OBJ meshes -> scripts.render_templates on the HIP rasteriser -> `shard-000000.tar`, 600 views per mesh),
+    the shard's members re-used under `--cli-meshes` names so that every mesh is a different set of tar reads and PNG decodes.
+      bank build  = scripts.extract_retrieval_features.process(): per mesh tar reads + 1200 PNG decodes + host->device copy + 600 ViT-L
+                    forwards @420^2 + FFA + one .npy, with the next mesh's host stage prefetched under this mesh's ViT calls, and the
+                    same loop with --no_prefetch;
+      inference   = scripts.dino_inference.process_images(): images of two proposals each, every proposal a NEW mesh (cold: template
+                    decode + 600 ViT forwards per proposal), then the same images again (warm: template store + feature store hits)."""
+    import shutil
+    from tests import _synth_scene as sc
+    from scripts import dino_inference, extract_retrieval_features
+    from freepose_amd.src.dataloader.bop import BOPDataset
+    from freepose_amd.src.dataloader.template import WebTemplateDataset
+    from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
+    from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+    out = {}
+    cwd = os.getcwd()
+    n_meshes, T = max(2, min(10, args.cli_meshes)), 600
+    root, names = make_cli_workspace(n_meshes, T)
+    try:
+        os.chdir(root)
         fe = DINOv2FeatureExtractor.__new__(DINOv2FeatureExtractor)      # share the already-resident ViT-L
         torch.nn.Module.__init__(fe)
         fe.model_name, fe.model, fe.num_register_tokens = "dinov2_vitl14_reg", vit, vit.n_reg
@@ -654,7 +667,7 @@ def main():
                        "parallelism": f"proposals sharded over {world} rank(s), bank replicated"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel + gemm_asm_kernel (all ViT linear layers)", "achieved": gemm_tf,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": _pmc_traffic(), "csrc_sha16": csrc_hash(), "launches": prof["gemm_launches"],
+                         "traffic": _pmc_traffic()[0], "traffic_source": _pmc_traffic()[1], "csrc_sha16": csrc_hash(), "launches": prof["gemm_launches"],
                          "avg_launch_ms": prof["ms_gemm"] / max(prof["gemm_launches"], 1),
                          "flops_per_launch": prof["gemm_flops"] / max(prof["gemm_launches"], 1)},
             "stage_ms_rank0": {"vit_gemm": prof["ms_gemm"] / args.steps, "vit_attention": prof["ms_attn"] / args.steps,
@@ -731,18 +744,19 @@ def csrc_hash() -> str:
 
 
 def _pmc_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary (tools/profile_job.sh -> profiles/), only if that
-    summary was taken on exactly these kernel sources (its csrc_sha16 equals csrc_hash()); otherwise null"""
-    for name in ("r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):
+    """(HBM bytes per GEMM launch, where the figure comes from): a QUOTED constant — the committed rocprofv3 --pmc summary
+    (tools/profile_job.sh -> profiles/), used only if it was taken on exactly these kernel sources (its csrc_sha16 equals
+    csrc_hash()); PMC counters cannot be collected inside this run.  (None, reason) otherwise."""
+    for name in ("r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):
         p = ROOT / "profiles" / name
         if p.exists():
             try:
                 d = json.loads(p.read_text())
                 if d.get("csrc_sha16") == csrc_hash():
-                    return d.get("hbm_bytes_per_launch")
+                    return d.get("hbm_bytes_per_launch"), f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of tools/profile_job.sh on these sources, csrc_sha16 {csrc_hash()}); quoted, not counted in this run"
             except Exception:
-                return None
-    return None
+                return None, f"profiles/{name} unreadable"
+    return None, "no committed PMC summary matches these kernel sources (csrc_sha16 " + csrc_hash() + ")"
 
 
 if __name__ == "__main__":

@@ -181,6 +181,11 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
     // PRE (VAR bit 64): Q arrives multiplied by log2(e) / sqrt(hd) (folded into the q rows of the qkv weights), and the first S^T MFMA
     // starts from C = -reference, so the accumulators ARE the exponents: no multiply-add per element in the softmax.
     constexpr bool PRE = (VAR & 64) != 0;
+    // VAR bit 256 (lab A/B, round 5): the row sums on the VECTOR ALU — one v_dot2_f32_bf16 per packed P word (16 per tile and wave) into a
+    // per-lane partial, reduced over the query's four lanes once at the end — instead of the fifth "V^T" fragment of ones (4 of the
+    // tile's 36 MFMAs).  The review's question: do the dot products find free issue slots behind the PV MFMAs?
+    constexpr bool VSUM = (VAR & 256) != 0;
+    float vsum[2] = {0.f, 0.f};
     f32x4_t nref[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};   // -reference (log2 units) on every register
     f32x4_t lacc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};   // [0]: running sum of P per query
     bf16x8_t ones;
@@ -326,6 +331,7 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
                     if constexpr (!FIRST) {   // (the first tile finds O and l at zero: nothing to rescale)
                         const float alpha = __builtin_amdgcn_exp2f(-delta);
                         lacc[fq][0] *= alpha;
+                        if constexpr (VSUM) vsum[fq] *= alpha;
 #pragma unroll
                         for (int fd = 0; fd < 4; ++fd)
 #pragma unroll
@@ -416,7 +422,17 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
 #pragma unroll
                     for (int fd = 0; fd < 4; ++fd)
                         o[fd][fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0][fd], pf[fq][ks], o[fd][fq], 0, 0, 0);
-                    lacc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[fq][ks], lacc[fq], 0, 0, 0);
+                    if constexpr (VSUM) {
+                        typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+                        const uint4 pw = __builtin_bit_cast(uint4, pf[fq][ks]);
+                        const bf16x2_hw one2 = __builtin_bit_cast(bf16x2_hw, 0x3f803f80u);
+                        vsum[fq] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, pw.x), one2, vsum[fq], false);
+                        vsum[fq] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, pw.y), one2, vsum[fq], false);
+                        vsum[fq] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, pw.z), one2, vsum[fq], false);
+                        vsum[fq] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, pw.w), one2, vsum[fq], false);
+                    } else {
+                        lacc[fq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[fq][ks], lacc[fq], 0, 0, 0);
+                    }
                 }
             }
             return;
@@ -474,7 +490,13 @@ __global__ __launch_bounds__(NWAVE * 64, (VAR & 16) ? 4 : 3) void attn_fwd_kerne
     // ---- normalise and store: lane owns 16 consecutive d (= 16 lg + 4 fd + r) of query li ---------
 #pragma unroll
     for (int fq = 0; fq < 2; ++fq) {
-        const float inv = 1.0f / lacc[fq][0];   // D-row 4 lg of the ones product: the full row sum on every lane
+        float rowsum = lacc[fq][0];             // D-row 4 lg of the ones product: the full row sum on every lane
+        if constexpr (VSUM) {                   // per-lane partials over this lane's keys: add the query's four lanes (lane bits 4, 5)
+            rowsum = vsum[fq];
+            rowsum += lane_xor<16>(rowsum);
+            rowsum += lane_xor<32>(rowsum);
+        }
+        const float inv = 1.0f / rowsum;
         const int q = q0 + 16 * fq + li;
         if (q < p.npad) {
             uint4 w0, w1;
@@ -533,6 +555,14 @@ int fp_attention_fwd(const bf16_t* QK, int ldqk, const bf16_t* Vt, bf16_t* O, in
         FP_LAUNCH_CHECK();
         return FP_OK;
     }
+    }
+#endif
+#ifdef FP_LAB
+    if (q_prescaled && (fp_opt_get(FP_OPT_ATTN_VARIANT, 0) & 256)) {   // lab A/B: row sums by v_dot2_f32_bf16 instead of the ones MFMA
+        if (short_tail) hipLaunchKernelGGL((attn_fwd_kernel<2, 4 | 16 | 64 | 256>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<2, 16 | 64 | 256>), grid, dim3(NWAVE * 64), 2 * STAGE, stream, a);
+        FP_LAUNCH_CHECK();
+        return FP_OK;
     }
 #endif
     if (q_prescaled) {

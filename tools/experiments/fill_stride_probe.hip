@@ -3,7 +3,7 @@
 // [rows, K] operand: 8 cache lines whose addresses are one row stride (2 KiB at K = 1024, 8 KiB at K = 4096) apart.  This probe issues
 // pieces of that shape — the workgroups of an XCD stream one shared, L2-resident [256 rows x K] panel, 64 columns (128 B) per step like a K loop — against
 // the contiguous form, for row strides 128 B (= contiguous K-panel layout), 2 KiB, 2 KiB + 128 B (padded rows), 8 KiB, 8 KiB + 128 B.
-//   hipcc --offload-arch=gfx950 -O3 tools/experiments/fill_stride_probe.hip -o /tmp/fsp && /tmp/fsp
+//   hipcc --offload-arch=gfx950 -O3 tools/experiments/fill_stride_probe.hip -o /tmp/fsp && /tmp/fsp && /tmp/fsp private
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -14,10 +14,12 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 
 // workgroup = W waves; per step the workgroup fetches ROWS rows x 128 B (ROWS / 8 pieces, dealt to the waves), then moves 128 B along K
 template <int ROWS>
-__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, uint32_t* __restrict__ sink, int iters, int stride, int ksteps, size_t panel) {
+__global__ __launch_bounds__(512) void probe(const char* __restrict__ src, uint32_t* __restrict__ sink, int iters, int stride, int ksteps, size_t panel, int priv) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const char* base = src + (size_t)(blockIdx.x & 7) * panel;   // one panel per XCD (workgroups are dealt to the 8 XCDs round-robin): L2-resident, shared like a GEMM's W panel
+    // shared: one panel per XCD (workgroups are dealt to the 8 XCDs round-robin): L2-resident, shared like a GEMM's W panel;
+    // private: a panel per workgroup (128 MiB+ in all: streams from the Infinity Cache / HBM like first-touch operands)
+    const char* base = src + (size_t)(priv ? blockIdx.x : (blockIdx.x & 7)) * panel;
     constexpr int NP = ROWS / 8;                 // pieces per step
     const int ppw = NP / nw;                      // pieces per wave and step
     const int r8 = lane >> 3, s8 = lane & 7;
@@ -39,7 +41,9 @@ __global__ __launch_bounds__(512) void probe(const char* __restrict__ src, uint3
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const int priv = argc > 1 && argv[1][0] == 'p';
+    printf("%s panels\n", priv ? "PRIVATE (one per workgroup: Infinity Cache / HBM)" : "SHARED (one per XCD: L2-resident)");
     int ncu = 256, mhz = 2400;
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
     hipDeviceGetAttribute(&mhz, hipDeviceAttributeClockRate, 0);
@@ -60,9 +64,9 @@ int main() {
                 const int ksteps = stride == 128 ? 1 : (stride / 128 > 64 ? 64 : stride / 128 - (stride % 2048 ? 1 : 0));
                 const size_t panel = (size_t)ROWS * stride;
                 const int iters = 4000;
-                hipLaunchKernelGGL(probe<ROWS>, dim3(ncu * wg), dim3(waves * 64), 2 * ROWS * 128, 0, d, sink, 50, stride, ksteps, panel);
+                hipLaunchKernelGGL(probe<ROWS>, dim3(ncu * wg), dim3(waves * 64), 2 * ROWS * 128, 0, d, sink, 50, stride, ksteps, panel, priv);
                 hipEventRecord(a);
-                hipLaunchKernelGGL(probe<ROWS>, dim3(ncu * wg), dim3(waves * 64), 2 * ROWS * 128, 0, d, sink, iters, stride, ksteps, panel);
+                hipLaunchKernelGGL(probe<ROWS>, dim3(ncu * wg), dim3(waves * 64), 2 * ROWS * 128, 0, d, sink, iters, stride, ksteps, panel, priv);
                 hipEventRecord(b);
                 hipEventSynchronize(b);
                 float ms = 0;

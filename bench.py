@@ -400,11 +400,10 @@ def config_legs(args, vit, bank):
         t = span("bank_scan_topk"); t.start()
         s_, i_ = bank.topk(desc, 100)                                                           # ONE bank pass for all of them
         t.stop()
-        res_ = []
-        for pidx in range(n_prop):
-            t = span("estimator_forward_cached"); t.start()
-            res_.append(est.forward(pcrops[pidx], tdicts[pidx], K, boxes[pidx], float(scales[pidx]), query_feat=feats[pidx:pidx + 1]))
-            t.stop()
+        t = span("estimator_forward_cached"); t.start()
+        res_ = est.forward_many([dict(proposal=pcrops[pidx], template_dict=tdicts[pidx], K=K, bbox=boxes[pidx], est_scale=float(scales[pidx]),
+                                      query_feat=feats[pidx:pidx + 1]) for pidx in range(n_prop)])       # what scripts.dino_inference runs per image
+        t.stop()
         return res_, s_, i_
     c3()
     torch.cuda.synchronize()
@@ -430,8 +429,9 @@ def config_legs(args, vit, bank):
                                "frac": passes * args.bank * D * 2.0 / max(st_ms.get("bank_scan_topk", 1e9), 1e-9) / 1e6 / HBM_PEAK_GBS, "bank_passes": passes},
             "template_score_normed": {"bound": "hbm", "achieved": T * P * D * 2.0 / ts_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": T * P * D * 2.0 / ts_ms / 1e6 / HBM_PEAK_GBS, "ms": ts_ms, "bytes": T * P * D * 2.0}},
-        "note": "estimator_forward_cached = DinoPoseEstimator.forward with the caller's query features: normalise query, streaming score over the "
-                "1.1 GB pre-normalised store, top-3, depth extents of the 3 winners, host pose formula (one sync per proposal)"}
+        "note": "estimator_forward_cached = DinoPoseEstimator.forward_many over the image's proposals with the caller's query features: per proposal "
+                "normalise query, streaming score over the 1.1 GB pre-normalised store, top-3, depth extents of the 3 winners; ONE device -> host copy "
+                "per image, then the host pose formula (round 4: one sync per proposal)"}
     est.feature_cache.clear()
     return out
 

@@ -55,13 +55,23 @@ def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, s
     crops = list(proposals.proposals)
     feats = model.feature_extractor(torch.stack([torch.as_tensor(c) for c in crops]), layer=layer, feature_type="patch") if crops else None
     ahead = [p["mesh"] for p in scene_props] + list(upcoming)
-    for i, prop in enumerate(crops):
+
+    def template_of(i):
+        def load():
+            if hasattr(templates, "prefetch_by_name"):
+                for nxt in ahead[i + 1:i + 1 + PREFETCH_DEPTH]:
+                    templates.prefetch_by_name(nxt)
+            return templates.get_template_by_name(scene_props[i]["mesh"])
+        return load
+    # the image's proposals go through ONE batched estimator step: each proposal's kernels are enqueued as its templates arrive, the
+    # scores / indices / extents of all of them come back in one device -> host copy (DinoPoseEstimator.forward_many == forward per item)
+    items = [dict(proposal=prop, template_dict=template_of(i), K=K, bbox=boxes[i], est_scale=scales[i], query_feat=feats[i:i + 1])
+             for i, prop in enumerate(crops)]
+    outs = model.forward_many(items, layer=layer, batch_size=batch_size) if hasattr(model, "forward_many") else \
+        [model(it["proposal"], it["template_dict"](), K, it["bbox"], it["est_scale"], layer=layer, batch_size=batch_size, query_feat=it["query_feat"])
+         for it in items]
+    for i, out in enumerate(outs):
         mesh = scene_props[i]["mesh"]
-        if hasattr(templates, "prefetch_by_name"):
-            for nxt in ahead[i + 1:i + 1 + PREFETCH_DEPTH]:
-                templates.prefetch_by_name(nxt)
-        out = model(prop, templates.get_template_by_name(mesh), K, boxes[i], scales[i], layer=layer, batch_size=batch_size,
-                    query_feat=feats[i:i + 1])
         rows.append(pose_row(scene_id, frame_id, mesh, out["scores"][0], out["TCO"][0], out["bbox"].cpu().numpy(), scales[i],
                              t_scale=t_scale, time_value=time_value))
     return rows

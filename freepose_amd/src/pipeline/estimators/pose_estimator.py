@@ -110,10 +110,9 @@ class DinoPoseEstimator(torch.nn.Module):
             q = ops.l2_normalize(q)
         return ops.template_score(feats_template, q, normalized=templates_normalized)
 
-    def forward(self, proposal, template_dict, K, bbox, est_scale, layer=22, batch_size=128, return_query_feat=False,
-                query_feat=None):
-        """`query_feat` (optional, [1,P,D]): patch features of `proposal` computed by the caller, e.g. for all proposals of
-        an image in one ViT batch (a B = 1 forward is launch-bound; features do not depend on batch neighbours)."""
+    def _enqueue(self, proposal, template_dict, query_feat, layer, batch_size):
+        """device side of one forward: template features (store / spill file / ViT), patchwise scores, canonical top-3, the winners'
+        depth extents — everything stays on the device: (scores [3], indices [3], extents [3, 8])"""
         if self.cache_size > 0:
             feats_template = self._get_template_features(template_dict, layer=layer, batch_size=batch_size)
         else:
@@ -124,21 +123,59 @@ class DinoPoseEstimator(torch.nn.Module):
         T = scores.shape[0]
         idx_all = torch.arange(T, dtype=torch.int32, device=scores.device)
         top_scores, top_indices = ops.topk_merge(scores[None], idx_all[None], min(3, T))
-        top_scores = top_scores[0].cpu().numpy()
-        top_indices = top_indices[0].cpu().numpy().astype(np.int64)
-
-        out = {"TCO": [], "scores": top_scores, "proposal": proposal, "K": K, "bbox": bbox,
-               "retrieved_proposals": [template_dict["templates"][i] for i in top_indices]}
         depths = template_dict["depths"]
-        sel = torch.stack([torch.as_tensor(depths[int(i)]) for i in top_indices]).float()
+        if torch.is_tensor(depths) and depths.is_cuda:
+            sel = depths.index_select(0, top_indices[0].long()).float()
+        else:                                             # host-side depth maps (reference-style list / numpy): one small sync for the indices
+            sel = torch.stack([torch.as_tensor(depths[int(i)]) for i in top_indices[0].cpu()]).float()
         fx, fy, cx, cy = _intrinsics(template_dict["intrinsic"])
-        ext = ops.depth_extents(sel, fx, fy, cx, cy).cpu().numpy()
+        ext = ops.depth_extents(sel, fx, fy, cx, cy)
+        return top_scores[0], top_indices[0], ext, query_feat
+
+    def _finish(self, proposal, template_dict, K, bbox, est_scale, top_scores, top_indices, ext, query_feat, return_query_feat):
+        """host side: the reference's float64 pose formula on the three winners (:104-112)"""
+        top_indices = np.asarray(top_indices).astype(np.int64)
+        out = {"TCO": [], "scores": np.asarray(top_scores), "proposal": proposal, "K": K, "bbox": bbox,
+               "retrieved_proposals": [template_dict["templates"][i] for i in top_indices]}
         ratio = float(est_scale) / 0.25   # cloud re-centred, /0.25 (render scale), *est_scale (reference :104-111)
         for j, i in enumerate(top_indices):
             out["TCO"].append(z_from_extents(bbox, ext[j, 4] * ratio, ext[j, 5] * ratio, K, self.mesh_poses[int(i)]))
         if return_query_feat:
             out["query_feat"] = query_feat
         return out
+
+    def forward(self, proposal, template_dict, K, bbox, est_scale, layer=22, batch_size=128, return_query_feat=False,
+                query_feat=None):
+        """`query_feat` (optional, [1,P,D]): patch features of `proposal` computed by the caller, e.g. for all proposals of
+        an image in one ViT batch (a B = 1 forward is launch-bound; features do not depend on batch neighbours)."""
+        s, i, ext, query_feat = self._enqueue(proposal, template_dict, query_feat, layer, batch_size)
+        return self._finish(proposal, template_dict, K, bbox, est_scale, s.cpu().numpy(), i.cpu().numpy(), ext.cpu().numpy(), query_feat,
+                            return_query_feat)
+
+    def forward_many(self, items, layer=22, batch_size=128, return_query_feat=False):
+        """`forward` for several proposals (dicts with proposal, template_dict, K, bbox, est_scale [, query_feat]) — the proposals of one
+        image in scripts.dino_inference — with ONE device -> host copy for all of them: every proposal's kernels are enqueued first
+        (different meshes: different template stores), then the scores, indices and extents come back together.  Same kernels on the
+        same inputs as separate calls: identical results."""
+        if not items:
+            return []
+        for it in items:                                  # `template_dict` may be a callable (lazy: the CLI loads / prefetches templates
+            if callable(it["template_dict"]):             # in proposal order, so a mesh's decode still hides under its predecessor's ViT calls)
+                it["template_dict"] = it["template_dict"]()
+            it["_queued"] = self._enqueue(it["proposal"], it["template_dict"], it.get("query_feat"), layer, batch_size)
+        queued = [it.pop("_queued") for it in items]
+        k = queued[0][0].shape[0]
+        if any(q[0].shape[0] != k for q in queued):       # (meshes with fewer than 3 templates: no common shape to pack)
+            return [self._finish(it["proposal"], it["template_dict"], it["K"], it["bbox"], it["est_scale"], q[0].cpu().numpy(), q[1].cpu().numpy(),
+                                 q[2].cpu().numpy(), q[3], return_query_feat) for it, q in zip(items, queued)]
+        packed = torch.cat([torch.cat([q[0].double(), q[1].double(), q[2].double().reshape(-1)]) for q in queued]).cpu().numpy()
+        w = packed.size // len(items)
+        outs = []
+        for n, (it, q) in enumerate(zip(items, queued)):
+            row = packed[n * w:(n + 1) * w]
+            outs.append(self._finish(it["proposal"], it["template_dict"], it["K"], it["bbox"], it["est_scale"], row[:k].astype(np.float32),
+                                     row[k:2 * k], row[2 * k:].reshape(k, -1), q[3], return_query_feat))
+        return outs
 
     @staticmethod
     def generate_poses(n_poses=600):

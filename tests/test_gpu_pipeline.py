@@ -74,6 +74,16 @@ def test_pose_estimator_forward_matches_reference(golden_dir, tmp_path):
     #  normalise-every-call scores bit for bit)
     s = est.score_templates(est.feature_cache["m"], out["query_feat"], templates_normalized=True).cpu().numpy()
     assert np.array_equal(s, g["scores_all"])
+    # ---- forward_many (the proposals of one image in one step, one device -> host copy) == forward per item, exactly
+    td2 = dict(td, model_name="m2", depths=torch.from_numpy(g["depths"]).cuda())          # device-resident depths, as the template loader returns them
+    items = [dict(proposal=torch.from_numpy(g["query"]), template_dict=lambda: td, K=g["Kq"], bbox=torch.from_numpy(g["bbox"]), est_scale=float(g["est_scale"])),
+             dict(proposal=torch.from_numpy(g["query"]), template_dict=td2, K=g["Kq"], bbox=torch.from_numpy(g["bbox"]), est_scale=0.5 * float(g["est_scale"]))]
+    many = est.forward_many(items, return_query_feat=True)
+    one = [est.forward(torch.from_numpy(g["query"]), t_, g["Kq"], torch.from_numpy(g["bbox"]), sc_) for t_, sc_ in ((td, float(g["est_scale"])), (td2, 0.5 * float(g["est_scale"])))]
+    for a_, b_ in zip(many, one):
+        assert np.array_equal(a_["scores"], b_["scores"]) and a_["scores"].dtype == b_["scores"].dtype == np.float32
+        assert all(np.array_equal(x, y) for x, y in zip(a_["TCO"], b_["TCO"])) and len(a_["retrieved_proposals"]) == 3
+    assert np.array_equal(many[0]["scores"], g["scores_top3"]) and "query_feat" in many[0] and est.forward_many([]) == []
     # ---- the reference's cache semantics (pose_estimator.py:43-53,63-65): an entry the LRU evicts is written to <cache_dir> (under
     # flock) and a revisit reads it back instead of running the ViT again; save_all keeps the RAW features as <name>.pth
     class Counting(_StoredExtractor):

@@ -16,6 +16,8 @@ from pathlib import Path
 N_REP = 6
 SHAPES = {  # name: (N, K, epi)   epi 0 bias (qk), 1 bias+GELU (fc1), 2 LayerScale+residual (proj / fc2), 4 transposed V
     "qk": (2048, 1024, 0), "v": (1024, 1024, 4), "proj": (1024, 1024, 2), "fc1": (4096, 1024, 1), "fc2": (1024, 4096, 2)}
+if __import__("os").environ.get("SK_SHAPES") == "stats":   # the forward's proj / fc2 launches: LayerScale + residual + row statistics (epilogue 8), in place
+    SHAPES = {"proj": (1024, 1024, 2), "proj+stats": (1024, 1024, 8), "fc2": (1024, 4096, 2), "fc2+stats": (1024, 4096, 8)}
 MS = {"B1@518": (1376, 1376), "B2@518": (2752, 1376), "B5@420": (4560, 912), "B21@420 remainder": (2768, 0), "B21@420": (19152, 912), "B8@420": (7296, 912)}
 
 
@@ -81,13 +83,15 @@ def run(label_path):
                 def call(w):
                     if epi == 4:
                         return ops.gemm_vt(x, w, bias, npad, 16)
+                    if epi == 8:
+                        return ops.gemm_stats(x, w, bias, gamma, resid)[0]
                     return ops.gemm(x, w, bias, epi, gamma=gamma, resid=resid)
                 out = call(ws[0]).float()
                 if ref is None:
                     ref = out
                 else:
                     d = (out - ref).abs()
-                    tol = (ref.abs() + (resid.float().abs() if epi == 2 else 0.0)) * 2.0 ** -6 + 1e-3   # (epi 2 cancels against the residual)
+                    tol = (ref.abs() + (resid.float().abs() if epi in (2, 8) else 0.0)) * 2.0 ** -6 + 1e-3   # (epi 2 cancels against the residual)
                     bad = int((d > tol).sum())
                     neq = int((out != ref).sum())
                     print(f"  check {mname} {sname} {fname}: {neq} of {out.numel()} elements differ from plain, {bad} beyond 1 bf16 ulp", flush=True)

@@ -22,7 +22,7 @@ extern "C" int fp_version(void) { return 100; }
 
 #ifdef FP_LAB
 // lab build only: process-global experiment toggles (tools/ A/B runs)
-static int g_opts[FP_OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+static int g_opts[FP_OPT_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 int fp_opt_get(int key, int dflt) { return (key >= 0 && key < FP_OPT_COUNT && g_opts[key] >= 0) ? g_opts[key] : dflt; }
 extern "C" int fp_lab_set_option(const char* name, int value) {
     FP_REQUIRE(name, "lab_set_option: null name");
@@ -34,6 +34,7 @@ extern "C" int fp_lab_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_ring")) g_opts[FP_OPT_GEMM_RING] = value;   // cap on the 64x64 tier's K-tile ring depth
     else if (!strcmp(name, "gemm_sk")) g_opts[FP_OPT_GEMM_SK] = value;       // balanced tier: 1 never, 2 / 3 / 4 force a form (gemm_bf16.hip)
     else if (!strcmp(name, "gemm_sk_grid")) g_opts[FP_OPT_GEMM_SK_GRID] = value;
+    else if (!strcmp(name, "gemm_stream_mb")) g_opts[FP_OPT_GEMM_STREAM_MB] = value;   // big tier: outputs above this many MiB are stored non-temporally
     else { fp_set_error("lab_set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
     return FP_OK;
 }

@@ -30,6 +30,7 @@
 #endif
 #define FP_GEMM_DEFAULT_VARIANT 238   // 2|4|8|32|64|128 (profiles/r02_ab.md: +4..6 % over 110 on every ViT shape)
 #define FP_GEMM_VAR_BIG (4 | 32 | 64 | 128)   // 16-wave 256x256: table GELU, persistent walk, streaming epilogue I/O, split DMA issue
+#define FP_GEMM_STREAM_BYTES (128L << 20)     // big-tier outputs above this are stored non-temporally (launch_epi: streaming policy)
 #define FP_GEMM_VAR_SMALL 6                   // 128x128 (4 waves): pipelined fragment reads, table GELU
 #define FP_GEMM_VAR_TINY (6 | 1024)           // 64x64 (2 waves, 1 for the transposed store): the same on a K-tile ring of run-time depth
 
@@ -862,6 +863,19 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
     // tiny tier: 64x64 tiles.  Row-major epilogues split the tile over TWO waves (32 x 64 each): a launch that cannot fill the chip is
     // bound by one wave's walk along K, and per K step a lone wave issues 16 LDS-DMA pieces for 32 MFMAs — two waves halve both
     // (ViT-L B = 1 @518^2: see profiles/r04_ab.md §4).  The transposed V store needs 64-token wave tiles and keeps one wave.
+    // STREAMING POLICY of the big tier (round 5).  Non-temporal full-line stores (and residual loads) keep a large output from dirtying
+    // every XCD's L2 (round 1: qk 0.373 -> 0.312 ms at 214 crops) — but an output that fits in the 256 MiB Infinity Cache beside its
+    // consumer's other operands is what the next kernel reads, and bypassing the caches sends that kernel to HBM.  Same-process A/B of
+    // ViT-L forwards with the threshold at 0 / 128 / 256 / 512 MiB / never, three boxes (profiles/r05_stream_policy_ab.log): ordinary
+    // stores below 128 MiB are 1.8-3.1 % faster at 5, 8 and 32 crops @420^2, -3 ... +1 % at 12 / 21 crops (box-dependent), neutral from
+    // 96 crops on; a 256 MiB threshold loses up to 1.5 % at 21-32 crops on two of the boxes; never streaming loses 1-3 % from 48 crops on.
+    long stream_bytes = FP_GEMM_STREAM_BYTES;
+#ifdef FP_LAB
+    stream_bytes = (long)fp_opt_get(FP_OPT_GEMM_STREAM_MB, (int)(FP_GEMM_STREAM_BYTES >> 20)) << 20;   // lab A/B: the threshold in MiB (0 = always stream)
+    if (var & 8388608) stream_bytes = 1L << 60;                                                          // bit 8388608: never stream
+#endif
+    const bool stream_out = (long)a.M * a.N * 2 > stream_bytes;
+    if (big && !stream_out) return launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG & ~64>(a, stream);
     if constexpr (FpEpiTraits<EPI>::TRANS) {
 #ifdef FP_LAB
         if (!big && !tiny && (var & 524288)) return (var & 262144) ? launch_cfg<128, 128, 2, 4, EPI, FP_GEMM_VAR_SMALL | 4096>(a, stream) : launch_cfg<128, 128, 2, 2, EPI, FP_GEMM_VAR_SMALL | 4096>(a, stream);   // lab A/B: spread DMA issue

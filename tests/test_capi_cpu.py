@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
 def test_product_library_carries_no_lab():
     """The shipped library reads no environment variable and has no process-global option: every FP_* measurement toggle, the
     alternative GEMM / attention kernels and the wrong-numerics hooks exist only in the lab build (-DFP_LAB).  One GEMM kernel per
-    (epilogue, tile tier): 9 epilogues x 3 tiers + the two GELU helper kernels."""
+    (epilogue, tile tier): 9 epilogues x 3 tiers, the big tier in two store policies (streaming / cached output, round 5) + the two GELU
+    helper kernels."""
     from freepose_amd import _lib, build
     build.build_hip(verbose=False)
     blob = _lib.LIB_PATH.read_bytes()
@@ -44,7 +45,7 @@ def test_product_library_carries_no_lab():
     obj = ROOT / "freepose_amd" / "lib" / "obj" / "gemm_bf16.o"
     stubs = [ln for ln in subprocess.run(["nm", str(obj)], capture_output=True, text=True, check=True).stdout.splitlines()
              if "__device_stub__" in ln]
-    assert 0 < len(stubs) <= 30, len(stubs)
+    assert 0 < len(stubs) <= 39, len(stubs)
     asm_obj = ROOT / "freepose_amd" / "lib" / "obj" / "gemm_asm.o"     # the hand-scheduled tier: one kernel per epilogue it can be dispatched for
     asm_stubs = [ln for ln in subprocess.run(["nm", str(asm_obj)], capture_output=True, text=True, check=True).stdout.splitlines()
                  if "__device_stub__" in ln]

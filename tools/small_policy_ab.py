@@ -15,6 +15,9 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else 420
 vit = ops.ViT("dinov2_vitl14_reg", seed=0)
 POL = (("HIP small tiers", 238), ("asm 128x128 wherever supported", 238 | 1048576), ("asm where every CU gets a tile", 238 | 1048576 | 2097152),
        ("asm for K >= 2048", 238 | 1048576 | 4194304), ("asm for K >= 2048 where every CU gets a tile", 238 | 1048576 | 4194304 | 2097152))
+import os
+if os.environ.get("POLICY") == "stream":     # big tier with / without non-temporal epilogue I/O (the asm big kernel always streams: bit 8192 keeps it out)
+    POL = (("streaming epilogue I/O (product)", 238), ("plain stores on the big tier", 238 | 8388608), ("plain stores, no asm tier", 238 | 8388608 | 8192), ("no asm tier", 238 | 8192))
 for B in ([int(b) for b in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 2, 3, 4, 5, 6, 8, 12, 16, 21)):
     x = torch.rand((B, 3, res, res), device="cuda").to(torch.bfloat16)
     ts = {n: [] for n, _ in POL}

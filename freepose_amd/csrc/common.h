@@ -35,6 +35,11 @@ __host__ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 // round an f32 to the nearest bf16 value but keep it in f32 (models a bf16 module boundary)
 __host__ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+// IEEE square root.  `__fsqrt_rn` is NOT one on this target: the HIP headers map it to __ocml_native_sqrt_f32 = a bare v_sqrt_f32
+// (1 ulp), and a norm that lands within that ulp of a bf16 rounding boundary then rounds the other way — every element of the row moves
+// (about one row in 16 000; found by tests/test_gpu_fuzz.py at 53 357 x 768).  `sqrtf` compiles to v_sqrt_f32 + the correction
+// steps (correctly rounded: -fhip-fp32-correctly-rounded-divide-sqrt, on by default), which is what the C oracle's sqrtf is.
+__device__ __forceinline__ float fp_sqrt_rn(float x) { return sqrtf(x); }
 
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));

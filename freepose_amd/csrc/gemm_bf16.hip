@@ -954,7 +954,8 @@ int fp_gemm_bf16(const FpGemmArgs& a_in, int epi, hipStream_t stream) {
             return launch_epi<FP_EPI_VT>(a, stream);
         case FP_EPI_LN_BIAS:
         case FP_EPI_LN_GELU:
-            FP_REQUIRE(a.ln_mfrag && a.ln_rstd && a.ln_cfrag && a.N % 64 == 0 && a.M >= 16, "gemm: LN-folded epilogue needs ln_mfrag, ln_rstd, ln_cfrag and N %% 64 == 0");
+            FP_REQUIRE(a.ln_mfrag && a.ln_rstd && a.ln_cfrag && a.N % 64 == 0 && a.M >= 16,
+                       "gemm: LN-folded epilogue needs ln_mfrag, ln_rstd, ln_cfrag, N %% 64 == 0 and M >= 16 (M=%d N=%d)", a.M, a.N);
             return epi == FP_EPI_LN_BIAS ? launch_epi<FP_EPI_LN_BIAS>(a, stream) : launch_epi<FP_EPI_LN_GELU>(a, stream);
         case FP_EPI_LN_VT:
             FP_REQUIRE(a.ln_mfrag && a.ln_rstd && a.ln_cfrag, "gemm: LN-folded epilogue needs ln_mfrag, ln_rstd and ln_cfrag");

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void template_dots_kernel(const bf16_t* __rest
             for (int e = 0; e < 8; ++e) ss = __fmaf_rn(x[c][e], x[c][e], ss);
         }
         ss = wave_sum(ss);
-        const float nrm = fmaxf(rbf(__fsqrt_rn(ss)), 1e-12f);
+        const float nrm = fmaxf(rbf(fp_sqrt_rn(ss)), 1e-12f);
         const float rinv = __builtin_amdgcn_rcpf(nrm);
         float acc = 0.f;
 #pragma unroll
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void rerank_views_kernel(const bf16_t* __restr
             for (int e = 0; e < 8; ++e) ss = __fmaf_rn(x[ch][e], x[ch][e], ss);
         }
         ss = wave_sum(ss);
-        const float nrm = fmaxf(rbf(__fsqrt_rn(ss)), 1e-12f);
+        const float nrm = fmaxf(rbf(fp_sqrt_rn(ss)), 1e-12f);
         const float rinv = __builtin_amdgcn_rcpf(nrm);
         float acc = 0.f;
 #pragma unroll

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void l2norm_rows_kernel(const bf16_t* __restric
         for (int e = 0; e < 8; ++e) { const float v = bf2f(xr[base + e]); acc = __fmaf_rn(v, v, acc); }
     }
     acc = wave_sum(acc);
-    const float n = fmaxf(rbf(__fsqrt_rn(acc)), 1e-12f);
+    const float n = fmaxf(rbf(fp_sqrt_rn(acc)), 1e-12f);
     for (int base = lane * 8; base < D; base += 512) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) Y[(size_t)r * D + base + e] = f2bf(__fdiv_rn(bf2f(xr[base + e]), n));
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_vec_kernel(const bf16_t* X, b
         }
     }
     acc = wave_sum(acc);
-    const float n = fmaxf(rbf(__fsqrt_rn(acc)), 1e-12f);
+    const float n = fmaxf(rbf(fp_sqrt_rn(acc)), 1e-12f);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int base = (c * 64 + lane) * 8;

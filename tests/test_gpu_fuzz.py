@@ -1,0 +1,318 @@
+"""Randomised parity: the kernels of the hot path at shapes NOBODY picked by hand, against the same checkers as the fixed-shape tests —
+the C oracle bit for bit (integer / byte / index work and the bf16-rounded scores), fp64 torch within the stated tolerance (GEMM
+epilogues, attention), and the library's own contract where one exists (a row's bits do not depend on the rows around it).
+
+Every case comes from one seeded generator, so a failure names a (section, case) that reproduces.  `FP_FUZZ_ITERS` = cases per section
+(default 6: the suite stays short); the round's long run (`FP_FUZZ_ITERS=150`, profiles/r05_fuzz.log) is the evidence."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ITERS = int(os.environ.get("FP_FUZZ_ITERS", "6"))
+SEED = int(os.environ.get("FP_FUZZ_SEED", "20250928"))
+
+
+def _rng(section: str, case: int):
+    return np.random.Generator(np.random.PCG64([SEED, sum(map(ord, section)), case]))
+
+
+def _bf(rng, shape, scale=1.0):
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32)).to(torch.bfloat16)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def _pick_m(rng):
+    """row counts across every tile tier and their seams: tiny, below / at / above the 64 / 128 / 256-row tile edges, partial rounds of the
+    256-CU grid, and a few tens of thousands (big tier + row split)"""
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        return int(rng.integers(1, 70))
+    if kind == 1:
+        return int(rng.choice([64, 128, 256, 512, 1024, 4096, 16384]) + rng.integers(-3, 4))
+    if kind == 2:
+        return int(rng.integers(70, 3000))
+    if kind == 3:
+        return int(rng.integers(3000, 20000))
+    if kind == 4:
+        return int(rng.integers(1, 44)) * int(rng.choice([912, 1376, 272]))          # whole crops of 905 / 1374 / 261 tokens
+    return int(rng.integers(20000, 70000))
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_gemm_epilogues_and_row_independence(case):
+    """x W^T + b (+ GELU | residual + layer scale) vs fp64 at a random (M, N, K), and the contract the ViT's batching rests on: the first
+    m rows of an M-row launch carry the bits of an m-row launch (whatever tiers the two launches were given)"""
+    from freepose_amd import ops
+    rng = _rng("gemm", case)
+    M = _pick_m(rng)
+    N = 64 * int(rng.integers(1, 65))
+    K = 64 * int(rng.integers(1, 65))
+    if M * (N + K) > 150e6:
+        M = max(1, int(150e6 // (N + K)))
+    epi = int(rng.integers(0, 3))
+    x, w = _bf(rng, (M, K)), _bf(rng, (N, K), 0.05)
+    bias, gamma, resid = _bf(rng, (N,), 0.5), _bf(rng, (N,)), _bf(rng, (M, N))
+    out = ops.gemm(x, w, bias, epi, gamma=gamma, resid=resid)
+    rows = np.unique(np.concatenate([rng.integers(0, M, size=min(M, 96)), [0, M - 1]]))        # fp64 check on a row sample
+    ref = x[rows].double() @ w.double().t() + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 2:
+        ref = resid[rows].double() + gamma.double() * ref
+    got = out[torch.from_numpy(rows).cuda()].float().cpu()
+    assert _rel(got, ref) < 6e-3, (M, N, K, epi, _rel(got, ref))
+    assert ((got - ref.float()).abs() <= 0.02 * ref.float().abs() + 0.03 * max(1.0, (K / 1024) ** 0.5)).all(), (M, N, K, epi)
+    m = int(rng.integers(1, M + 1))
+    sub = ops.gemm(x[:m].contiguous(), w, bias, epi, gamma=gamma, resid=resid[:m].contiguous())
+    assert torch.equal(sub, out[:m]), f"rows depend on their launch: M={M} m={m} N={N} K={K} epi={epi}"
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_ln_folded_linear_and_statistics(case):
+    """LayerNorm folded into the consuming GEMM (qkv / fc1 form) fed by the producer's row statistics (proj / fc2 form), vs fp64, and
+    row independence of both"""
+    from freepose_amd import ops
+    rng = _rng("lnlin", case)
+    M = max(16, min(_pick_m(rng), 30000))                  # (the folded epilogue's record layout wants >= 16 rows: one padded crop)
+    K = 64 * int(rng.choice([6, 12, 16]))                  # embed dims of ViT-S / B / L
+    N = 64 * int(rng.integers(1, 65))
+    mode = int(rng.integers(0, 2))
+    x = torch.from_numpy((rng.standard_normal((M, K)) * (0.2 + 3.0 * rng.random((M, 1))) + 4.0 * rng.standard_normal((M, 1))).astype(np.float32))
+    x[:, int(rng.integers(0, K))] += 40.0                  # a massive-activation channel
+    x = x.to(torch.bfloat16)
+    w, bias = _bf(rng, (N, K), 0.05), _bf(rng, (N,), 0.5)
+    g_ln = torch.from_numpy((1.0 + 0.3 * rng.standard_normal(K)).astype(np.float32)).to(torch.bfloat16)
+    b_ln = _bf(rng, (K,), 0.2)
+    out = ops.ln_linear(x, g_ln, b_ln, w, bias, mode)
+    rows = np.unique(np.concatenate([rng.integers(0, M, size=min(M, 96)), [0, M - 1]]))
+    y = torch.nn.functional.layer_norm(x[rows].double(), (K,), g_ln.double(), b_ln.double(), 1e-6)
+    ref = y @ w.double().t() + bias.double()
+    if mode == 1:
+        ref = torch.nn.functional.gelu(ref)
+    got = out[torch.from_numpy(rows).cuda()].float().cpu()
+    assert _rel(got, ref) < 8e-3, (M, N, K, mode, _rel(got, ref))
+    assert ((got - ref.float()).abs() <= 0.02 * ref.float().abs() + 0.04).all(), (M, N, K, mode)
+    m = int(rng.integers(16, M + 1))
+    assert torch.equal(ops.ln_linear(x[:m].contiguous(), g_ln, b_ln, w, bias, mode), out[:m]), (M, m, N, K, mode)
+    # producer side: residual + layer-scale epilogue that also emits the next LayerNorm's row statistics
+    Kp = 64 * int(rng.choice([6, 12, 16, 24, 48, 64]))
+    xp, wp, bp = _bf(rng, (M, Kp)), _bf(rng, (K, Kp), 0.05), _bf(rng, (K,), 0.5)
+    gamma, resid = _bf(rng, (K,)), _bf(rng, (M, K), 2.0)
+    o, st = ops.gemm_stats(xp, wp, bp, gamma, resid)
+    assert torch.equal(o, ops.gemm(xp, wp, bp, 2, gamma=gamma, resid=resid)), "the statistics epilogue must not change the output"
+    o2, st2 = ops.gemm_stats(xp[:m].contiguous(), wp, bp, gamma, resid[:m].contiguous())
+    assert torch.equal(o2, o[:m]) and torch.equal(st2, st[:m]), (M, m, K, Kp)
+    of = o[torch.from_numpy(rows).cuda()].double().cpu()                                   # statistics are those of the bf16 output rows
+    mean, var = of.mean(-1), of.var(-1, unbiased=False)
+    sigma, rstd = torch.sqrt(var + 1e-6), 1.0 / torch.sqrt(var + 1e-6)
+    s = st[torch.from_numpy(rows).cuda()].double().cpu()                                    # (mean, sigma, rstd)
+    assert ((s[:, 0] - mean).abs() <= 3e-5 * (1e-3 + mean.abs()) + 3e-5 * sigma).all(), (M, K, Kp)
+    assert ((s[:, 1] - sigma).abs() <= 3e-5 * sigma).all(), (M, K, Kp)
+    assert ((s[:, 2] - rstd).abs() <= 2e-4 * rstd).all(), (M, K, Kp)
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_attention(case):
+    from freepose_amd import ops
+    rng = _rng("attn", case)
+    n_tok = int(rng.choice([int(rng.integers(16, 1500)), int(rng.integers(16, 200)), 64 * int(rng.integers(1, 23)) + int(rng.integers(-1, 2)),
+                            905, 1374, 1449, 261]))
+    n_tok = max(n_tok, 16)
+    B, H = int(rng.integers(1, 5)), int(rng.choice([1, 2, 6, 12, 16]))
+    prescaled = bool(rng.integers(0, 2))
+    npad = (n_tok + 15) // 16 * 16
+    D = H * 64
+    qkv = _bf(rng, (B, npad, 3, H, 64), float(rng.choice([0.3, 1.0, 1.5, 2.5])))
+    if prescaled:
+        qkv[:, :, 0] = (qkv[:, :, 0].float() * ops.ATTN_QSCALE).to(torch.bfloat16)
+    qk = qkv[:, :, :2].reshape(B * npad, 2 * D).contiguous()
+    vt = qkv[:, :, 2].permute(0, 2, 3, 1).contiguous()
+    o = ops.attention(qk, vt, n_tok, q_prescaled=prescaled)
+    q, k, v = (qkv[:, :n_tok, i].permute(0, 2, 1, 3).double() for i in range(3))
+    ref = torch.softmax(q @ k.transpose(-1, -2) * (float(np.log(2.0)) if prescaled else 1.0 / 8.0), dim=-1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(B, n_tok, D)
+    got = o.reshape(B, npad, D)[:, :n_tok].float().cpu()
+    assert torch.isfinite(o.float()).all(), (B, H, n_tok, prescaled)
+    assert _rel(got, ref) < 1e-2, (B, H, n_tok, prescaled, _rel(got, ref))
+    assert (got - ref.float()).abs().max().item() < 0.06, (B, H, n_tok, prescaled)
+    # a crop's output does not depend on the crops beside it
+    b = int(rng.integers(0, B))
+    one = ops.attention(qk[b * npad:(b + 1) * npad].contiguous(), vt[b:b + 1].contiguous(), n_tok, q_prescaled=prescaled)
+    assert torch.equal(one, o[b * npad:(b + 1) * npad]), (B, H, n_tok, b)
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_bank_topk(case):
+    """cosine top-k over a random bank with planted duplicate rows (ties on the score): indices AND score bits equal the oracle's canonical
+    order (score descending, index ascending), for any N / D / k / number of queries / index offset"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    rng = _rng("topk", case)
+    N = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 6000)), int(rng.integers(6000, 60000))]))
+    D = int(rng.choice([384, 768, 1024]))
+    Q = int(rng.integers(1, 10))
+    k = int(min(N, rng.choice([1, 2, 3, 10, 100, 101, 500, 1024])))
+    mu = rng.standard_normal(D).astype(np.float32)
+    bank = rng.standard_normal((N, D)).astype(np.float32) + float(rng.choice([0.0, 2.0])) * mu
+    if N > 4:
+        dup = rng.integers(0, N, size=(max(1, N // 5), 2))
+        bank[dup[:, 0]] = bank[dup[:, 1]]
+    bank_o = fo.bank_prepare(bank)
+    bank_g = ops.bank_prepare(torch.from_numpy(bank))
+    assert np.array_equal(fo.torch_to_bits(bank_g), bank_o), (N, D)
+    qs = rng.standard_normal((Q, D)).astype(np.float32) + mu
+    if Q > 2:
+        qs[1] = bank[int(rng.integers(0, N))]               # a query that IS a bank row
+    q_bits = fo.l2norm_rows(fo.to_bf16_bits(qs))
+    off = int(rng.choice([0, 12345]))
+    s_o, i_o = fo.bank_topk(bank_o, q_bits, k, idx_offset=off)
+    s_g, i_g = ops.bank_topk(bank_g, fo.bits_to_torch(q_bits), k, idx_offset=off)
+    assert np.array_equal(i_g.cpu().numpy(), i_o), (N, D, Q, k)
+    assert np.array_equal(s_g.cpu().numpy().view(np.uint32), s_o.view(np.uint32)), (N, D, Q, k)
+    # shards merged == unsharded
+    if N >= 8:
+        cut = int(rng.integers(1, N))
+        parts = []
+        for lo, hi in ((0, cut), (cut, N)):
+            kk = min(k, hi - lo)
+            s, i = ops.bank_topk(bank_g[lo:hi].contiguous(), fo.bits_to_torch(q_bits), kk, idx_offset=off + lo)
+            pad = k - kk
+            if pad:
+                s = torch.cat([s, torch.full((Q, pad), -float("inf"), device=s.device)], 1)
+                i = torch.cat([i, torch.full((Q, pad), 2 ** 31 - 1, dtype=i.dtype, device=i.device)], 1)
+            parts.append((s, i))
+        s_m, i_m = ops.topk_merge(torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1), k)
+        assert np.array_equal(i_m.cpu().numpy(), i_o) and np.array_equal(s_m.cpu().numpy().view(np.uint32), s_o.view(np.uint32)), (N, cut, k)
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_ffa_and_template_score(case):
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    rng = _rng("ffa", case)
+    B, g, D = int(rng.integers(1, 5)), int(rng.integers(2, 38)), int(rng.choice([384, 768, 1024]))
+    P = g * g
+    feats = fo.to_bf16_bits((rng.standard_normal((B, P, D)) * float(rng.choice([0.5, 3.0]))).astype(np.float32))
+    mask = (rng.random((B, g * 14, g * 14)) < rng.choice([0.002, 0.2, 0.9])).astype(np.uint8)
+    mask[0, :14, :14] = 1                                  # (never an empty mask here: 0/0 has its own test)
+    mask[:, 5, 5] = 1
+    ob, of = fo.ffa(feats, mask, 14)
+    assert np.array_equal(fo.torch_to_bits(ops.ffa(fo.bits_to_torch(feats), torch.from_numpy(mask), cell=14)), ob), (B, g, D)
+    assert np.array_equal(ops.ffa(fo.bits_to_torch(feats), torch.from_numpy(mask), cell=14, out_f32=True).cpu().numpy(), of), (B, g, D)
+    gn = ops.ffa(fo.bits_to_torch(feats), torch.from_numpy(mask), cell=14, normalize=True)
+    assert np.array_equal(fo.torch_to_bits(gn), fo.l2norm_rows(ob)), (B, g, D)
+    # template scores: mean over the patches of the cosine between template and query patch features
+    T = int(rng.integers(1, 30))
+    tm = fo.to_bf16_bits((rng.standard_normal((T, P, D)) * 3).astype(np.float32))
+    q = fo.l2norm_rows(fo.to_bf16_bits(rng.standard_normal((P, D)).astype(np.float32)))
+    s_g = ops.template_score(fo.bits_to_torch(tm), fo.bits_to_torch(q)).cpu().numpy()
+    assert np.array_equal(s_g.view(np.uint32), fo.template_score(tm, q).view(np.uint32)), (T, P, D)
+    w = rng.random((T, P)).astype(np.float32)
+    sw = ops.template_score(fo.bits_to_torch(tm), fo.bits_to_torch(q), torch.from_numpy(w)).cpu().numpy()
+    assert np.array_equal(sw.view(np.uint32), fo.template_score(tm, q, w).view(np.uint32)), (T, P, D)
+    tn = ops.l2_normalize(fo.bits_to_torch(tm).cuda().clone(), inplace=True)
+    assert np.array_equal(ops.template_score(tn, fo.bits_to_torch(q), normalized=True).cpu().numpy().view(np.uint32), s_g.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_crop_resize_pad(case):
+    """boxes anywhere (inside, clipped by the image, one pixel wide, larger than the image), every mask mode and extension, float and
+    u8 sources, several target sizes: the crops equal the oracle's byte for byte"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    rng = _rng("crop", case)
+    H, W = int(rng.integers(24, 700)), int(rng.integers(24, 700))
+    target = int(rng.choice([32, 98, 224, 420]))
+    n = int(rng.integers(1, 12))
+    boxes = []
+    for _ in range(n):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            x0, y0 = rng.integers(0, W - 8), rng.integers(0, H - 8)
+            boxes.append([x0, y0, rng.integers(x0 + 2, W + 1), rng.integers(y0 + 2, H + 1)])
+        elif kind == 1:
+            x0, y0 = rng.integers(0, W - 2), rng.integers(0, H - 2)
+            boxes.append([x0, y0, x0 + rng.integers(1, 3), rng.integers(y0 + 1, H + 1)])          # a sliver
+        elif kind == 2:
+            boxes.append([0, 0, W, H])
+        else:
+            x0, y0 = rng.integers(0, W - 8), rng.integers(0, H - 8)
+            boxes.append([x0, y0, min(W, x0 + rng.integers(4, 200)), min(H, y0 + rng.integers(4, 200))])
+    boxes = np.array(boxes, dtype=np.int32)
+    ext = float(rng.choice([0.0, 0.05, 0.1, 0.2, 0.5]))
+    mode = int(rng.integers(0, 3))
+    if rng.integers(0, 2):
+        img = rng.random((1, 3, H, W)).astype(np.float32)
+        masks = (rng.random((n, H, W)) < 0.7).astype(np.uint8)
+        o = fo.crop_resize_pad(img, boxes, target, ext, masks, mode)
+        g = ops.crop_resize_pad(torch.from_numpy(img), torch.from_numpy(boxes), target, ext, torch.from_numpy(masks), mode)
+    else:
+        img = rng.integers(0, 256, size=(n, H, W, 3), dtype=np.uint8)                          # per-box u8 HWC sources (render -> crop)
+        o = fo.crop_resize_pad(img, boxes, target, ext)
+        g = ops.crop_resize_pad(torch.from_numpy(img), torch.from_numpy(boxes), target, ext)
+    assert np.array_equal(g.cpu().numpy(), o), (H, W, target, ext, mode, boxes.tolist())
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_rasterizer_and_extents(case):
+    """a random triangle soup (needles, slivers, zero-area and screen-filling triangles, vertices behind the camera) under random poses at a
+    random image size: both rasteriser strategies equal the oracle bit for bit (depth, colour), and so do the depth extents"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    rng = _rng("raster", case)
+    nv, nf = int(rng.integers(3, 400)), int(rng.integers(1, 900))
+    v = rng.standard_normal((nv, 3)).astype(np.float32)
+    v /= np.abs(v).max()
+    if rng.integers(0, 2):
+        v[:, int(rng.integers(0, 3))] *= 0.02                                                   # a nearly flat object
+    f = rng.integers(0, nv, size=(nf, 3)).astype(np.int32)                                      # (repeated indices = zero-area faces)
+    colors = rng.integers(0, 256, size=(nv, 3), dtype=np.uint8)
+    n = int(rng.integers(1, 7))
+    Rs = fo.generate_rotations(max(n, 2))[:n]
+    poses = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    poses[:, :3, :3] = Rs
+    poses[:, :3, 3] = np.stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), rng.choice([0.12, 0.3, 0.8, 1.5], n)], 1)   # 0.12: through the near plane
+    W, H = int(rng.integers(16, 560)), int(rng.integers(16, 560))
+    fx = float(rng.uniform(200, 900))
+    scale = float(rng.choice([0.1, 0.25, 0.6]))
+    rgb_o, d_o = fo.rasterize(v, f, colors, poses, scale, fx, fx, W / 2, H / 2, W, H)
+    mesh = ops.Mesh(v, f, colors)
+    for tiled in (1, 0):
+        ops.set_option("raster_tiled", tiled)
+        try:
+            rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(poses), scale, fx, fx, W / 2, H / 2, W, H)
+        finally:
+            ops.set_option("raster_tiled", -1)
+        assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32)), (tiled, nv, nf, n, W, H, fx, scale)
+        assert np.array_equal(rgb_g.cpu().numpy(), rgb_o), (tiled, nv, nf, n, W, H, fx, scale)
+    ext_g = ops.depth_extents(d_g, fx, fx, W / 2, H / 2).cpu().numpy()
+    assert np.array_equal(ext_g, fo.depth_extents(d_o, fx, fx, W / 2, H / 2)), (nv, nf, n, W, H)
+
+
+@pytest.mark.parametrize("case", range(max(1, ITERS // 3)))
+def test_fuzz_vit_crop_bits_do_not_depend_on_the_batch(case):
+    """the estimators batch whatever crops they hold (hypotheses of several objects, the query riding along): a crop's features must be
+    the same bits alone, in a small batch and in a large one — across all tile tiers and the row split"""
+    from freepose_amd import ops
+    rng = _rng("vit", case)
+    name, size = [("dinov2_vits14_reg", 224), ("dinov2_vits14_reg", 420), ("dinov2_vitb14_reg", 224), ("dinov2_vitl14_reg", 224)][int(rng.integers(0, 4))]
+    vit = ops.ViT(name, seed=int(rng.integers(0, 100)))
+    B = int(rng.integers(2, 70 if size == 224 else 24))
+    imgs = torch.from_numpy(rng.random((B, 3, size, size)).astype(np.float32)).to(torch.bfloat16).cuda()
+    layer = int(rng.choice([9, 11])) if "vitl" not in name else int(rng.choice([18, 22]))
+    full = vit(imgs, layer=layer, feature_type="patch")
+    cls = vit(imgs, layer=layer, feature_type="cls")
+    for _ in range(3):
+        lo = int(rng.integers(0, B))
+        hi = int(rng.integers(lo + 1, B + 1))
+        assert torch.equal(vit(imgs[lo:hi], layer=layer, feature_type="patch"), full[lo:hi]), (name, size, B, lo, hi)
+    b = int(rng.integers(0, B))
+    assert torch.equal(vit(imgs[b:b + 1], layer=layer, feature_type="cls"), cls[b:b + 1]), (name, size, B, b)

@@ -35,6 +35,26 @@ def test_bank_prepare_and_topk_bit_exact(N, D):
         assert (full == s_o[0, -1]).sum() > 1
 
 
+def test_row_norms_next_to_a_bf16_rounding_boundary():
+    """F.normalize on bf16 rows rounds the norm to bf16 before dividing: a square root that is one fp32 ulp off moves the norm across a
+    rounding boundary for about one row in 16 000, and then EVERY element of the row.  1.5 M short rows hold ~100 such rows; all of
+    them must carry the oracle's bits (the device code needs an IEEE square root, not `__fsqrt_rn` = v_sqrt_f32: csrc/common.h)."""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    g = torch.Generator().manual_seed(77)
+    rows, D = 1_500_000, 64
+    xt = (torch.randn((rows, D), generator=g) * (0.5 + 7.5 * torch.rand((rows, 1), generator=g))).to(torch.bfloat16)
+    x = fo.torch_to_bits(xt)
+    want = fo.l2norm_rows(x)
+    got = fo.torch_to_bits(ops.l2_normalize(xt))
+    bad = np.unique(np.argwhere(got != want)[:, 0])
+    assert len(bad) == 0, f"{len(bad)} rows differ, first {bad[:5]}"
+    # how many rows were at risk: norm within 2 fp32 ulps of a bf16 midpoint
+    n = np.sqrt((fo.bits_to_torch(x).double().numpy() ** 2).sum(1))
+    frac = np.abs((n.astype(np.float32).view(np.uint32) & 0xFFFF).astype(np.int64) - 0x8000)
+    assert (frac <= 2).sum() > 20
+
+
 def test_topk_tie_heavy_and_offsets():
     from freepose_amd import ops
     from oracle import fp_oracle as fo

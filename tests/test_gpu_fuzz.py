@@ -316,3 +316,148 @@ def test_fuzz_vit_crop_bits_do_not_depend_on_the_batch(case):
         assert torch.equal(vit(imgs[lo:hi], layer=layer, feature_type="patch"), full[lo:hi]), (name, size, B, lo, hi)
     b = int(rng.integers(0, B))
     assert torch.equal(vit(imgs[b:b + 1], layer=layer, feature_type="cls"), cls[b:b + 1]), (name, size, B, b)
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_textured_rasterizer_options(case):
+    """textured triangle soups: random texture sizes (not powers of two), UVs far outside [0, 1] (repeat wrap), both filters, every culling
+    mode, both shading rules, ambient and diffuse factors — both strategies against the oracle bit for bit"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    rng = _rng("rastex", case)
+    nv, nf = int(rng.integers(3, 200)), int(rng.integers(1, 400))
+    v = rng.standard_normal((nv, 3)).astype(np.float32)
+    v /= np.abs(v).max()
+    f = rng.integers(0, nv, size=(nf, 3)).astype(np.int32)
+    uv = (rng.standard_normal((nf, 3, 2)) * float(rng.choice([0.3, 1.0, 4.0]))).astype(np.float32)
+    th, tw = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+    tex = rng.integers(0, 256, size=(th, tw, 3), dtype=np.uint8)
+    kd = None if rng.integers(0, 2) else rng.uniform(0.1, 1.0, 3).astype(np.float32)
+    shade, filt, cull = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    ambient = float(rng.choice([1.0, 2.0, 5.0]))
+    n = int(rng.integers(1, 5))
+    poses = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+    poses[:, :3, :3] = fo.generate_rotations(max(n, 2))[:n]
+    poses[:, :3, 3] = np.stack([rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n), rng.choice([0.15, 0.5, 1.2], n)], 1)
+    W, H = int(rng.integers(16, 540)), int(rng.integers(16, 540))
+    fx, fy = float(rng.uniform(200, 900)), float(rng.uniform(200, 900))
+    rgb_o, d_o = fo.rasterize(v, f, None, poses, 0.25, fx, fy, W / 2, H / 2, W, H, ambient=ambient, shade=shade, uv=uv, texture=tex, kd=kd,
+                              filter=filt, cull=cull)
+    mesh = ops.Mesh(v, f, uv=uv, texture=tex, kd=kd).set_ambient(ambient).set_shading(shade).set_filter(filt).set_cull(cull)
+    try:
+        for tiled in (1, 0):
+            ops.set_option("raster_tiled", tiled)
+            rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(poses), 0.25, fx, fy, W / 2, H / 2, W, H)
+            what = (tiled, nv, nf, th, tw, shade, filt, cull, ambient, W, H)
+            assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32)), what
+            assert np.array_equal(rgb_g.cpu().numpy(), rgb_o), what
+    finally:
+        ops.set_option("raster_tiled", -1)
+    xy_o, z_o = fo.project_vertices(v, poses, 0.25, fx, fy, W / 2, H / 2)
+    xy_g, z_g = ops.project_vertices(mesh, torch.from_numpy(poses), 0.25, fx, fy, W / 2, H / 2)
+    assert np.array_equal(xy_g.cpu().numpy(), xy_o) and np.array_equal(z_g.cpu().numpy().view(np.uint32), z_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_depth_extents_and_geodesics(case):
+    """extents of arbitrary depth maps (empty, one pixel, sparse, full; any size) and the geodesic neighbourhood of a random rotation on a
+    random grid, thresholds from 0 to 180 degrees: equal to the oracle (fp64 extents bit for bit, the same index set in the same order)"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    rng = _rng("extents", case)
+    n, H, W = int(rng.integers(1, 9)), int(rng.integers(1, 600)), int(rng.integers(1, 600))
+    depth = (rng.random((n, H, W)) * 3).astype(np.float32)
+    depth[rng.random((n, H, W)) < float(rng.choice([0.0, 0.5, 0.999]))] = 0
+    depth[0] = 0                                              # an empty render
+    if n > 1:
+        depth[1] = 0
+        depth[1, int(rng.integers(0, H)), int(rng.integers(0, W))] = 0.7
+    fx, fy = float(rng.uniform(100, 1200)), float(rng.uniform(100, 1200))
+    cx, cy = float(rng.uniform(0, W)), float(rng.uniform(0, H))
+    e_o = fo.depth_extents(depth, fx, fy, cx, cy)
+    e_g = ops.depth_extents(torch.from_numpy(depth), fx, fy, cx, cy).cpu().numpy()
+    assert np.array_equal(e_g.view(np.uint64), e_o.view(np.uint64)), (n, H, W)
+    G = int(rng.choice([2, 17, 600, 10000, 33333]))
+    grid_o = fo.generate_rotations(G)
+    assert np.abs(ops.generate_rotations(G) - grid_o).max() <= 1e-15
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    R = grid_o[int(rng.integers(0, G))] if rng.integers(0, 2) else q
+    for thr in (0.0, float(rng.uniform(0.5, 30)), float(rng.uniform(30, 180)), 180.0):
+        assert np.array_equal(ops.geodesic_select(torch.from_numpy(grid_o), R, thr), fo.geodesic_select(grid_o, R, thr)), (G, thr)
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_rerank_views_and_roi_align(case):
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    rng = _rng("rerank", case)
+    D = int(rng.choice([384, 768, 1024]))
+    n_mesh = int(rng.integers(1, 40))
+    counts = rng.integers(1, 90, size=n_mesh)
+    views = rng.standard_normal((int(counts.sum()), D)).astype(np.float32)
+    views /= np.linalg.norm(views, axis=1, keepdims=True)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    Q, Cn = int(rng.integers(1, 6)), int(rng.integers(1, min(n_mesh, 20) + 1))
+    cand = np.stack([rng.choice(n_mesh, size=Cn, replace=False) for _ in range(Q)]).astype(np.int32)
+    view_bits = fo.to_bf16_bits(views)
+    q_bits = fo.l2norm_rows(fo.to_bf16_bits(rng.standard_normal((Q, D)).astype(np.float32)))
+    k = int(rng.choice([1, 2, 7, 8, 9, 25, 64, 128]))
+    o = fo.rerank_views(view_bits, off, cand, q_bits, k)
+    g = ops.rerank_views(fo.bits_to_torch(view_bits), torch.from_numpy(off), torch.from_numpy(cand), fo.bits_to_torch(q_bits), k)
+    assert np.array_equal(g.cpu().numpy().view(np.uint32), o.view(np.uint32)), (D, n_mesh, Q, Cn, k)
+    # RoIAlign (aligned=False): boxes inside, across and outside the frame, fractional corners, any output size and sampling ratio
+    N, Cc, H, W = int(rng.integers(1, 3)), int(rng.integers(1, 4)), int(rng.integers(8, 300)), int(rng.integers(8, 300))
+    img = rng.random((N, Cc, H, W)).astype(np.float32)
+    nr = int(rng.integers(1, 8))
+    x1, y1 = rng.uniform(-0.3 * W, W, nr), rng.uniform(-0.3 * H, H, nr)
+    rois = np.stack([rng.integers(0, N, nr).astype(np.float64), x1, y1, x1 + rng.uniform(0, 1.2 * W, nr), y1 + rng.uniform(0, 1.2 * H, nr)], 1).astype(np.float32)
+    ph, pw, sr = int(rng.integers(1, 80)), int(rng.integers(1, 80)), int(rng.choice([0, 1, 2, 3]))
+    scale = float(rng.choice([1.0, 0.5, 0.25]))
+    got = ops.roi_align(torch.from_numpy(img), torch.from_numpy(rois), (ph, pw), sampling_ratio=sr, spatial_scale=scale).cpu().numpy()
+    assert np.array_equal(got, fo.roi_align(img, rois, ph, pw, sr, scale)), (N, Cc, H, W, ph, pw, sr, scale)
+
+
+@pytest.mark.parametrize("case", range(ITERS))
+def test_fuzz_vt_store_layernorm_im2col(case):
+    """the transposed V store (plain and LN-folded) vs fp64, one crop alone == the same crop in a batch; the standalone LayerNorm vs fp64; the patch
+    unfold vs torch's unfold of the normalised image, bit for bit"""
+    from freepose_amd import ops
+    rng = _rng("vt", case)
+    H = int(rng.choice([6, 12, 16]))
+    D = 64 * H
+    npad = 16 * int(rng.integers(1, 95))
+    B = int(rng.integers(1, 6 if npad > 600 else 40))
+    M = B * npad
+    x, w, bias = _bf(rng, (M, D)), _bf(rng, (D, D), 0.05), _bf(rng, (D,), 0.5)
+    vt = ops.gemm_vt(x, w, bias, npad, H)
+    ref = (x.double() @ w.double().t() + bias.double()).reshape(B, npad, H, 64).permute(0, 2, 3, 1)
+    assert _rel(vt, ref) < 6e-3, (B, npad, H)
+    assert ((vt.double().cpu() - ref).abs() <= 0.02 * ref.abs() + 0.03).all(), (B, npad, H)
+    b = int(rng.integers(0, B))                                # a crop's V^T does not depend on the crops beside it
+    assert torch.equal(ops.gemm_vt(x[b * npad:(b + 1) * npad].contiguous(), w, bias, npad, H), vt[b:b + 1]), (B, npad, H, b)
+    g_ln = torch.from_numpy((1.0 + 0.3 * rng.standard_normal(D)).astype(np.float32)).to(torch.bfloat16)
+    b_ln = _bf(rng, (D,), 0.2)
+    vt_ln = ops.ln_linear(x, g_ln, b_ln, w, bias, mode=2, npad=npad, heads=H)
+    y = torch.nn.functional.layer_norm(x.double(), (D,), g_ln.double(), b_ln.double(), 1e-6)
+    ref_ln = (y @ w.double().t() + bias.double()).reshape(B, npad, H, 64).permute(0, 2, 3, 1)
+    assert _rel(vt_ln, ref_ln) < 8e-3, (B, npad, H)
+    assert torch.equal(ops.ln_linear(x[b * npad:(b + 1) * npad].contiguous(), g_ln, b_ln, w, bias, mode=2, npad=npad, heads=H), vt_ln[b:b + 1])
+    rows = np.unique(rng.integers(0, M, size=min(M, 64)))
+    ln = ops.layernorm(x, g_ln, b_ln)
+    ref = torch.nn.functional.layer_norm(x[rows].double(), (D,), g_ln.double(), b_ln.double(), 1e-6)
+    assert ((ln[torch.from_numpy(rows).cuda()].double().cpu() - ref).abs() <= 0.01 * ref.abs() + 0.02).all(), (M, D)
+    # im2col + ImageNet normalisation
+    ps = int(rng.choice([14, 16, 7]))
+    gh, gw = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    Bi = int(rng.integers(1, 5))
+    img = torch.from_numpy(rng.random((Bi, 3, gh * ps, gw * ps)).astype(np.float32)).to(torch.bfloat16)
+    kp = (3 * ps * ps + 63) // 64 * 64
+    got = ops.im2col_norm(img, ps, kp).cpu()
+    mean = torch.tensor([0.485, 0.456, 0.406]).to(torch.bfloat16).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).to(torch.bfloat16).view(1, 3, 1, 1)
+    normed = (img - mean) / std                                                  # two bf16 operations, each rounded (dino.py:12,16)
+    K = 3 * ps * ps
+    want = normed.unfold(2, ps, ps).unfold(3, ps, ps).permute(0, 2, 3, 1, 4, 5).reshape(Bi * gh * gw, K)
+    assert torch.equal(got[:, :K], want), (Bi, gh, gw, ps)
+    assert (got[:, K:] == 0).all()

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from freepose_amd import ops
-from freepose_amd.src.utils.bbox_utils import CropResizePad
+from freepose_amd.src.utils.bbox_utils import CropResizePad, unresizable_box
 
 
 # ---- proposals-JSON mask codec: uncompressed COCO RLE, column-major, first run = background -----------------
@@ -72,6 +72,9 @@ class Proposals:
         img = self._image_u8[None].cuda()
         masks = self.masks.cuda().to(torch.uint8)
         ext = float(self.rgb_proposal_processor.bbox_extend)
+        bad = unresizable_box(self.boxes.cpu().numpy(), self._image_u8.shape[0], self._image_u8.shape[1], T, ext)
+        if bad >= 0:           # the reference's CropResizePad raises on such a detection (torch, bbox_utils.py:35)
+            raise RuntimeError(f"Proposals: detection {bad} {self.boxes[bad].tolist()} has an empty crop or resizes to a side of 0 px")
         rgbs = ops.crop_resize_pad(img, self.boxes, T, ext, masks, 1 if mask_rgb else 0, u8_float_div=True)
         m = ops.crop_resize_pad(img, self.boxes, T, ext, masks, 2, u8_float_div=True)
         return rgbs, m[:, 0] > 0.5

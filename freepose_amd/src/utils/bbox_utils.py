@@ -14,6 +14,38 @@ import torch
 from freepose_amd import ops
 
 
+def unresizable_box(boxes, h: int, w: int, target: int, bbox_extend: float) -> int:
+    """Index of the first box the reference cannot crop, or -1: after the extension and the clip to the image (bbox_utils.py:20-28) the
+    crop is empty, or `F.interpolate(scale_factor = target / max side)` (:30-35) would have to produce a side of 0 px — torch raises
+    "Input and output sizes should be greater than 0" there and the reference's script ends — or the crop does not come out at the
+    target size (see below).  Same integer / float32 arithmetic as the
+    device kernel (csrc/pose.hip crop_params_kernel) and the oracle (fpo_crop_resize_pad), on the host: no device round trip."""
+    b = np.asarray(boxes).reshape(-1, 4).astype(np.int64)
+    x0, y0, x1, y1 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    if float(bbox_extend) == 0.0:
+        x0, y0, x1, y1 = np.maximum(x0, 0), np.maximum(y0, 0), np.minimum(x1, w), np.minimum(y1, h)
+    else:
+        e = np.float32(bbox_extend)
+        ew, eh = e * (x1 - x0).astype(np.float32), e * (y1 - y0).astype(np.float32)
+        fx0, fx1 = x0.astype(np.float32) - ew, x1.astype(np.float32) + ew
+        fy0, fy1 = y0.astype(np.float32) - eh, y1.astype(np.float32) + eh
+        x0 = np.where(fx0 > 0, np.trunc(fx0), 0).astype(np.int64)
+        x1 = np.where(fx1 < np.float32(w), np.trunc(fx1), w).astype(np.int64)
+        y0 = np.where(fy0 > 0, np.trunc(fy0), 0).astype(np.int64)
+        y1 = np.where(fy1 < np.float32(h), np.trunc(fy1), h).astype(np.int64)
+    cw, ch = x1 - x0, y1 - y0
+    side = np.maximum(np.maximum(cw, ch), 1)
+    scale = ((np.float32(1.0) / side.astype(np.float32)) * np.float32(target)).astype(np.float64)      # reciprocal(tensor) * scalar in float32, then .item()
+    h1, w1 = np.floor(ch * scale), np.floor(cw * scale)
+    # a crop that is exactly square is not padded to the target (:41-48) and the last resize (:52-54) can then come out one pixel short
+    # (floor(h1 * (target / h1)) = target - 1): the reference's torch.stack of unequal crops, or the ViT's patch-size check, raises
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s_h = np.where(w1 / h1 != 1.0, float(target), h1)
+        out = np.floor(s_h * (float(target) / s_h))
+    bad = np.flatnonzero((cw <= 0) | (ch <= 0) | (h1 <= 0) | (w1 <= 0) | (out != target))
+    return int(bad[0]) if len(bad) else -1
+
+
 class CropResizePad:
     def __init__(self, target_size: Union[Tuple, int], orig_size: Union[Tuple, int], bbox_extend: float = 0):
         if isinstance(target_size, int):
@@ -41,6 +73,13 @@ class CropResizePad:
             raise ValueError(f"image size {tuple(images.shape[-2:])} differs from orig_size {(self.h, self.w)}")
         if images.shape[0] not in (1, n):
             raise ValueError("need one image per box (or a single shared image)")
+        if not boxes.is_cuda:
+            # the reference fails on such a box (torch raises inside F.interpolate, bbox_utils.py:35); boxes that live on the device (the
+            # template loader's, cut from depth masks of >= 100 px or the fallback square) are not read back for this
+            bad = unresizable_box(boxes.numpy(), self.h, self.w, self.target_max, float(self.bbox_extend))
+            if bad >= 0:
+                raise RuntimeError(f"CropResizePad: box {bad} {boxes[bad].tolist()} has an empty crop or resizes to a side of 0 px "
+                                   f"(target {self.target_max}, extension {self.bbox_extend}) — the reference's F.interpolate raises here")
         return ops.crop_resize_pad(images, boxes, self.target_max, float(self.bbox_extend), masks, mask_mode, out_bf16)
 
 

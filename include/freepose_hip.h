@@ -119,7 +119,11 @@ int fp_template_score_normed(fp_ctx* ctx, const void* d_tmpl_normed, const void*
  * d_boxes i32 [n,4] xyxy BEFORE extension.  d_masks u8 [n,H,W] or NULL; mask_mode 0 = ignore,
  * 1 = multiply pixels by the mask (mask_rgb=True, utils.py:39-40), 2 = output the mask itself as 0/1
  * (utils.py:35-37,48-51).  d_out: out_fmt 0 = f32, 1 = bf16, shape [n,C,target,target].
- * Nearest-neighbour index rules replicate F.interpolate exactly (bbox_utils.py:29-35,52-54). */
+ * Nearest-neighbour index rules replicate F.interpolate exactly (bbox_utils.py:29-35,52-54).
+ * A box the reference cannot crop — empty after the clip, a resized side of 0 px (torch raises inside F.interpolate, :35) or an
+ * exactly square crop that comes out one pixel short of `target` — gets an all-zero crop here (the boxes are device data: no
+ * read-back); the Python mirror classes raise on such boxes like the reference when the boxes are host-resident
+ * (freepose_amd/src/utils/bbox_utils.py unresizable_box: the same arithmetic on the host). */
 int fp_crop_resize_pad(fp_ctx* ctx, const void* d_images, int src_fmt, int n_img, int C, int H, int W,
                        const int32_t* d_boxes, int n, float bbox_extend, int target, const uint8_t* d_masks,
                        int mask_mode, void* d_out, int out_fmt, void* stream);

@@ -277,7 +277,8 @@ int fpo_crop_resize_pad(const void* images, int src_u8, int n_img, int C, int H,
         const double scale2 = (double)target / (double)S_h;               /* :52-54 */
         const int outsz = (int)floor((double)S_h * scale2);
         const float inv2 = (float)(1.0 / scale2);
-        if (outsz != target || cw <= 0 || ch <= 0) return 1 + i;
+        /* a crop the reference cannot make: empty, or F.interpolate would have to produce a side of 0 px (torch raises, :35) */
+        if (outsz != target || cw <= 0 || ch <= 0 || h1 <= 0 || w1 <= 0) return 1 + i;
         const int img = n_img == 1 ? 0 : i;
         for (int oy = 0; oy < target; ++oy)
             for (int ox = 0; ox < target; ++ox) {

@@ -1,0 +1,215 @@
+"""Randomised pinning of the oracle: IMPORT the reference (/root/reference) in this container and run its own functions beside the
+oracle's restatements on thousands of seeded random inputs — the same comparison the golden fixtures make (oracle/gen_golden.py) at
+inputs nobody chose.  Test infrastructure, run by hand here (the reference does not travel); its log is committed:
+
+    python -m oracle.fuzz_vs_reference [cases-per-section] [seed]  >  profiles/r05_oracle_fuzz_vs_reference.log
+
+Sections (reference function -> oracle / host restatement, criterion):
+  crop      src/utils/bbox_utils.py CropResizePad.__call__           -> fpo_crop_resize_pad                       every byte equal; a box torch
+            refuses (F.interpolate to 0 px) is refused by the oracle and by the mirror's host check (bbox_utils.unresizable_box), and no other
+  proposals src/pipeline/utils.py Proposals (crops + crop masks)     -> fpo_crop_resize_pad modes 0 / 1 / 2       every byte equal
+  rle       sam2/utils/amg.py mask_to_rle_pytorch / rle_to_mask      -> freepose_amd.src.pipeline.utils           equal
+  depth     depthmap_to_pointcloud + get_z_from_pointcloud, mask_to_bbox -> fpo_depth_extents + z_from_extents    count / bbox equal, extents <= 1e-12, pose <= 1e-9 m
+  poses     DinoPoseEstimator.generate_poses(n)                      -> fpo_generate_rotations                    <= 1e-15
+  geodesic  DinoOnlinePoseEstimator.geodesic_distance < threshold    -> fpo_geodesic_select                       the same index list
+Shims for packages the image lacks are gen_golden's (none of them is on the functions under test)."""
+from __future__ import annotations
+
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from oracle import fp_oracle as fo
+from oracle.gen_golden import REF, install_shims
+
+
+def main():
+    assert REF.exists(), "/root/reference is only present in the build container"
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    # host-side product code under test is imported BEFORE the shims drop the repo's alias packages from the path
+    from freepose_amd.src.pipeline.utils import mask_to_rle_pytorch as my_to_rle, rle_to_mask as my_from_rle, z_from_extents
+    from freepose_amd.src.utils.bbox_utils import unresizable_box
+    install_shims()
+    from src.utils.bbox_utils import CropResizePad
+    from src.pipeline.utils import Proposals, depthmap_to_pointcloud, get_z_from_pointcloud, mask_to_bbox
+    from sam2.utils.amg import mask_to_rle_pytorch, rle_to_mask
+    import src.pipeline.estimators.pose_estimator as pe_mod
+    import src.pipeline.estimators.online_pose_estimator as on_mod
+    torch.set_num_threads(8)
+    print(f"oracle vs reference, {n_cases} random cases per section, seed {seed}")
+
+    def rng_of(section, case):
+        return np.random.Generator(np.random.PCG64([seed, sum(map(ord, section)), case]))
+
+    # ---- crop ------------------------------------------------------------------------------------------------------------
+    t0, n_box, n_raise = time.time(), 0, 0
+    for case in range(n_cases):
+        rng = rng_of("crop", case)
+        H, W = int(rng.integers(12, 260)), int(rng.integers(12, 260))
+        target = int(rng.choice([14, 30, 42, 98, 224]))
+        ext = float(rng.choice([0, 0.05, 0.1, 0.2, 0.5]))
+        img = rng.random((3, H, W)).astype(np.float32)
+        boxes = []
+        for _ in range(int(rng.integers(1, 9))):
+            kind = rng.integers(0, 4)
+            x0, y0 = int(rng.integers(0, W - 4)), int(rng.integers(0, H - 4))
+            if kind == 0:
+                boxes.append([x0, y0, int(rng.integers(x0 + 2, W + 1)), int(rng.integers(y0 + 2, H + 1))])
+            elif kind == 1:
+                boxes.append([x0, y0, x0 + int(rng.integers(1, 4)), int(rng.integers(y0 + 1, H + 1))])      # a sliver
+            elif kind == 2:
+                boxes.append([0, 0, W, H])
+            else:
+                boxes.append([x0, y0, min(W, x0 + int(rng.integers(3, 60))), min(H, y0 + int(rng.integers(3, 60)))])
+        boxes = np.array(boxes, dtype=np.int32)
+        proc = CropResizePad(target, (H, W), bbox_extend=ext)
+        for b in boxes:                                       # one box at a time: a box the reference cannot resize must fail in the oracle too
+            try:
+                want = proc(torch.from_numpy(img)[None], torch.from_numpy(b[None])).numpy()
+                made = want.shape[-1] == target               # (an exactly square crop can come out one pixel short: unusable downstream)
+            except Exception:
+                made = False
+            if not made:
+                n_raise += 1
+                assert unresizable_box(b[None], H, W, target, ext) == 0, f"crop case {case}: the mirror's host check lets box {b.tolist()} through"
+                try:
+                    fo.crop_resize_pad(img[None], b[None], target, ext)
+                except ValueError:
+                    continue
+                raise AssertionError(f"crop case {case}: the reference raises on box {b.tolist()} ({H}x{W}, target {target}, ext {ext}), the oracle does not")
+            assert unresizable_box(b[None], H, W, target, ext) == -1, f"crop case {case}: the mirror's host check refuses box {b.tolist()}"
+            got = fo.crop_resize_pad(img[None], b[None], target, ext)
+            assert np.array_equal(got, want), f"crop case {case}: box {b.tolist()} image {H}x{W} target {target} ext {ext}: {np.abs(got - want).max()}"
+            n_box += 1
+    print(f"crop      {n_cases} cases, {n_box} boxes byte-identical, {n_raise} boxes the reference cannot crop to the target size: refused by the oracle and the mirror too   ({time.time() - t0:.0f} s)")
+
+    # ---- proposals -----------------------------------------------------------------------------------------------------------
+    t0, n_prop, n_short = time.time(), 0, 0
+    for case in range(n_cases):
+        rng = rng_of("proposals", case)
+        Hi, Wi = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+        image = rng.integers(0, 256, size=(Hi, Wi, 3), dtype=np.uint8)
+        n = int(rng.integers(1, 5))
+        yy, xx = np.mgrid[0:Hi, 0:Wi]
+        masks, boxes = [], []
+        for _ in range(n):
+            cy, cx = rng.uniform(0.2, 0.8) * Hi, rng.uniform(0.2, 0.8) * Wi
+            ry, rx = rng.uniform(0.08, 0.3) * Hi, rng.uniform(0.08, 0.3) * Wi
+            m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1
+            if rng.integers(0, 3) == 0:
+                m &= rng.random((Hi, Wi)) < 0.8                                         # a mask with holes
+            ys, xs = np.nonzero(m)
+            masks.append(m)
+            boxes.append([xs.min(), ys.min(), xs.max() + 1, ys.max() + 1])
+        masks, boxes = np.stack(masks), np.array(boxes, dtype=np.int64)
+        res = int(rng.choice([28, 56, 98]))
+        ext = float(rng.choice([0.05, 0.1, 0.2]))
+        mask_rgb = bool(rng.integers(0, 2))
+        try:
+            p = Proposals(image, {"masks": torch.from_numpy(masks), "boxes": torch.from_numpy(boxes)}, res, 1, 2, bbox_extend=ext, mask_rgb=mask_rgb)
+            sizes_ok = tuple(p.proposals.shape[-2:]) == (res, res)
+        except RuntimeError:                                   # torch.stack of crops of unequal size (an exactly square box can come out one pixel short)
+            sizes_ok = False
+        if not sizes_ok:
+            n_short += 1
+            assert unresizable_box(boxes, Hi, Wi, res, ext) >= 0, f"proposals case {case}: the mirror's host check lets the detections through"
+            try:
+                fo.crop_resize_pad(image[None], boxes.astype(np.int32), res, ext, masks.astype(np.uint8), 0, u8_float_div=True)
+            except ValueError:
+                continue
+            raise AssertionError(f"proposals case {case}: the reference cannot make {res} px crops of these detections, the oracle does")
+        assert unresizable_box(boxes, Hi, Wi, res, ext) == -1, f"proposals case {case}: the mirror's host check refuses good detections"
+        rgb = fo.crop_resize_pad(image[None], boxes.astype(np.int32), res, ext, masks.astype(np.uint8), 1 if mask_rgb else 0, u8_float_div=True)
+        mm = fo.crop_resize_pad(image[None], boxes.astype(np.int32), res, ext, masks.astype(np.uint8), 2, u8_float_div=True)
+        assert np.array_equal(rgb, p.proposals.numpy()), f"proposals case {case}: crops differ ({Hi}x{Wi}, res {res}, ext {ext}, mask_rgb {mask_rgb})"
+        assert np.array_equal(mm[:, 0] > 0.5, p.proposals_masks.numpy()), f"proposals case {case}: crop masks differ"
+        n_prop += n
+    print(f"proposals {n_cases} cases, {n_prop} proposals: crops and crop masks byte-identical; {n_short} cases where the reference cannot make crops of "
+          f"the target size (refused by the oracle and the mirror too)   ({time.time() - t0:.0f} s)")
+
+    # ---- rle -------------------------------------------------------------------------------------------------------------
+    t0 = time.time()
+    for case in range(n_cases):
+        rng = rng_of("rle", case)
+        H, W, n = int(rng.integers(1, 120)), int(rng.integers(1, 120)), int(rng.integers(1, 5))
+        m = rng.random((n, H, W)) < float(rng.choice([0.0, 0.02, 0.5, 0.98, 1.0]))
+        ref = mask_to_rle_pytorch(torch.from_numpy(m))
+        mine = my_to_rle(m)
+        for a, b, mk in zip(ref, mine, m):
+            assert list(a["size"]) == list(b["size"]) and list(a["counts"]) == list(b["counts"]), f"rle case {case}"
+            assert np.array_equal(my_from_rle(a), mk) and np.array_equal(rle_to_mask(b), mk), f"rle case {case}: decode"
+    print(f"rle       {n_cases} cases: encoder and decoder equal to sam2's, both directions   ({time.time() - t0:.0f} s)")
+
+    # ---- depth -> point cloud -> pose ------------------------------------------------------------------------------------------
+    t0, worst_ext, worst_t = time.time(), 0.0, 0.0
+    grid = np.array(pe_mod.DinoPoseEstimator.generate_poses(64))
+    for case in range(n_cases):
+        rng = rng_of("depth", case)
+        depth = np.zeros((420, 420), np.float32)
+        y0, x0 = int(rng.integers(0, 400)), int(rng.integers(0, 400))
+        h, w = int(rng.integers(1, 420 - y0 + 1)), int(rng.integers(1, 420 - x0 + 1))
+        if rng.integers(0, 6) == 0:
+            h, w = min(h, 9), min(w, 9)                                                  # fewer than 100 px: the fallback square
+        patch = (0.3 + 2.0 * rng.random((h, w))).astype(np.float32)
+        patch[rng.random((h, w)) < float(rng.choice([0.0, 0.3, 0.9]))] = 0
+        depth[y0:y0 + h, x0:x0 + w] = patch
+        if not (depth > 0).any():
+            depth[y0, x0] = 1.0
+        K420 = np.array([[600, 0, 210], [0, 600, 210], [0, 0, 1]], dtype=np.int64)
+        ext = fo.depth_extents(depth[None], 600, 600, 210, 210)[0]
+        pc = depthmap_to_pointcloud(depth, K420)
+        assert len(pc) == int(ext[6]), f"depth case {case}: point count"
+        ex, ey = pc[:, 0].max() - pc[:, 0].min(), pc[:, 1].max() - pc[:, 1].min()
+        worst_ext = max(worst_ext, abs(ext[4] - ex), abs(ext[5] - ey))
+        mask = depth > 0
+        if mask.sum() < 100:
+            mask[105:315, 105:315] = True                                                # template.py:75-77, renderer.py:116-117
+        bb = mask_to_bbox(mask)
+        assert list(ext[:4]) == list(bb), f"depth case {case}: mask bbox {list(ext[:4])} vs {list(bb)}"
+        Kq = np.array([[rng.uniform(400, 1200), 0, rng.uniform(200, 400)], [0, rng.uniform(400, 1200), rng.uniform(150, 300)], [0, 0, 1]])
+        bx0, by0 = rng.uniform(0, 400), rng.uniform(0, 300)
+        bbox = np.array([bx0, by0, bx0 + rng.uniform(5, 300), by0 + rng.uniform(5, 300)])
+        est = float(rng.uniform(0.02, 0.5))
+        pose = grid[int(rng.integers(0, 64))]
+        mean = pc.mean(axis=0)
+        pc2 = (pc - mean) / 0.25 * est + mean
+        want = get_z_from_pointcloud(bbox, pc2, Kq, pose)
+        got = z_from_extents(bbox, ext[4] * est / 0.25, ext[5] * est / 0.25, Kq, pose)
+        worst_t = max(worst_t, float(np.abs(np.asarray(got) - np.asarray(want)).max()))
+    assert worst_ext < 1e-12 and worst_t < 1e-9, (worst_ext, worst_t)
+    print(f"depth     {n_cases} cases: point counts and mask boxes equal, extents within {worst_ext:.1e}, poses within {worst_t:.1e} m   ({time.time() - t0:.0f} s)")
+
+    # ---- rotation grids + geodesic neighbourhoods ----------------------------------------------------------------------------------
+    t0, worst_R, n_sel = time.time(), 0.0, 0
+    for case in range(max(1, n_cases // 10)):
+        rng = rng_of("poses", case)
+        n = int(rng.choice([1, 2, 3, int(rng.integers(4, 3000)), int(rng.integers(3000, 30000))]))
+        ref = np.array(pe_mod.DinoPoseEstimator.generate_poses(n))
+        R = fo.generate_rotations(n)
+        worst_R = max(worst_R, float(np.abs(R - ref[:, :3, :3]).max()))
+        assert (ref[:, 3] == [0, 0, 0, 1]).all()
+        for _ in range(10):
+            q = np.eye(4)
+            if rng.integers(0, 2):
+                q[:3, :3] = ref[int(rng.integers(0, n)), :3, :3]
+            else:
+                a, _r = np.linalg.qr(rng.standard_normal((3, 3)))
+                q[:3, :3] = a * np.sign(np.linalg.det(a))
+            thr = float(rng.choice([rng.uniform(1, 40), rng.uniform(40, 180)]))
+            d = on_mod.DinoOnlinePoseEstimator.geodesic_distance(ref[:, :3, :3], q)
+            if np.abs(d - thr).min() < 1e-9:
+                continue                                                                 # (a distance ON the threshold: not decidable in floating point)
+            want = np.where(d < thr)[0]
+            assert np.array_equal(fo.geodesic_select(ref[:, :3, :3], q, thr), want), f"geodesic case {case}: n {n} thr {thr}"
+            n_sel += 1
+    assert worst_R <= 1e-15, worst_R
+    print(f"poses     {max(1, n_cases // 10)} grids within {worst_R:.1e} of generate_poses; geodesic: {n_sel} neighbourhoods, identical index lists   ({time.time() - t0:.0f} s)")
+    print("all sections green")
+
+
+if __name__ == "__main__":
+    main()

@@ -54,3 +54,22 @@ def test_fully_masked_and_degenerate_boxes():
     boxes = torch.tensor([[10, 10, 10, 10], [-50, -50, 5, 5], [60, 60, 200, 200]], dtype=torch.int32).cuda()
     out = ops.crop_resize_pad(img, boxes, 32, 0.0)
     assert out.shape == (3, 3, 32, 32) and torch.isfinite(out).all()
+
+
+def test_detection_the_reference_cannot_crop_raises_like_the_reference():
+    """a detection whose crop resizes to a side of 0 px ends the reference's script inside F.interpolate (bbox_utils.py:35); the mirror
+    classes raise too (host check on the host-resident boxes) instead of handing the ViT the kernel's all-zero crop"""
+    import numpy as np
+    from freepose_amd.src.pipeline.utils import Proposals
+    from freepose_amd.src.utils.bbox_utils import CropResizePad
+    img = np.zeros((146, 125, 3), dtype=np.uint8)
+    masks = np.zeros((2, 146, 125), dtype=bool)
+    masks[0, 20:60, 20:60] = True
+    masks[1, 87:132, 43] = True
+    dets = {"masks": torch.from_numpy(masks), "boxes": torch.tensor([[20, 20, 60, 60], [43, 87, 44, 132]])}
+    with pytest.raises(RuntimeError, match="detection 1"):
+        Proposals(img, dets, 30, 0, 0, bbox_extend=0.5)
+    ok = Proposals(img, {"masks": dets["masks"][:1], "boxes": dets["boxes"][:1]}, 30, 0, 0, bbox_extend=0.5)
+    assert ok.proposals.shape == (1, 3, 30, 30)
+    with pytest.raises(RuntimeError, match="box 0"):
+        CropResizePad(30, (146, 125), bbox_extend=0.5)(torch.zeros((1, 3, 146, 125)), torch.tensor([[43, 87, 44, 132]]))

@@ -12,6 +12,9 @@ Sections (reference function -> oracle / host restatement, criterion):
   depth     depthmap_to_pointcloud + get_z_from_pointcloud, mask_to_bbox -> fpo_depth_extents + z_from_extents    count / bbox equal, extents <= 1e-12, pose <= 1e-9 m
   poses     DinoPoseEstimator.generate_poses(n)                      -> fpo_generate_rotations                    <= 1e-15
   geodesic  DinoOnlinePoseEstimator.geodesic_distance < threshold    -> fpo_geodesic_select                       the same index list
+  csv       scripts/dino_inference.py:113-127, dino_inference_video.py:160-176 (exec'd) -> scripts.dino_inference.pose_row   the CSV text
+  score     pose_estimator.py:85-88 (normalize, einsum, mean in bf16 torch)   -> fpo_template_score                       <= 1 bf16 ulp, same arg-max when decisive
+  retrieval extract_proposals_ground.py:40-41,130-140 (torch expressions)     -> fpo_bank_prepare / scores / topk, fpo_ffa  >= 99.8 % of scores identical, same top-100 multiset
 Shims for packages the image lacks are gen_golden's (none of them is on the functions under test)."""
 from __future__ import annotations
 
@@ -33,6 +36,7 @@ def main():
     # host-side product code under test is imported BEFORE the shims drop the repo's alias packages from the path
     from freepose_amd.src.pipeline.utils import mask_to_rle_pytorch as my_to_rle, rle_to_mask as my_from_rle, z_from_extents
     from freepose_amd.src.utils.bbox_utils import unresizable_box
+    from freepose_amd.scripts.dino_inference import CSV_COLUMNS, pose_row
     install_shims()
     from src.utils.bbox_utils import CropResizePad
     from src.pipeline.utils import Proposals, depthmap_to_pointcloud, get_z_from_pointcloud, mask_to_bbox
@@ -208,6 +212,101 @@ def main():
             n_sel += 1
     assert worst_R <= 1e-15, worst_R
     print(f"poses     {max(1, n_cases // 10)} grids within {worst_R:.1e} of generate_poses; geodesic: {n_sel} neighbourhoods, identical index lists   ({time.time() - t0:.0f} s)")
+    # ---- CSV rows of the two pose drivers ------------------------------------------------------------------------------------------
+    import io
+    import types
+    import pandas as pd
+    from scipy.spatial.transform import Rotation as Rot
+    from oracle.gen_golden_r2 import _ref_block
+    t0 = time.time()
+    img_block = _ref_block(REF / "scripts" / "dino_inference.py", 'results_dict["scene_id"].append(int(scene_id))', 'results_dict["time"].append(0.2)')
+    vid_block = _ref_block(REF / "scripts" / "dino_inference_video.py", 'results_dict["scene_id"].append(0)', 'results_dict["time"].append(-1)')
+    keys = ["scene_id", "im_id", "obj_id", "score", "R", "t", "bbox_visib", "scale", "time"]
+    for case in range(n_cases):
+        rng = rng_of("csv", case)
+        T = np.eye(4)
+        T[:3, :3] = Rot.from_rotvec(rng.standard_normal(3) * float(rng.choice([1e-4, 1.0, 3.0]))).as_matrix()
+        T[:3, 3] = rng.standard_normal(3) * float(rng.choice([1e-6, 0.1, 5.0, 1e4]))
+        if rng.integers(0, 8) == 0:
+            T[:3, 3] = [0.0, -0.0, 1.0]
+        score = np.float32(torch.tensor(float(rng.uniform(-1, 1))).to(torch.bfloat16).float().item())
+        out = {"TCO": [T, np.eye(4), np.eye(4)], "scores": np.array([score, 0.5, 0.25], dtype=np.float32),
+               "bbox": torch.tensor([int(v) for v in rng.integers(0, 2000, 4)])}
+        mesh = str(rng.choice(["0a1b2c3d4e5f60718293a4b5c6d7e8f9", "Shark", "mug_01", "7"]))
+        scale = float(rng.choice([0.05, 0.1234567, 1e-3, 0.3, 1 / 3]))
+        scene, frame = str(int(rng.integers(0, 100))), int(rng.integers(0, 5000))
+        rd = {k: [] for k in keys}
+        exec(img_block, {"np": np}, {"results_dict": rd, "scene_id": scene, "frame_id": frame, "proposals": types.SimpleNamespace(meshes=[mesh]),
+                                     "prop_idx": 0, "out": out, "scales": [scale]})
+        want, got = io.StringIO(), io.StringIO()
+        pd.DataFrame(rd).to_csv(want, index=False, header=True)
+        pd.DataFrame([pose_row(scene, frame, mesh, out["scores"][0], T, out["bbox"].numpy(), scale)], columns=CSV_COLUMNS).to_csv(got, index=False, header=True)
+        assert got.getvalue() == want.getvalue(), f"csv case {case} (image driver):\n{got.getvalue()}\n{want.getvalue()}"
+        rd = {k: [] for k in keys}
+        exec(vid_block, {"np": np}, {"results_dict": rd, "frame_idx": frame, "mesh_id": mesh, "out": out, "scales": [scale], "obj_idx": 0})
+        want, got = io.StringIO(), io.StringIO()
+        pd.DataFrame(rd).to_csv(want, index=False, header=True)
+        pd.DataFrame([pose_row(0, frame, mesh, out["scores"][0], T, out["bbox"].numpy(), scale, t_scale=1, time_value=-1)],
+                     columns=CSV_COLUMNS).to_csv(got, index=False, header=True)
+        assert got.getvalue() == want.getvalue(), f"csv case {case} (video driver):\n{got.getvalue()}\n{want.getvalue()}"
+    print(f"csv       {n_cases} cases: rows of both drivers character for character   ({time.time() - t0:.0f} s)")
+
+    # ---- bf16 score expressions (the reference leaves the reduction order to torch: agreement is statistical, never worse than 1 ulp) ----
+    import torch.nn.functional as F
+    from einops import einsum
+    t0, same, total, worst = time.time(), 0, 0, 0.0
+    decisive, agree = 0, 0
+    for case in range(max(1, n_cases // 20)):
+        rng = rng_of("score", case)
+        Tn, P, D = int(rng.integers(2, 40)), int(rng.choice([36, 256, 900])), int(rng.choice([64, 384, 1024]))
+        base = rng.standard_normal((P, D)).astype(np.float32)
+        tm = torch.from_numpy((base[None] * 0.5 + rng.standard_normal((Tn, P, D))).astype(np.float32)).to(torch.bfloat16)
+        q = torch.from_numpy((base + 0.7 * rng.standard_normal((P, D))).astype(np.float32)).to(torch.bfloat16)
+        if rng.integers(0, 2):                                                            # a planted answer: one template is a noisy copy of the query
+            tm[int(rng.integers(0, Tn))] = (q.float() + 0.5 * torch.from_numpy(rng.standard_normal((P, D)).astype(np.float32))).to(torch.bfloat16)
+        ref = einsum(F.normalize(tm, dim=-1), F.normalize(q[None], dim=-1).expand(Tn, -1, -1), "b n d, b n d -> b n").mean(dim=-1).float().numpy()   # pose_estimator.py:85-88
+        s = fo.template_score(fo.torch_to_bits(tm), fo.l2norm_rows(fo.torch_to_bits(q)))
+        ulp = np.abs(ref) * 2.0 ** -7 + 1e-9
+        worst = max(worst, float((np.abs(s - ref) / ulp).max()))
+        same += int((s == ref).sum())
+        total += Tn
+        top2 = np.sort(ref)[::-1][:2]
+        if top2[0] - top2[1] > 2 * ulp.max():
+            decisive += 1
+            agree += int(s.argmax() == ref.argmax())
+    assert worst <= 1.0 and agree == decisive, (worst, agree, decisive)
+    print(f"score     {max(1, n_cases // 20)} template sets: {same}/{total} scores bit-identical to the reference's torch expression, all within "
+          f"{worst:.2f} bf16 ulp; arg-max identical on all {decisive} decisive sets   ({time.time() - t0:.0f} s)")
+
+    t0, same, total, n_set = time.time(), 0, 0, 0
+    for case in range(max(1, n_cases // 50)):
+        rng = rng_of("retrieval", case)
+        N, D = int(rng.integers(200, 4000)), int(rng.choice([384, 1024]))
+        bank = rng.standard_normal((N, D)).astype(np.float32) + 2.0 * rng.standard_normal(D).astype(np.float32)
+        rf = F.normalize(torch.from_numpy(bank).to(torch.bfloat16), dim=-1)                   # extract_proposals_ground.py:40-41
+        feat = torch.from_numpy(rng.standard_normal((900, D)).astype(np.float32)).to(torch.bfloat16)
+        m = rng.random(900) < rng.uniform(0.05, 0.9)
+        m[0] = True
+        qref = F.normalize(feat[torch.from_numpy(m)].mean(dim=0)[None], dim=-1)[0]            # :130-134
+        ffa_bits, _ = fo.ffa(fo.torch_to_bits(feat)[None], m.astype(np.uint8).reshape(1, 1, 900), 1)
+        d = np.abs(fo.from_bf16_bits(ffa_bits[0]) - feat[torch.from_numpy(m)].mean(dim=0).float().numpy())
+        assert (d <= np.abs(fo.from_bf16_bits(ffa_bits[0])) * 2.0 ** -7 + 1e-6).all(), f"retrieval case {case}: FFA"
+        ref = (rf @ qref).float().numpy()                                                     # :137
+        bank_bits = fo.bank_prepare(bank)
+        sc = fo.bank_scores(bank_bits, fo.torch_to_bits(qref[None])[0])
+        same += int((sc == ref).sum())
+        total += N
+        assert (np.abs(sc - ref) <= np.abs(ref) * 2.0 ** -5 + 1e-6).all(), f"retrieval case {case}: scores"
+        k = min(100, N)
+        s, i = fo.bank_topk(bank_bits, fo.torch_to_bits(qref[None]), k)
+        top = torch.topk(torch.from_numpy(ref), k)                                            # :140
+        assert np.allclose(np.sort(s[0]), np.sort(top.values.numpy()), atol=2.0 ** -8), f"retrieval case {case}: top-k scores"
+        thr = top.values.numpy().min()
+        assert (ref[i[0]] >= thr - abs(thr) * 2.0 ** -7).all(), f"retrieval case {case}: top-k members"
+        n_set += 1
+    assert same / total >= 0.998
+    print(f"retrieval {n_set} banks: {same}/{total} bank scores bit-identical to torch's bf16 matmul (the rest: rows whose bf16 norm flips under torch's "
+          f"reduction order), top-100 = the same score multiset, every member above the reference's 100th score   ({time.time() - t0:.0f} s)")
     print("all sections green")
 
 

@@ -150,6 +150,7 @@ __device__ __forceinline__ void aa_window(int i, int in, int out, int& xmin, int
     xmin = max((int)(center - support + 0.5f), 0);
     xsize = min((int)(center + support + 0.5f), in) - xmin;
 }
+constexpr int AA_MAX_TAPS = 192;
 __global__ void posembed_aa_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int G, int gh,
                                    int gw, int D) {
     const int op = blockIdx.x;  // output patch
@@ -158,18 +159,22 @@ __global__ void posembed_aa_kernel(const bf16_t* __restrict__ src, bf16_t* __res
     float cy, iy, cx, ix;
     aa_window(oy, G, gh, ymin, ysize, cy, iy);
     aa_window(ox, G, gw, xmin, xsize, cx, ix);
-    float wy[16], wx[16];
-    float sy = 0.f, sx = 0.f;
-    for (int j = 0; j < ysize && j < 16; ++j) { wy[j] = cubic_aa(((float)(j + ymin) - cy + 0.5f) * iy); sy += wy[j]; }
-    for (int j = 0; j < xsize && j < 16; ++j) { wx[j] = cubic_aa(((float)(j + xmin) - cx + 0.5f) * ix); sx += wx[j]; }
-    for (int j = 0; j < ysize && j < 16; ++j) wy[j] /= sy;
-    for (int j = 0; j < xsize && j < 16; ++j) wx[j] /= sx;
+    // window weights in LDS: 2 * support + 1 taps, support = 2 * G / g when shrinking (a 37-cell grid to one cell: 150 taps)
+    __shared__ float wy[AA_MAX_TAPS], wx[AA_MAX_TAPS];
+    if (threadIdx.x == 0) {
+        float sy = 0.f, sx = 0.f;
+        for (int j = 0; j < ysize; ++j) { wy[j] = cubic_aa(((float)(j + ymin) - cy + 0.5f) * iy); sy += wy[j]; }
+        for (int j = 0; j < xsize; ++j) { wx[j] = cubic_aa(((float)(j + xmin) - cx + 0.5f) * ix); sx += wx[j]; }
+        for (int j = 0; j < ysize; ++j) wy[j] /= sy;
+        for (int j = 0; j < xsize; ++j) wx[j] /= sx;
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         // horizontal pass first, then vertical (order of torch's separable CPU kernel)
         float acc = 0.f;
-        for (int jy = 0; jy < ysize && jy < 16; ++jy) {
+        for (int jy = 0; jy < ysize; ++jy) {
             float row = 0.f;
-            for (int jx = 0; jx < xsize && jx < 16; ++jx)
+            for (int jx = 0; jx < xsize; ++jx)
                 row += wx[jx] * bf2f(src[((size_t)(ymin + jy) * G + xmin + jx) * D + c]);
             acc += wy[jy] * row;
         }
@@ -454,7 +459,7 @@ int fp_layernorm(const bf16_t* X, bf16_t* Y, const bf16_t* gamma, const bf16_t* 
 
 int fp_posembed_aa(const bf16_t* src, bf16_t* dst, int G, int gh, int gw, int D, hipStream_t s) {
     FP_REQUIRE(G > 0 && gh > 0 && gw > 0, "posembed: bad grid");
-    FP_REQUIRE(4.0f * G / gh + 2 < 16 && 4.0f * G / gw + 2 < 16, "posembed: downscale factor too large");
+    FP_REQUIRE(4.0f * G / gh + 2 < AA_MAX_TAPS && 4.0f * G / gw + 2 < AA_MAX_TAPS, "posembed: downscale factor too large (grid %d -> %d x %d)", G, gh, gw);
     hipLaunchKernelGGL(posembed_aa_kernel, dim3(gh * gw), dim3(256), 0, s, src, dst, G, gh, gw, D);
     FP_LAUNCH_CHECK();
     return FP_OK;

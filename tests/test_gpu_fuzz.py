@@ -477,3 +477,35 @@ def test_fuzz_vt_store_layernorm_im2col(case):
     want = normed.unfold(2, ps, ps).unfold(3, ps, ps).permute(0, 2, 3, 1, 4, 5).reshape(Bi * gh * gw, K)
     assert torch.equal(got[:, :K], want), (Bi, gh, gw, ps)
     assert (got[:, K:] == 0).all()
+
+
+@pytest.mark.parametrize("case", range(max(1, ITERS // 3)))
+def test_fuzz_vit_against_the_fp32_oracle(case):
+    """fp_vit_forward vs oracle/vit_ref.py (torch fp32 on the host) at a random architecture, image size (any multiple of 14, not
+    necessarily square: the position embedding is interpolated per call), depth, batch and output kind; the tolerance of tests/test_gpu_vit.py
+    (per-token cosine >= 0.999, relative L2 <= 2e-2)"""
+    from freepose_amd import ops
+    from oracle import vit_ref
+    rng = _rng("vitref", case)
+    name = str(rng.choice(["dinov2_vits14_reg", "dinov2_vits14_reg", "dinov2_vitb14_reg", "dinov2_vitl14_reg"]))
+    big = "vitl" in name
+    gh, gw = int(rng.integers(1, 17 if big else 38)), int(rng.integers(1, 17 if big else 38))
+    if rng.integers(0, 3) == 0:
+        gw = gh
+    H, W = 14 * gh, 14 * gw
+    B = int(rng.integers(1, 4))
+    depth = {"dinov2_vits14_reg": 12, "dinov2_vitb14_reg": 12, "dinov2_vitl14_reg": 24}[name]
+    layer = int(rng.integers(1, min(depth, 8 if big else 12) + 1))
+    sd = ops.random_state_dict(name, seed=int(rng.integers(0, 1000)))
+    low = rng.random((B, 3, gh, gw)).astype(np.float32)
+    img = torch.nn.functional.interpolate(torch.from_numpy(low), size=(H, W), mode="bilinear")
+    img = (0.8 * img + 0.2 * torch.from_numpy(rng.random((B, 3, H, W)).astype(np.float32))).to(torch.bfloat16)
+    vit = ops.ViT(name, sd)
+    sdf = {k: v.float() for k, v in sd.items()}
+    for ft in ("patch", "cls", "reg"):
+        got = vit(img, layer=layer, feature_type=ft).float().cpu()
+        ref = vit_ref.vit_forward(sdf, img.float(), layer=layer, feature_type=ft, dtype=torch.float32).float()
+        assert got.shape == ref.shape, (name, H, W, layer, ft)
+        cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1).min().item()
+        rel = ((got - ref).norm() / ref.norm()).item()
+        assert cos >= 0.999 and rel <= 2e-2, (name, H, W, B, layer, ft, cos, rel)

@@ -15,6 +15,7 @@ Sections (reference function -> oracle / host restatement, criterion):
   csv       scripts/dino_inference.py:113-127, dino_inference_video.py:160-176 (exec'd) -> scripts.dino_inference.pose_row   the CSV text
   score     pose_estimator.py:85-88 (normalize, einsum, mean in bf16 torch)   -> fpo_template_score                       <= 1 bf16 ulp, same arg-max when decisive
   retrieval extract_proposals_ground.py:40-41,130-140 (torch expressions)     -> fpo_bank_prepare / scores / topk, fpo_ffa  >= 99.8 % of scores identical, same top-100 multiset
+  refiner   TrackingRefiner._crop_image / refiner_utils.update_K_with_crop / _get_threshold_for_confidence -> the mirror's host arithmetic   bit for bit
 Shims for packages the image lacks are gen_golden's (none of them is on the functions under test)."""
 from __future__ import annotations
 
@@ -37,6 +38,8 @@ def main():
     from freepose_amd.src.pipeline.utils import mask_to_rle_pytorch as my_to_rle, rle_to_mask as my_from_rle, z_from_extents
     from freepose_amd.src.utils.bbox_utils import unresizable_box
     from freepose_amd.scripts.dino_inference import CSV_COLUMNS, pose_row
+    from freepose_amd.src.pipeline import refiner_utils as my_ru
+    from freepose_amd.src.pipeline.estimators.tracking_refiner import TrackingRefiner as MyRefiner
     install_shims()
     from src.utils.bbox_utils import CropResizePad
     from src.pipeline.utils import Proposals, depthmap_to_pointcloud, get_z_from_pointcloud, mask_to_bbox
@@ -307,6 +310,61 @@ def main():
     assert same / total >= 0.998
     print(f"retrieval {n_set} banks: {same}/{total} bank scores bit-identical to torch's bf16 matmul (the rest: rows whose bf16 norm flips under torch's "
           f"reduction order), top-100 = the same score multiset, every member above the reference's 100th score   ({time.time() - t0:.0f} s)")
+    # ---- TrackingRefiner host arithmetic (crop boxes, RoIs, cropped intrinsics, confidence threshold) ---------------------------------
+    t0 = time.time()
+    tv = sys.modules["torchvision"]
+
+    class ToTensor:
+        def __call__(self, pic):
+            a = np.asarray(pic)
+            t = torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1)
+            return t.float().div(255) if t.dtype == torch.uint8 else t.float()
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+    tv.transforms.ToTensor, tv.transforms.Compose = ToTensor, Compose
+    recorded = {}
+
+    def roi_align(image, boxes, output_size, sampling_ratio=-1, **kw):           # torchvision's operator is not the reference's code: record its arguments
+        recorded["rois"] = boxes.clone()
+        return torch.zeros((boxes.shape[0], image.shape[1]) + tuple(output_size))
+    tv.ops = types.ModuleType("torchvision.ops")
+    tv.ops.roi_align = roi_align
+    sys.modules["torchvision.ops"] = tv.ops
+    sys.modules["open3d"] = types.ModuleType("open3d")
+    sys.modules["cv2"].INTER_CUBIC = 2
+    from src.pipeline import refiner_utils
+    from src.pipeline.estimators.tracking_refiner import TrackingRefiner
+    ref_obj, my_obj = TrackingRefiner.__new__(TrackingRefiner), MyRefiner.__new__(MyRefiner)
+    n_ref = max(1, n_cases // 10)
+    for case in range(n_ref):
+        rng = rng_of("refiner", case)
+        verts = (rng.standard_normal((int(rng.integers(100, 4000)), 3)) * rng.uniform(0.01, 0.3, 3)).astype(np.float64)
+        mesh = types.SimpleNamespace(vertices=verts)
+        K = np.array([[rng.uniform(400, 1400), 0, rng.uniform(200, 500)], [0, rng.uniform(400, 1400), rng.uniform(150, 400)], [0, 0, 1]])
+        T = np.eye(4)
+        T[:3, :3] = Rot.from_rotvec(rng.standard_normal(3) * 2).as_matrix()
+        T[:3, 3] = rng.uniform([-0.4, -0.3, 0.3], [0.4, 0.3, 3.0])
+        Hh, Ww = int(rng.integers(200, 800)), int(rng.integers(200, 1000))
+        image = torch.zeros((3, Hh, Ww))
+        crop, bbox, newK = ref_obj._crop_image(mesh, image, K, T)
+        pts = MyRefiner._sample_points(mesh)
+        Kt = torch.from_numpy(K).view(3, 3).float()
+        boxes = my_ru.crop_boxes(torch.from_numpy(T).view(1, 4, 4).float(), pts, Kt, 518, 518)
+        assert np.array_equal(boxes.numpy()[0], bbox.numpy()), f"refiner case {case}: crop box"
+        assert np.array_equal(torch.cat([torch.zeros((1, 1)), boxes], 1).numpy(), recorded["rois"].numpy()), f"refiner case {case}: RoI"
+        assert np.array_equal(my_ru.update_K_with_crop(Kt, boxes, 518, 518).numpy()[0], newK.numpy()), f"refiner case {case}: intrinsics"
+        sims = rng.random((int(rng.integers(1, 9)), 37, 37)).astype(np.float32) * (rng.random((1, 37, 37)) > rng.uniform(0, 0.9))
+        for qq in (0.2, 0.05, 0.5):
+            assert float(my_obj._get_threshold_for_confidence(sims, top_quantile=qq)) == float(ref_obj._get_threshold_for_confidence(sims, top_quantile=qq)), \
+                f"refiner case {case}: threshold {qq}"
+    print(f"refiner   {n_ref} cases: sampled points -> crop box, RoI, cropped intrinsics and confidence thresholds equal to the reference's, bit for bit   ({time.time() - t0:.0f} s)")
     print("all sections green")
 
 

@@ -13,6 +13,11 @@ d = json.loads(open("gpurun_out/r05/bench_line.json").read().strip().splitlines(
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"], d["stage_ms_rank0"])
 PY
 bash tools/profile_job.sh 2>&1 | tail -40
+# randomised parity at 100 cases per section on the same tree (tests/test_gpu_fuzz.py; the default suite above runs 6 per section)
+if [ "${FUZZ:-1}" = "1" ]; then
+  (FP_FUZZ_ITERS=100 timeout 1200 python -m pytest tests/test_gpu_fuzz.py -q 2>&1 | grep -v amdgpu.ids | tail -3) > gpurun_out/r05/fuzz_final.log
+  tail -1 gpurun_out/r05/fuzz_final.log
+fi
 # BASELINE config 4 at its own size (576 hypotheses, 518^2), oracle ViT in the reference's bf16 regime and in fp32: ~12 min of host CPU
 if [ "${FULL_PARITY:-0}" = "1" ]; then
   (FP_PARITY_FULL=1 FP_PARITY_FP32=1 timeout 1500 python -u -m pytest tests/test_gpu_pose_parity.py -x -q -s 2>&1 | grep -v amdgpu.ids) > gpurun_out/r05/pose_parity_full.log

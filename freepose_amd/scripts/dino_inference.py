@@ -77,6 +77,26 @@ def proposal_rows(model, templates, image, K, scene_id, frame_id, scene_props, s
     return rows
 
 
+def read_ahead(dataset, images, depth=2):
+    """dataset[idx] for idx in images, in order, with the next `depth` entries being read and decoded (PIL releases the GIL) on a
+    background thread while the caller works on the current one — a 640 x 480 BOP frame decodes in about the time the GPU needs for
+    its proposals"""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    images = list(images)
+    if depth <= 0 or len(images) < 2:
+        for idx in images:
+            yield dataset[idx]
+        return
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="fp-frames") as pool:
+        pending = deque(pool.submit(dataset.__getitem__, idx) for idx in images[:depth])
+        for nxt in images[depth:] + [None] * depth:
+            entry = pending.popleft().result()
+            if nxt is not None:
+                pending.append(pool.submit(dataset.__getitem__, nxt))
+            yield entry
+
+
 def process_images(model, templates, dataset, props, images, args):
     """the per-image loop of the driver (reference :69-127): pose rows of the given dataset entries"""
     rows = []
@@ -84,8 +104,7 @@ def process_images(model, templates, dataset, props, images, args):
     for p in props:
         by_image.setdefault((p["scene_id"], p["image_id"]), []).append(p)
     keys = [dataset.frame_key(idx) if hasattr(dataset, "frame_key") else None for idx in images]
-    for n, idx in enumerate(images):
-        entry = dataset[idx]
+    for n, entry in enumerate(read_ahead(dataset, images, getattr(args, "read_ahead", 2))):
         sid, fid = int(entry["scene_id"]), int(entry["frame_id"])
         sp = by_image.get((sid, fid), [])
         if not sp:

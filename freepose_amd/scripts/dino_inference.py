@@ -90,10 +90,10 @@ def read_ahead(dataset, images, depth=2):
         return
     with ThreadPoolExecutor(max_workers=1, thread_name_prefix="fp-frames") as pool:
         pending = deque(pool.submit(dataset.__getitem__, idx) for idx in images[:depth])
-        for nxt in images[depth:] + [None] * depth:
+        for n in range(len(images)):
             entry = pending.popleft().result()
-            if nxt is not None:
-                pending.append(pool.submit(dataset.__getitem__, nxt))
+            if n + depth < len(images):
+                pending.append(pool.submit(dataset.__getitem__, images[n + depth]))
             yield entry
 
 
@@ -143,6 +143,7 @@ def build_parser():
     ap.add_argument("--model", type=str, default="dinov2_vitl14_reg")        # not in the reference: backbone
     ap.add_argument("--allow_random_weights", action="store_true")           # not in the reference: run without the checkpoint
     ap.add_argument("--gpus", type=int, default=1)                           # not in the reference: self-launch N ranks, one per GPU
+    ap.add_argument("--read_ahead", type=int, default=2)                     # not in the reference: frames decoded ahead on a thread (0 = the sequential loop)
     return ap
 
 

@@ -33,7 +33,7 @@ from freepose_amd.src.pipeline.estimators.online_pose_estimator import DinoOnlin
 from freepose_amd.src.pipeline.estimators.pose_estimator import DinoPoseEstimator
 from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
 from freepose_amd.src.pipeline.utils import Proposals, rle_to_mask
-from freepose_amd.scripts.dino_inference import CSV_COLUMNS, pose_row
+from freepose_amd.scripts.dino_inference import CSV_COLUMNS, pose_row, read_ahead
 
 
 def guessed_intrinsics(h: int, w: int) -> np.ndarray:
@@ -50,12 +50,17 @@ def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, 
     if hasattr(templates, "prefetch_by_name"):       # the clip's meshes are known up front: read / decode them behind the first frame's work
         for o in list(obj_ids)[1:3]:
             templates.prefetch_by_name(mesh_ids[o])
-    for f in (range(len(frames)) if frame_ids is None else frame_ids):
-        sp = props[f]
-        img = np.asarray(Image.open(frames[f]).convert("RGB"), dtype=np.uint8)
-        masks = torch.from_numpy(np.stack([rle_to_mask(p["segmentation"]) for p in sp]))
-        boxes = torch.from_numpy(np.stack([np.array(p["bbox"]) for p in sp]))
-        boxes[:, 2:] += boxes[:, :2]
+    class _FrameInputs:          # host side of a frame (JPEG decode, RLE masks, boxes): nothing in it depends on the previous pose
+        def __getitem__(self, f):
+            sp = props[f]
+            img = np.asarray(Image.open(frames[f]).convert("RGB"), dtype=np.uint8)
+            masks = torch.from_numpy(np.stack([rle_to_mask(p["segmentation"]) for p in sp]))
+            boxes = torch.from_numpy(np.stack([np.array(p["bbox"]) for p in sp]))
+            boxes[:, 2:] += boxes[:, :2]
+            return f, img, masks, boxes
+    order = list(range(len(frames)) if frame_ids is None else frame_ids)
+    # the next two frames are decoded on a background thread while this frame's render-and-compare step runs (read_ahead)
+    for f, img, masks, boxes in read_ahead(_FrameInputs(), order, getattr(args, "read_ahead", 2)):
         proposals = Proposals(img, {"boxes": boxes, "masks": masks}, 420, bbox_extend=args.bbox_extend)
         outs = {}
         with torch.inference_mode():
@@ -178,6 +183,7 @@ def build_parser():
     ap.add_argument("--frame_chunks", action="store_true")
     ap.add_argument("--allow_random_weights", action="store_true")           # run without the DINOv2 checkpoint (tests, benches)
     ap.add_argument("--gpus", type=int, default=1)                           # self-launch N ranks, one per GPU (RCCL)
+    ap.add_argument("--read_ahead", type=int, default=2)                     # frames decoded ahead on a thread (0 = the sequential loop)
     return ap
 
 

@@ -78,6 +78,11 @@ def test_video_driver_one_rank_two_ranks_and_modes(workspace, monkeypatch):
     assert np.median(errs[:, 0]) < 25.0 and np.median(errs[:, 1]) < 0.15, errs
     text_1 = out.read_text()
 
+    # ---- the run above decoded the next two frames on a background thread; the sequential loop writes the same file -------------------
+    out.unlink()
+    div.run(argv + ["--read_ahead", "0"])
+    assert out.read_text() == text_1
+
     # ---- two ranks on the one GPU: objects are sharded, rows all-gathered -> byte-identical CSV -------------------------------
     out.unlink()
     _run_ranks("scripts.dino_inference_video", argv, root, 2, 29571)
@@ -127,6 +132,7 @@ def test_image_driver_and_bank_build(workspace, monkeypatch):
         # t is written in millimetres (dino_inference.py:124); z within 20 % of the drawn pose
         assert abs(t_mm[2] / 1000.0 - gts[fr, o][2, 3]) < 0.2 * gts[fr, o][2, 3]
     text_1 = out.read_text()
+    assert dino_inference.run(argv + ["--read_ahead", "0"]).read_text() == text_1        # frames read ahead on a thread or not: the same file
     # --depth_method depthmap (reference :82-85): the scale column is the depth-map estimate under each proposal mask — about the
     # objects' drawn scales (0.10 m ball, 0.08 m cube: half the largest extent of the eroded visible surface)
     out_d = dino_inference.run(argv + ["--depth_method", "depthmap"])

@@ -28,6 +28,7 @@ from PIL import Image
 
 from freepose_amd import ops, parallel
 from freepose_amd.retrieval import TemplateBank
+from freepose_amd.scripts.dino_inference import read_ahead
 from freepose_amd.src.dataloader.bop import BOPDataset
 from freepose_amd.src.pipeline.retrieval.dino import DINOv2FeatureExtractor
 from freepose_amd.src.pipeline.utils import Proposals, rle_to_mask
@@ -77,13 +78,11 @@ def run_images(args, extractor, bank, feature_type, layer):
     for d in dets:
         by_image.setdefault((int(d["scene_id"]), int(d["image_id"])), []).append(d)
     out = []
+    wanted = [idx for idx in range(len(dataset)) if by_image.get(dataset.frame_key(idx))]
     with torch.inference_mode():
-        for idx in range(len(dataset)):
+        for idx, entry in zip(wanted, read_ahead(dataset, wanted)):         # the next frames are decoded on a thread meanwhile
             key = dataset.frame_key(idx)
-            entries = by_image.get(key)
-            if not entries:
-                continue
-            entry = dataset[idx]
+            entries = by_image[key]
             proposals = Proposals(entry["image"], detections_of(entries), 420, key[0], key[1], bbox_extend=0.1, mask_rgb=True)   # :121
             proposals.meshes, proposals.scores = retrieve_image(bank, describe(extractor, proposals, feature_type, layer), args.topk)
             out.extend(proposals.to_bop_dict())
@@ -104,9 +103,11 @@ def run_video(args, extractor, bank, feature_type, layer):
     per_frame = [dets[i:i + n_obj] for i in range(0, len(dets), n_obj)]
     mine = parallel.shard_items(len(frames), rank, world)
     queries = []
+    class _Frames:
+        def __getitem__(self, f):
+            return np.asarray(Image.open(frames[f]).convert("RGB"), dtype=np.uint8)
     with torch.inference_mode():
-        for f in mine:
-            img = np.asarray(Image.open(frames[f]).convert("RGB"), dtype=np.uint8)
+        for f, img in zip(mine, read_ahead(_Frames(), mine)):
             proposals = Proposals(img, detections_of(per_frame[f]), 420, 0, f, bbox_extend=0.1, mask_rgb=False)                 # video :133
             queries.append(describe(extractor, proposals, feature_type, layer))
         # soft vote (:154-159,186-190): dense [N] vectors holding each frame's top-100 scores (or re-ranked means), mean over the

@@ -46,6 +46,19 @@ def main():
         templates = WebTemplateDataset(shards.as_posix(), "data/mesh_cache.csv", bbox_extend=0.05, n_views=T, cache_meshes=n_meshes)
         model = DinoPoseEstimator(n_poses=T, cache_size=n_meshes, cache_dir=root / "cache", feature_extractor=fe)
         rows = {}
+        if os.environ.get("COLD_PROFILE") == "1":          # the FIRST pass (every mesh new: decode + 600 ViT forwards + feature store fill) under the profiler
+            a = dino_inference.build_parser().parse_args(["--dataset", "synth", "--proposals", "props.json", "--n_views", str(T)])
+            pr = cProfile.Profile()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pr.enable()
+            dino_inference.process_images(model, templates, dataset, flat, list(range(min(len(dataset), max(2, n_meshes // 2)))), a)
+            torch.cuda.synchronize()
+            pr.disable()
+            print(f"cold pass: {n_meshes} new meshes in {(time.perf_counter() - t0) * 1e3:.0f} ms")
+            s = io.StringIO()
+            pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(40)
+            print("\n".join(l[:170] for l in s.getvalue().splitlines()[:70]))
         for ahead in (2, 0, 2, 0):
             a = dino_inference.build_parser().parse_args(["--dataset", "synth", "--proposals", "props.json", "--n_views", str(T)])
             a.read_ahead = ahead

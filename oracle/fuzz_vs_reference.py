@@ -16,9 +16,11 @@ Sections (reference function -> oracle / host restatement, criterion):
   score     pose_estimator.py:85-88 (normalize, einsum, mean in bf16 torch)   -> fpo_template_score                       <= 1 bf16 ulp, same arg-max when decisive
   retrieval extract_proposals_ground.py:40-41,130-140 (torch expressions)     -> fpo_bank_prepare / scores / topk, fpo_ffa  >= 99.8 % of scores identical, same top-100 multiset
   refiner   TrackingRefiner._crop_image / refiner_utils.update_K_with_crop / _get_threshold_for_confidence -> the mirror's host arithmetic   bit for bit
+  merge     scripts/merge_results.py (run as a script on a results tree)                                   -> scripts.merge_results                     same files, same rows
 Shims for packages the image lacks are gen_golden's (none of them is on the functions under test)."""
 from __future__ import annotations
 
+import os
 import sys
 import time
 from pathlib import Path
@@ -39,6 +41,7 @@ def main():
     from freepose_amd.src.utils.bbox_utils import unresizable_box
     from freepose_amd.scripts.dino_inference import CSV_COLUMNS, pose_row
     from freepose_amd.src.pipeline import refiner_utils as my_ru
+    from freepose_amd.scripts import merge_results as my_merge
     from freepose_amd.src.pipeline.estimators.tracking_refiner import TrackingRefiner as MyRefiner
     install_shims()
     from src.utils.bbox_utils import CropResizePad
@@ -365,6 +368,61 @@ def main():
             assert float(my_obj._get_threshold_for_confidence(sims, top_quantile=qq)) == float(ref_obj._get_threshold_for_confidence(sims, top_quantile=qq)), \
                 f"refiner case {case}: threshold {qq}"
     print(f"refiner   {n_ref} cases: sampled points -> crop box, RoI, cropped intrinsics and confidence thresholds equal to the reference's, bit for bit   ({time.time() - t0:.0f} s)")
+    # ---- merge_results: the reference's script run on a results tree, beside the mirror ------------------------------------------------
+    import runpy
+    import tempfile
+    t0 = time.time()
+    n_merge = max(1, n_cases // 100)
+    for case in range(n_merge):
+        rng = rng_of("merge", case)
+        with tempfile.TemporaryDirectory() as td:
+            td = Path(td)
+            ds, split = str(rng.choice(["ycbv", "tless", "lmo"])), "test"
+            for fi in range(int(rng.integers(1, 4))):
+                folder = td / "data" / "results" / ds / f"props-{fi}_{ds}-{split}_dinopose_layer_22_bbext_0.05"
+                folder.mkdir(parents=True)
+                for task in range(int(rng.integers(1, 6))):
+                    n_rows = int(rng.integers(0, 5))
+                    df = pd.DataFrame([{"scene_id": 1, "im_id": 100 * task + r, "obj_id": "m", "score": float(rng.random()), "R": "1 0 0 0 1 0 0 0 1",
+                                        "t": "0 0 1.5", "bbox_visib": "1 2 3 4", "scale": 0.1, "time": 0.2} for r in range(n_rows)], columns=CSV_COLUMNS)
+                    if n_rows and rng.integers(0, 4) == 0:
+                        df.loc[0, "t"] = None
+                    df.to_csv(folder / f"pose_outputs_{task}.csv", index=False)
+            (td / "data" / "results" / ds / "props.json").write_text("[]")
+            cwd, argv = os.getcwd(), sys.argv
+            out_ref, out_my = td / "ref", td / "mine"
+            out_ref.mkdir()
+            out_my.mkdir()
+            (out_ref / "data").symlink_to(td / "data")
+            (out_my / "data").symlink_to(td / "data")
+            try:
+                os.chdir(out_ref)
+                sys.argv = ["merge_results.py", "--dataset", ds]
+                try:
+                    runpy.run_path(str(REF / "scripts" / "merge_results.py"), run_name="__main__")
+                    ref_ok = True
+                except ValueError:                              # pd.concat of nothing: a folder without a single row
+                    ref_ok = False
+                os.chdir(out_my)
+                try:
+                    my_merge.main(["--dataset", ds])
+                    my_ok = True
+                except ValueError:
+                    my_ok = False
+            finally:
+                os.chdir(cwd)
+                sys.argv = argv
+            assert ref_ok == my_ok, f"merge case {case}: failure behaviour differs"
+            if ref_ok:
+                a = sorted(p.name for p in out_ref.glob("*.csv"))
+                b = sorted(p.name for p in out_my.glob("*.csv"))
+                assert a == b and a, f"merge case {case}: file names {a} vs {b}"
+                for name in a:
+                    ra = sorted((out_ref / name).read_text().splitlines()[1:])
+                    rb = sorted((out_my / name).read_text().splitlines()[1:])
+                    assert ra == rb and (out_ref / name).read_text().splitlines()[0] == (out_my / name).read_text().splitlines()[0], f"merge case {case}: rows of {name}"
+    print(f"merge     {n_merge} result trees: the reference's scripts/merge_results.py and the mirror write the same files with the same rows (the mirror in (task, rank) "
+          f"order, the reference in directory order)   ({time.time() - t0:.0f} s)")
     print("all sections green")
 
 

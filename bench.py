@@ -179,7 +179,7 @@ def video_workload(args, vit, rank, world):
     torch.nn.Module.__init__(fe)
     fe.model_name, fe.model, fe.num_register_tokens = "dinov2_vitl14_reg", vit, vit.n_reg
     est = DinoOnlinePoseEstimator(n_coarse_poses=600, n_fine_poses=20000, cache_size=4, cache_dir=f"/tmp/fp_bench_cache_r{rank}",
-                                  feature_extractor=fe)
+                                  feature_extractor=fe, hypothesis_cache=0)    # every hypothesis recomputed in every frame: the reference's step
     r600 = MeshRenderer(600)
     renders = r600.render(mesh, scale=0.25)
     crops, _, _ = MeshRenderer.generate_proposals(renders)
@@ -255,6 +255,13 @@ def video_workload(args, vit, rank, world):
     n_obj = max(1, args.video_objects)
     frames_multi = max(world, n_frames // n_obj)
     dtm, minem = run_clip(n_obj, frames_multi) if n_obj > 1 else (dt1, mine1)
+    # the same clips with the estimator's hypothesis store (its default in the video driver): only the fine-grid hypotheses that ENTER
+    # the 15-degree neighbourhood are rendered and sent through the ViT, the others are read from the per-mesh device store — same poses
+    # and scores bit for bit (tests/test_gpu_pipeline.py::test_hypothesis_store_gives_the_recomputed_results)
+    est.hypothesis_cache = 768
+    dt1c, mine1c = run_clip(1, n_frames)
+    dtmc, minemc = run_clip(n_obj, frames_multi) if n_obj > 1 else (dt1c, mine1c)
+    est.hypothesis_cache = 0
     strong = None
     if world > 1:                                                     # strong scaling with the chains intact: a fixed set of objects dealt to the ranks
         n_strong, frames_strong = 8, max(10, n_frames // 8)
@@ -270,6 +277,12 @@ def video_workload(args, vit, rank, world):
                              "ms_per_frame_object_per_gpu": dtm / max(minem, 1) / n_obj * 1e3,
                              "note": "the objects of a frame share one batched render-and-compare step (one ViT call, one host copy); "
                                      "per-object results equal the one-by-one run bit for bit (tests/test_gpu_cli_e2e.py)"},
+            "hypothesis_store": {"frames_per_s": n_frames / dt1c, "ms_per_frame_per_gpu": dt1c / max(mine1c, 1) * 1e3,
+                                 "multi_object_ms_per_frame_object_per_gpu": dtmc / max(minemc, 1) / n_obj * 1e3,
+                                 "object_rotation_deg_per_frame": 1.5,
+                                 "note": "the same clips with DinoOnlinePoseEstimator(hypothesis_cache=768), the video driver's default: hypotheses already "
+                                         "seen for the mesh are read from the device store instead of being re-rendered and re-encoded; identical "
+                                         "results.  `value` / `ms_per_frame_per_gpu` above are WITHOUT it (every hypothesis recomputed per frame)"},
             "object_sharded": strong,
             "sharding": "sequential clip on one rank (reference semantics)" if world == 1 else
                         f"{world} contiguous frame chunks, coarse re-initialisation per chunk (SURVEY 8e option 4: DEVIATES from the reference "

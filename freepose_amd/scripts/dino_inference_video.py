@@ -111,7 +111,8 @@ def main(args):
                                   cache_dir=cache_dir, feature_extractor=extractor)
     else:
         model = DinoOnlinePoseEstimator(n_coarse_poses=args.n_views, n_fine_poses=args.n_fine_poses, cache_size=args.cache_size,
-                                        save_all=args.save_all_cache, cache_dir=cache_dir, feature_extractor=extractor)
+                                        save_all=args.save_all_cache, cache_dir=cache_dir, feature_extractor=extractor,
+                                        hypothesis_cache=args.hypothesis_cache)
 
     props = json.loads((results_dir / args.proposals).read_text())
     n_objects = len(list(takewhile(lambda x: x["image_id"] == 0, props)))
@@ -184,6 +185,7 @@ def build_parser():
     ap.add_argument("--allow_random_weights", action="store_true")           # run without the DINOv2 checkpoint (tests, benches)
     ap.add_argument("--gpus", type=int, default=1)                           # self-launch N ranks, one per GPU (RCCL)
     ap.add_argument("--read_ahead", type=int, default=2)                     # frames decoded ahead on a thread (0 = the sequential loop)
+    ap.add_argument("--hypothesis_cache", type=int, default=768)             # fine-grid hypotheses kept per mesh between frames (0 = recompute all, same CSV)
     return ap
 
 

@@ -8,6 +8,8 @@ the host.  One ViT instance is shared with the coarse estimator (the reference l
 """
 from __future__ import annotations
 
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
@@ -17,10 +19,63 @@ from freepose_amd.src.pipeline.retrieval.renderer import MeshRenderer
 from freepose_amd.src.pipeline.utils import z_from_extents
 
 
+class _HypothesisStore:
+    """What the render-and-compare step computed for fine-grid hypotheses of ONE mesh (at one ViT layer): patch features, cloud extents
+    and — when the scores are mask-weighted — the render masks, device-resident, addressed by fine-grid index.  A grid pose is the same
+    render, the same crop and (a crop's features do not depend on its batch: tests/test_gpu_fuzz.py) the same feature bits in every
+    frame, and consecutive frames share most of their 15-degree neighbourhood, so only the hypotheses that ENTER the neighbourhood are
+    rendered and sent through the ViT.  The reference recomputes all of them per frame (online_pose_estimator.py:55-79); the results
+    are identical.  When `cap` would be exceeded the store is emptied (the next step refills it with its own neighbourhood)."""
+
+    def __init__(self, mesh, cap, need_masks):
+        self.mesh, self.cap, self.need_masks = mesh, int(cap), bool(need_masks)    # (the mesh reference keeps id(mesh) unique)
+        self.slot = {}
+        self.feats = self.ext = self.masks = None
+
+    def make_room(self, grid_ids) -> bool:
+        """called once per step with ALL grid ids the step needs from this store: empties the store when they would not fit beside what
+        it holds; False = they do not fit at all (the step then recomputes them without the store)"""
+        need = {int(g) for g in grid_ids}
+        if len(need) > self.cap:
+            return False
+        if len(need | set(self.slot)) > self.cap:
+            self.slot.clear()
+        return True
+
+    def reserve(self, grid_ids):
+        """slots for grid ids not held yet -> (ids, slots)"""
+        new = [int(g) for g in grid_ids if int(g) not in self.slot]
+        base = len(self.slot)
+        for k, g in enumerate(new):
+            self.slot[g] = base + k
+        return new, list(range(base, base + len(new)))
+
+    def write(self, slots, feats, ext, masks):
+        if self.feats is None:
+            self.feats = torch.empty((self.cap,) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
+            self.ext = torch.empty((self.cap,) + tuple(ext.shape[1:]), dtype=ext.dtype, device=ext.device)
+            if self.need_masks:
+                self.masks = torch.empty((self.cap,) + tuple(masks.shape[1:]), dtype=masks.dtype, device=masks.device)
+        idx = torch.as_tensor(slots, dtype=torch.long, device=feats.device)
+        self.feats.index_copy_(0, idx, feats)
+        self.ext.index_copy_(0, idx, ext)
+        if self.need_masks:
+            self.masks.index_copy_(0, idx, masks)
+
+    def gather(self, grid_ids):
+        idx = torch.as_tensor([self.slot[int(g)] for g in grid_ids], dtype=torch.long, device=self.feats.device)
+        return self.feats.index_select(0, idx), self.ext.index_select(0, idx), (self.masks.index_select(0, idx) if self.need_masks else None)
+
+
 class DinoOnlinePoseEstimator(torch.nn.Module):
     def __init__(self, n_coarse_poses=600, n_fine_poses=10000, cache_size=50, save_all=False, cache_dir="./data/cache",
-                 feature_extractor=None):
+                 feature_extractor=None, hypothesis_cache=768, hypothesis_meshes=8):
+        """`hypothesis_cache`: fine-grid hypotheses kept per mesh between frames (_HypothesisStore; 0 = recompute every hypothesis in
+        every frame like the reference — same results); `hypothesis_meshes`: meshes that keep such a store (least recently used out).
+        768 hypotheses of a ViT-L @420^2 are 1.4 GB."""
         super().__init__()
+        self.hypothesis_cache, self.hypothesis_meshes = int(hypothesis_cache), int(hypothesis_meshes)
+        self._hyp_stores = OrderedDict()             # (id(mesh), layer, masks?) -> _HypothesisStore
         self.coarse_estimator = DinoPoseEstimator(n_coarse_poses, cache_size, save_all, cache_dir, feature_extractor)
         self.feature_extractor = self.coarse_estimator.feature_extractor
         self.fine_mesh_poses = np.array(self.coarse_estimator.generate_poses(n_fine_poses))
@@ -50,6 +105,16 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
         return self.forward_fine(proposal, proposal_mask, template_dict, mesh, K, bbox, est_scale, prev_pose, neighborhood,
                                  layer, mask_scores, query_feat)
 
+    def _hypothesis_store(self, mesh, layer, need_masks):
+        key = (id(mesh), int(layer), bool(need_masks))
+        st = self._hyp_stores.get(key)
+        if st is None:
+            st = self._hyp_stores[key] = _HypothesisStore(mesh, self.hypothesis_cache, need_masks)
+            while len(self._hyp_stores) > max(1, self.hypothesis_meshes):
+                self._hyp_stores.popitem(last=False)
+        self._hyp_stores.move_to_end(key)
+        return st
+
     def forward_fine(self, proposal, proposal_mask, template_dict, mesh, K, bbox, est_scale, prev_pose, neighborhood=15,
                      layer=22, mask_scores=False, query_feat=None):
         item = dict(proposal=proposal, proposal_mask=proposal_mask, template_dict=template_dict, mesh=mesh, K=K, bbox=bbox,
@@ -68,51 +133,73 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
         if len(items) == 0:
             return []
         work, pieces = [], []
+        neighbourhoods, wanted = [], {}
         for it in items:
             close = ops.geodesic_select(self._fine_rots_dev, np.asarray(it["prev_pose"])[:3, :3], float(neighborhood))
             if len(close) == 0:
                 raise RuntimeError("no fine-grid rotation within the neighbourhood of the previous pose")
-            selected = self.fine_mesh_poses[close]
-            renders = self.renderer.render_from_poses(it["mesh"], selected, scale=self.rendering_scale)
-            crops, poses, masks, ext = MeshRenderer.generate_proposals(renders, out_bf16=True, return_extents=True,
-                                                                       need_masks=mask_scores)
+            neighbourhoods.append(close)
+            if self.hypothesis_cache > 0:
+                st = self._hypothesis_store(it["mesh"], layer, mask_scores)
+                wanted.setdefault(id(st), (st, []))[1].extend(int(g) for g in close)
+        usable = {k: st.make_room(ids) for k, (st, ids) in wanted.items()}       # (objects that share a mesh share its store)
+        for it, close in zip(items, neighbourhoods):
+            store = self._hypothesis_store(it["mesh"], layer, mask_scores) if self.hypothesis_cache > 0 else None
+            if store is not None and not usable[id(store)]:
+                store = None
+            todo, slots = store.reserve(close) if store is not None else ([int(g) for g in close], None)
+            crops = masks = ext = None
+            if todo:                                   # hypotheses not seen for this mesh yet (all of them without a store)
+                renders = self.renderer.render_from_poses(it["mesh"], self.fine_mesh_poses[todo], scale=self.rendering_scale)
+                crops, _, masks, ext = MeshRenderer.generate_proposals(renders, out_bf16=True, return_extents=True, need_masks=mask_scores)
             proposal, query_feat = it["proposal"], it.get("query_feat")
             # the query crop rides in the same ViT batch as the hypothesis crops: a separate B = 1 forward is launch-bound
             # (~2.5 ms of a ~19 ms step)
-            rides = query_feat is None and tuple(proposal.shape[-2:]) == tuple(crops.shape[-2:])
+            rides = query_feat is None and tuple(proposal.shape[-2:]) == (420, 420)
             if rides:
-                pieces.append(torch.as_tensor(proposal)[None].to(crops.device, crops.dtype))
+                pieces.append(torch.as_tensor(proposal)[None].to("cuda", torch.bfloat16))
             elif query_feat is None:
                 query_feat = ops.l2_normalize(self.feature_extractor(proposal[None], layer=layer, feature_type="patch"))
-            pieces.append(crops)
-            work.append(dict(n=len(close), poses=poses, masks=masks, ext=ext, rides=rides, query_feat=query_feat))
+            if todo:
+                pieces.append(crops)
+            work.append(dict(close=close, n_new=len(todo), slots=slots, store=store, masks=masks, ext=ext, rides=rides, query_feat=query_feat))
         feats_all = self.feature_extractor(pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=0), layer=layer,
-                                           feature_type="patch")
-        at, packed = 0, []
-        for it, w in zip(items, work):
+                                           feature_type="patch") if pieces else None
+        at = 0
+        for w in work:                                 # first every store receives its new hypotheses (two objects may share a mesh) ...
             if w["rides"]:
                 w["query_feat"] = ops.l2_normalize(feats_all[at:at + 1])
                 at += 1
-            feats = feats_all[at:at + w["n"]]
-            at += w["n"]
+            w["feats"] = feats_all[at:at + w["n_new"]] if w["n_new"] else None
+            at += w["n_new"]
+            if w["store"] is not None and w["n_new"]:
+                w["store"].write(w["slots"], w["feats"], w["ext"], w["masks"])
+        packed = []
+        for it, w in zip(items, work):                 # ... then every object is scored against its own neighbourhood, in grid order
+            n = len(w["close"])
+            if w["store"] is not None:
+                feats, ext, masks = w["store"].gather(w["close"])
+            else:
+                feats, ext, masks = w["feats"], w["ext"], w["masks"]
+            w["ext"] = ext
             q = w["query_feat"].reshape(-1, w["query_feat"].shape[-1])
             weights = None
             if mask_scores:
-                m = torch.logical_or(w["masks"], torch.as_tensor(it["proposal_mask"]).to(w["masks"].device)[None]).float()
+                m = torch.logical_or(masks, torch.as_tensor(it["proposal_mask"]).to(masks.device)[None]).float()
                 g = int(round(feats.shape[1] ** 0.5))
-                weights = torch.nn.functional.interpolate(m[None], size=(g, g), mode="bilinear")[0].reshape(w["n"], -1)
+                weights = torch.nn.functional.interpolate(m[None], size=(g, g), mode="bilinear")[0].reshape(n, -1)
             scores = ops.template_score(feats, q, weights)
             # max / argmax (first maximum): canonical (score desc, index asc)
-            idx_all = torch.arange(w["n"], dtype=torch.int32, device=scores.device)
+            idx_all = torch.arange(n, dtype=torch.int32, device=scores.device)
             top_s, top_i = ops.topk_merge(scores[None], idx_all[None], 1)
             # winner index, its score and its two cloud extents (the score is a bf16 value held in fp32, the index is small: both
             # are exact in float64)
-            packed.append(torch.cat([top_i[0, :1].double(), top_s[0, :1].double(), w["ext"][top_i[0, 0].long(), 4:6].double()]))
+            packed.append(torch.cat([top_i[0, :1].double(), top_s[0, :1].double(), ext[top_i[0, 0].long(), 4:6].double()]))
         packed = torch.stack(packed).cpu().numpy()          # ONE device -> host copy for all objects of the frame
         outs = []
         for it, w, pk in zip(items, work, packed):
             top = int(pk[0])
             ratio = float(it["est_scale"]) / 0.25
-            TCO = z_from_extents(it["bbox"], pk[2] * ratio, pk[3] * ratio, it["K"], w["poses"][top])
+            TCO = z_from_extents(it["bbox"], pk[2] * ratio, pk[3] * ratio, it["K"], self.fine_mesh_poses[int(w["close"][top])])
             outs.append({"TCO": [TCO], "scores": [np.float32(pk[1])], "proposal": it["proposal"], "K": it["K"], "bbox": it["bbox"]})
         return outs

@@ -82,6 +82,10 @@ def test_video_driver_one_rank_two_ranks_and_modes(workspace, monkeypatch):
     out.unlink()
     div.run(argv + ["--read_ahead", "0"])
     assert out.read_text() == text_1
+    # ... and kept the fine-grid hypotheses of each mesh between frames; recomputing all of them in every frame (the reference) too
+    out.unlink()
+    div.run(argv + ["--hypothesis_cache", "0"])
+    assert out.read_text() == text_1
 
     # ---- two ranks on the one GPU: objects are sharded, rows all-gathered -> byte-identical CSV -------------------------------
     out.unlink()

@@ -186,6 +186,74 @@ def test_online_estimator_recovers_planted_pose(tmp_path):
     assert np.allclose(many[1]["TCO"][0][:3, :3], est.fine_mesh_poses[1234][:3, :3])
 
 
+def test_hypothesis_store_gives_the_recomputed_results(tmp_path):
+    """DinoOnlinePoseEstimator keeps the features / extents / masks of fine-grid hypotheses per mesh between frames and only renders
+    those that ENTER the neighbourhood; the reference recomputes every hypothesis in every frame.  Over a clip — two objects that share
+    a mesh plus one with its own, plain and mask-weighted scores, a store so small that it overflows and is emptied, and no store at
+    all — every pose and every score must be identical, and the store must really save ViT work."""
+    import warnings
+    from src.pipeline.estimators.online_pose_estimator import DinoOnlinePoseEstimator
+    from src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+    from src.pipeline.retrieval.renderer import MeshRenderer
+    from scipy.spatial.transform import Rotation as Rot
+    from tests._meshes import textured_cube
+    from freepose_amd.mesh_io import TriMesh
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fe = DINOv2FeatureExtractor("dinov2_vits14_reg", seed=4)
+    mesh = _mesh()
+    v2, f2, _ = textured_cube()
+    mesh2 = TriMesh(v2 * np.array([1.0, 0.6, 0.4], np.float32), f2, np.random.default_rng(3).integers(0, 255, size=(len(v2), 3), dtype=np.uint8))
+    K = np.array([[600.0, 0, 210], [0, 600.0, 210], [0, 0, 1]])
+    n_frames = 14
+    calls = {}
+
+    def run(cap, mask_scores):
+        est = DinoOnlinePoseEstimator(n_coarse_poses=8, n_fine_poses=20000, cache_size=0, cache_dir=tmp_path / f"c{cap}", feature_extractor=fe,
+                                      hypothesis_cache=cap)
+        crops_seen = [0]
+        inner = est.feature_extractor
+
+        class Counting(torch.nn.Module):
+            def forward(self, x, **kw):
+                crops_seen[0] += x.shape[0]
+                return inner(x, **kw)
+        est.feature_extractor = Counting()
+        starts = [(mesh, 7777, np.array([0.3, 1.0, 0.2])), (mesh2, 1234, np.array([1.0, -0.2, 0.4])), (mesh, 7790, np.array([-0.5, 0.3, 1.0]))]
+        prev = [est.fine_mesh_poses[j] for _, j, _ in starts]
+        out_all = []
+        for fr in range(n_frames):
+            items = []
+            for o, (msh, j, ax) in enumerate(starts):
+                tp = np.eye(4)
+                tp[:3, :3] = Rot.from_rotvec(np.deg2rad(2.5 * fr) * ax / np.linalg.norm(ax)).as_matrix() @ est.fine_mesh_poses[j][:3, :3]
+                tp[:3, 3] = est.fine_mesh_poses[j][:3, 3]
+                rj = est.renderer.render_from_poses(msh, [tp], scale=0.25)
+                cj, _, mj, ej = MeshRenderer.generate_proposals(rj, return_extents=True)
+                ee = ej[0].cpu().numpy()
+                items.append(dict(proposal=cj[0].float(), proposal_mask=mj[0], template_dict=None, mesh=msh, K=K,
+                                  bbox=torch.tensor([int(ee[0]), int(ee[1]), int(ee[2]), int(ee[3])]), est_scale=0.25, prev_pose=prev[o]))
+            outs = est.forward_fine_many(items, mask_scores=mask_scores)
+            prev = [o_["TCO"][0] for o_ in outs]
+            out_all.append([(o_["TCO"][0].copy(), float(o_["scores"][0])) for o_ in outs])
+        calls[(cap, mask_scores)] = crops_seen[0]
+        return out_all
+
+    for mask_scores in (False, True):
+        ref = run(0, mask_scores)                       # every hypothesis recomputed in every frame (the reference's behaviour)
+        for cap in (768, 60):                           # a roomy store; one that overflows (three neighbourhoods of ~20 barely fit) and is emptied
+            got = run(cap, mask_scores)
+            for fr in range(n_frames):
+                for (Ta, sa), (Tb, sb) in zip(ref[fr], got[fr]):
+                    assert np.array_equal(Ta, Tb) and sa == sb, (mask_scores, cap, fr)
+    # the object moves 2.5 degrees per frame through a ~9-degree grid: most neighbours repeat from frame to frame
+    assert calls[(768, False)] < 0.45 * calls[(0, False)], calls
+    assert calls[(60, False)] <= calls[(0, False)]
+    # the poses follow the planted rotation (sanity of the scenario itself)
+    last = ref[-1][0][0]
+    assert np.isfinite(last).all() and abs(np.linalg.det(last[:3, :3]) - 1) < 1e-6
+
+
 def _png(arr, mode):
     from PIL import Image
     b = io.BytesIO()

@@ -21,7 +21,11 @@ from freepose_amd.src.pipeline.retrieval.renderer import MeshRenderer  # noqa: E
 def main():
     fe = DINOv2FeatureExtractor("dinov2_vitl14_reg", seed=0)
     with tempfile.TemporaryDirectory() as td:
-        est = DinoOnlinePoseEstimator(n_coarse_poses=8, n_fine_poses=20000, cache_size=0, cache_dir=Path(td) / "c", feature_extractor=fe)
+        import os
+        # VIDEO_STORE=0: every hypothesis recomputed per frame (the reference's step); default: the estimator's hypothesis store — with this
+        # tool's STATIC query the pose settles and every later frame finds its whole neighbourhood in the store (the store's best case)
+        est = DinoOnlinePoseEstimator(n_coarse_poses=8, n_fine_poses=20000, cache_size=0, cache_dir=Path(td) / "c", feature_extractor=fe,
+                                      hypothesis_cache=int(os.environ.get("VIDEO_STORE", "768")))
         v, f, c = bench.synthetic_mesh(6)
         mesh = TriMesh(v, f, c)
         K = np.array([[600.0, 0, 210], [0, 600.0, 210], [0, 0, 1]])

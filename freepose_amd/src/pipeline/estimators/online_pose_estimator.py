@@ -106,7 +106,7 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
                                  layer, mask_scores, query_feat)
 
     def _hypothesis_store(self, mesh, layer, need_masks):
-        key = (id(mesh), int(layer), bool(need_masks))
+        key = (id(mesh), int(layer), bool(need_masks), float(self.rendering_scale))
         st = self._hyp_stores.get(key)
         if st is None:
             st = self._hyp_stores[key] = _HypothesisStore(mesh, self.hypothesis_cache, need_masks)

@@ -3,7 +3,8 @@ the C oracle bit for bit (integer / byte / index work and the bf16-rounded score
 epilogues, attention), and the library's own contract where one exists (a row's bits do not depend on the rows around it).
 
 Every case comes from one seeded generator, so a failure names a (section, case) that reproduces.  `FP_FUZZ_ITERS` = cases per section
-(default 6: the suite stays short); the round's long run (`FP_FUZZ_ITERS=150`, profiles/r05_fuzz.log) is the evidence."""
+(default 6: the suite stays short); the round's long runs (`FP_FUZZ_ITERS=100 ... 300`, three seeds: profiles/r05_fuzz.log) are the
+evidence."""
 import os
 
 import numpy as np

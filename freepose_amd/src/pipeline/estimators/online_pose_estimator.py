@@ -76,6 +76,7 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
         super().__init__()
         self.hypothesis_cache, self.hypothesis_meshes = int(hypothesis_cache), int(hypothesis_meshes)
         self._hyp_stores = OrderedDict()             # (id(mesh), layer, masks?) -> _HypothesisStore
+        self._nb_cache, self._grid_keys = {}, None   # neighbourhood of a fine-grid rotation by its bytes (_neighbourhood)
         self.coarse_estimator = DinoPoseEstimator(n_coarse_poses, cache_size, save_all, cache_dir, feature_extractor)
         self.feature_extractor = self.coarse_estimator.feature_extractor
         self.fine_mesh_poses = np.array(self.coarse_estimator.generate_poses(n_fine_poses))
@@ -104,6 +105,24 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
             query_feat = None
         return self.forward_fine(proposal, proposal_mask, template_dict, mesh, K, bbox, est_scale, prev_pose, neighborhood,
                                  layer, mask_scores, query_feat)
+
+    def _neighbourhood(self, R_prev, thresh_deg):
+        """fp_geodesic_select of the previous pose.  From the second tracked frame on the previous pose IS a fine-grid rotation (the winner
+        of the last step, copied into TCO), so its neighbourhood is a function of that grid index: looked up by the rotation's bytes, computed
+        once per (grid rotation, threshold) — a kernel, a compaction and two device -> host copies less per frame and object."""
+        R = np.ascontiguousarray(R_prev, dtype=np.float64)
+        key = (R.tobytes(), thresh_deg)
+        hit = self._nb_cache.get(key)
+        if hit is not None:
+            return hit
+        close = ops.geodesic_select(self._fine_rots_dev, R, thresh_deg)
+        if self._grid_keys is None:
+            self._grid_keys = {np.ascontiguousarray(P[:3, :3], dtype=np.float64).tobytes() for P in self.fine_mesh_poses}
+        if key[0] in self._grid_keys:                 # (arbitrary rotations — the coarse estimate of frame 0 — are not worth remembering)
+            if len(self._nb_cache) >= 65536:
+                self._nb_cache.clear()
+            self._nb_cache[key] = close
+        return close
 
     def _hypothesis_store(self, mesh, layer, need_masks):
         key = (id(mesh), int(layer), bool(need_masks), float(self.rendering_scale))
@@ -135,7 +154,7 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
         work, pieces = [], []
         neighbourhoods, wanted = [], {}
         for it in items:
-            close = ops.geodesic_select(self._fine_rots_dev, np.asarray(it["prev_pose"])[:3, :3], float(neighborhood))
+            close = self._neighbourhood(np.asarray(it["prev_pose"])[:3, :3], float(neighborhood))
             if len(close) == 0:
                 raise RuntimeError("no fine-grid rotation within the neighbourhood of the previous pose")
             neighbourhoods.append(close)

@@ -193,7 +193,7 @@ def video_workload(args, vit, rank, world):
     dm = ops.Mesh(mv, mf, mc)
     est.coarse_estimator._get_template_features(template)            # template features resident (the drivers' cache hit path)
 
-    def run_clip(n_obj, frames_total, shard="frames"):
+    def run_clip(n_obj, frames_total, shard="frames", window=1):
         """`frames_total` frames with `n_obj` tracked objects each; the objects of a frame go through ONE batched step
         (DinoOnlinePoseEstimator.forward_fine_many, what scripts.dino_inference_video does).  shard = "frames": contiguous frame chunks
         per rank (deviating: coarse re-initialisation per chunk); "objects": every rank walks ALL frames with its own objects
@@ -229,15 +229,24 @@ def video_workload(args, vit, rank, world):
             dist.barrier()
         t0 = time.perf_counter()
         prev, errs = [None] * len(my_objs), []
-        for fp, fg in zip(props, gt):
+        qn = {}
+        for fi, (fp, fg) in enumerate(zip(props, gt)):
             if not fp:
                 continue             # (more ranks than objects: this rank only joins the barriers)
+            if window > 1 and fi % window == 0:
+                # the query crops of the next `window` frames in ONE ViT call (scripts.dino_inference_video --query_window): a query depends on
+                # its frame only; the stretch's first frame goes through the coarse estimator, which encodes its own
+                todo = [(g, o) for g in range(fi, min(fi + window, len(props))) for o in range(len(props[g])) if g > 0]
+                if todo:
+                    crops = torch.stack([torch.as_tensor(props[g][o][0]) for g, o in todo]).to("cuda", torch.bfloat16)
+                    feats = ops.l2_normalize(est.feature_extractor(crops, layer=22, feature_type="patch"))
+                    qn = {go: feats[i:i + 1] for i, go in enumerate(todo)}
             if prev[0] is None:      # head of the stretch: coarse estimate + fine step per object
                 outs = [est(c, cm, template, meshes[my_objs[o]], K, b, scale, prev_pose=None, neighborhood=15, layer=22, batch_size=128)
                         for o, (c, cm, b) in enumerate(fp)]
             else:
                 outs = est.forward_fine_many([dict(proposal=c, proposal_mask=cm, template_dict=template, mesh=meshes[my_objs[o]], K=K, bbox=b,
-                                                   est_scale=scale, prev_pose=prev[o]) for o, (c, cm, b) in enumerate(fp)],
+                                                   est_scale=scale, prev_pose=prev[o], query_feat=qn.get((fi, o))) for o, (c, cm, b) in enumerate(fp)],
                                              neighborhood=15, layer=22)
             for o, out in enumerate(outs):
                 prev[o] = out["TCO"][0]
@@ -261,6 +270,8 @@ def video_workload(args, vit, rank, world):
     est.hypothesis_cache = 768
     dt1c, mine1c = run_clip(1, n_frames)
     dtmc, minemc = run_clip(n_obj, frames_multi) if n_obj > 1 else (dt1c, mine1c)
+    dt1w, mine1w = run_clip(1, n_frames, window=8)                   # + the query crops of 8 frames in one ViT call (the driver's --query_window 8)
+    dtmw, minemw = run_clip(n_obj, frames_multi, window=8) if n_obj > 1 else (dt1w, mine1w)
     est.hypothesis_cache = 0
     strong = None
     if world > 1:                                                     # strong scaling with the chains intact: a fixed set of objects dealt to the ranks
@@ -280,6 +291,10 @@ def video_workload(args, vit, rank, world):
             "hypothesis_store": {"frames_per_s": n_frames / dt1c, "ms_per_frame_per_gpu": dt1c / max(mine1c, 1) * 1e3,
                                  "multi_object_ms_per_frame_object_per_gpu": dtmc / max(minemc, 1) / n_obj * 1e3,
                                  "object_rotation_deg_per_frame": 1.5,
+                                 "with_query_window_8": {"frames_per_s": n_frames / dt1w, "ms_per_frame_per_gpu": dt1w / max(mine1w, 1) * 1e3,
+                                                         "multi_object_ms_per_frame_object_per_gpu": dtmw / max(minemw, 1) / n_obj * 1e3,
+                                                         "note": "the driver's default: the query crops of 8 consecutive frames share one ViT call (a query "
+                                                                 "crop depends on its frame only); same poses and scores"},
                                  "note": "the same clips with DinoOnlinePoseEstimator(hypothesis_cache=768), the video driver's default: hypotheses already "
                                          "seen for the mesh are read from the device store instead of being re-rendered and re-encoded; identical "
                                          "results.  `value` / `ms_per_frame_per_gpu` above are WITHOUT it (every hypothesis recomputed per frame)"},

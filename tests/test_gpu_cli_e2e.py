@@ -86,6 +86,13 @@ def test_video_driver_one_rank_two_ranks_and_modes(workspace, monkeypatch):
     out.unlink()
     div.run(argv + ["--hypothesis_cache", "0"])
     assert out.read_text() == text_1
+    # ... and encoded the query crops of 8 frames per ViT call; one call per frame (and everything off at once) writes the same file
+    out.unlink()
+    div.run(argv + ["--query_window", "1"])
+    assert out.read_text() == text_1
+    out.unlink()
+    div.run(argv + ["--query_window", "3", "--read_ahead", "0", "--hypothesis_cache", "0"])
+    assert out.read_text() == text_1
 
     # ---- two ranks on the one GPU: objects are sharded, rows all-gathered -> byte-identical CSV -------------------------------
     out.unlink()

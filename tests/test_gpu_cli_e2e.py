@@ -144,6 +144,9 @@ def test_image_driver_and_bank_build(workspace, monkeypatch):
         assert abs(t_mm[2] / 1000.0 - gts[fr, o][2, 3]) < 0.2 * gts[fr, o][2, 3]
     text_1 = out.read_text()
     assert dino_inference.run(argv + ["--read_ahead", "0"]).read_text() == text_1        # frames read ahead on a thread or not: the same file
+    # the run above sent the proposals of up to eight images through one ViT call and one estimator step; per image / odd windows too
+    assert dino_inference.run(argv + ["--image_window", "1"]).read_text() == text_1
+    assert dino_inference.run(argv + ["--image_window", "3", "--read_ahead", "0"]).read_text() == text_1
     # --depth_method depthmap (reference :82-85): the scale column is the depth-map estimate under each proposal mask — about the
     # objects' drawn scales (0.10 m ball, 0.08 m cube: half the largest extent of the eroded visible surface)
     out_d = dino_inference.run(argv + ["--depth_method", "depthmap"])

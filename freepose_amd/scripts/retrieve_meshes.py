@@ -42,14 +42,26 @@ def detections_of(entries):
     return {"boxes": boxes, "masks": masks}
 
 
-def describe(extractor, proposals: Proposals, feature_type: str, layer: int) -> torch.Tensor:
+def describe(extractor, proposals, feature_type: str, layer: int):
     """bf16 [n, D] L2-normalised descriptors of the proposals (ground.py:123-134): cls token, or FFA = mean of the patch features under
-    the crop's mask any-pooled to the 30 x 30 patch grid (cv2 INTER_AREA > 0, :127)"""
-    crops = proposals.proposals
+    the crop's mask any-pooled to the 30 x 30 patch grid (cv2 INTER_AREA > 0, :127).  `proposals`: one Proposals object or a list of
+    them (several images / frames: ONE ViT call for all their crops — a crop's descriptor does not depend on the crops beside it —
+    and a list of descriptor tensors back, one per object)"""
+    many = isinstance(proposals, (list, tuple))
+    group = list(proposals) if many else [proposals]
+    crops = torch.cat([torch.as_tensor(p.proposals) for p in group], dim=0)
     if feature_type == "cls":
-        return ops.l2_normalize(extractor(crops, layer=layer, feature_type="cls"))
-    feats = extractor(crops, layer=layer, feature_type="patch")
-    return ops.ffa(feats, proposals.proposals_masks, cell=14, normalize=True)
+        out = ops.l2_normalize(extractor(crops, layer=layer, feature_type="cls"))
+    else:
+        feats = extractor(crops, layer=layer, feature_type="patch")
+        out = ops.ffa(feats, torch.cat([torch.as_tensor(p.proposals_masks) for p in group], dim=0), cell=14, normalize=True)
+    if not many:
+        return out
+    sizes = [len(p.proposals) for p in group]
+    return list(torch.split(out, sizes, dim=0))
+
+
+WINDOW = 8     # images / frames whose crops share one ViT call
 
 
 def load_bank(retrieval: str, filelist: str, topk: int) -> TemplateBank:
@@ -80,12 +92,19 @@ def run_images(args, extractor, bank, feature_type, layer):
     out = []
     wanted = [idx for idx in range(len(dataset)) if by_image.get(dataset.frame_key(idx))]
     with torch.inference_mode():
-        for idx, entry in zip(wanted, read_ahead(dataset, wanted)):         # the next frames are decoded on a thread meanwhile
+        group = []
+
+        def flush():
+            for proposals, q in zip(group, describe(extractor, group, feature_type, layer) if group else []):
+                proposals.meshes, proposals.scores = retrieve_image(bank, q, args.topk)
+                out.extend(proposals.to_bop_dict())
+            group.clear()
+        for idx, entry in zip(wanted, read_ahead(dataset, wanted, WINDOW)):  # the next frames are decoded on threads meanwhile
             key = dataset.frame_key(idx)
-            entries = by_image[key]
-            proposals = Proposals(entry["image"], detections_of(entries), 420, key[0], key[1], bbox_extend=0.1, mask_rgb=True)   # :121
-            proposals.meshes, proposals.scores = retrieve_image(bank, describe(extractor, proposals, feature_type, layer), args.topk)
-            out.extend(proposals.to_bop_dict())
+            group.append(Proposals(entry["image"], detections_of(by_image[key]), 420, key[0], key[1], bbox_extend=0.1, mask_rgb=True))   # :121
+            if len(group) == WINDOW:
+                flush()
+        flush()
     name = f"props-ground-box-{args.box_thresh}-text-{args.text_thresh}-{feature_type}-{layer}-top-{args.topk}_{args.dataset}-{args.split}.json"
     path = results / (args.output or name)
     path.write_text(json.dumps(out))
@@ -107,9 +126,14 @@ def run_video(args, extractor, bank, feature_type, layer):
         def __getitem__(self, f):
             return np.asarray(Image.open(frames[f]).convert("RGB"), dtype=np.uint8)
     with torch.inference_mode():
-        for f, img in zip(mine, read_ahead(_Frames(), mine)):
-            proposals = Proposals(img, detections_of(per_frame[f]), 420, 0, f, bbox_extend=0.1, mask_rgb=False)                 # video :133
-            queries.append(describe(extractor, proposals, feature_type, layer))
+        group = []
+        for f, img in zip(mine, read_ahead(_Frames(), mine, WINDOW)):
+            group.append(Proposals(img, detections_of(per_frame[f]), 420, 0, f, bbox_extend=0.1, mask_rgb=False))               # video :133
+            if len(group) == WINDOW:
+                queries.extend(describe(extractor, group, feature_type, layer))
+                group = []
+        if group:
+            queries.extend(describe(extractor, group, feature_type, layer))
         # soft vote (:154-159,186-190): dense [N] vectors holding each frame's top-100 scores (or re-ranked means), mean over the
         # frames, arg-max per object; every frame then carries the clip's meshes and scores (:192-195)
         rows, best = bank.soft_vote(queries, k=min(100, bank.N), topk=args.topk, frame_ids=mine if world > 1 else None, n_obj=n_obj)

@@ -218,6 +218,10 @@ def test_retrieve_meshes_feeds_the_pose_drivers(workspace, monkeypatch):
     got0 = json.loads(out0.read_text())
     out5 = retrieve_meshes.run(["--dataset", "synth", "--detections", "dets.json", "--topk", "5", "--output", "props_top5.json"] + common)
     got5 = json.loads(out5.read_text())
+    # (the crops of up to 8 images went through one ViT call; image by image gives the same file)
+    monkeypatch.setattr(retrieve_meshes, "WINDOW", 1)
+    assert retrieve_meshes.run(["--dataset", "synth", "--detections", "dets.json", "--output", "props_w1.json"] + common).read_text() == out0.read_text()
+    monkeypatch.setattr(retrieve_meshes, "WINDOW", 8)
     for got in (got0, got5):
         assert len(got) == len(props)
         for g_, p in zip(got, props):
@@ -246,6 +250,10 @@ def test_retrieve_meshes_feeds_the_pose_drivers(workspace, monkeypatch):
         for i, g_ in enumerate(got):
             assert (g_["mesh"], g_["score"]) == per_obj[i % 2] and g_["image_id"] == i // 2 and g_["bbox"] == vprops[i]["bbox"]
         outs[topk] = got
+    monkeypatch.setattr(retrieve_meshes, "WINDOW", 1)           # frame by frame: the same soft vote
+    o1 = retrieve_meshes.run(["--video", "clip", "--detections", "dets.json", "--topk", "0", "--output", "props_w1.json"] + common)
+    assert json.loads(o1.read_text()) == outs[0]
+    monkeypatch.setattr(retrieve_meshes, "WINDOW", 8)
     # two ranks (frames sharded, soft vote as a collective) write the same file
     first = (vd / "props-ground-box-0.2-text-0.2-ffa-22-top-0_clip.json").read_text()
     _run_ranks("scripts.retrieve_meshes", ["--video", "clip", "--detections", "dets.json", "--topk", "0"] + common, root, 2, 29741)

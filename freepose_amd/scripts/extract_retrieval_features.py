@@ -26,8 +26,11 @@ def mesh_descriptors(model, sample, feature: str, layer: int, batch_size: int) -
     """[<=T, D] fp32 per-view descriptors of one mesh (FFA) or [T, D] cls features."""
     templates = sample["templates"]
     ftype = "cls" if feature == "cls" else "patch"
-    feats = torch.cat([model(templates[i:i + batch_size], layer=layer, feature_type=ftype)
-                       for i in range(0, len(templates), batch_size)], dim=0)
+    if hasattr(model, "forward_batched"):               # batches of about batch_size that fill whole GEMM rounds (DINOv2FeatureExtractor.forward_batched)
+        feats = model.forward_batched(templates, layer=layer, feature_type=ftype, batch_size=batch_size)
+    else:
+        feats = torch.cat([model(templates[i:i + batch_size], layer=layer, feature_type=ftype)
+                           for i in range(0, len(templates), batch_size)], dim=0)
     if feature != "ffa":
         return feats.float().cpu().numpy()
     desc = ops.ffa(feats, sample["masks"], cell=14, out_f32=True).cpu().numpy()

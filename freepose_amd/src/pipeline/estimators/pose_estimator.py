@@ -45,6 +45,8 @@ class DinoPoseEstimator(torch.nn.Module):
         self.cache_dir.mkdir(parents=True, exist_ok=True)
 
     def _extract_features(self, proposals, layer=22, batch_size=128):
+        if hasattr(self.feature_extractor, "forward_batched"):        # batches of about batch_size that fill whole GEMM rounds, no concatenation
+            return self.feature_extractor.forward_batched(proposals, layer=layer, feature_type="patch", batch_size=batch_size)
         feats = [self.feature_extractor(proposals[i:i + batch_size], layer=layer, feature_type="patch")
                  for i in range(0, len(proposals), batch_size)]
         return torch.cat(feats, dim=0)

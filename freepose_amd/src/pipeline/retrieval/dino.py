@@ -75,3 +75,26 @@ class DINOv2FeatureExtractor(torch.nn.Module):
     def forward(self, images, layer=22, feature_type="cls"):
         with torch.inference_mode():
             return self.model.forward(images, layer=layer, feature_type=feature_type)
+
+    def forward_batched(self, images, layer=22, feature_type="patch", batch_size=128):
+        """features of MANY crops (the 600 templates of a mesh) in ViT calls of about `batch_size` crops — the reference's loops slice
+        `[i:i + batch_size]` (pose_estimator.py:29-33, extract_retrieval_features.py:49-52).  `batch_size` stays the memory bound (never
+        exceeded by more than an eighth); within it the split is chosen so that the GEMM grids run whole rounds of the 256-CU grid
+        (ops.plan_vit_batches: 600 crops @420^2 at 128 -> 143/143/143/107/64 instead of 4 x 128 + 88: 34 instead of 37 rounds in the
+        N = 1024 layers), and each call writes straight into its slice of one output tensor.  Same features: a crop's features do not
+        depend on its batch."""
+        from freepose_amd import ops
+        n = len(images)
+        if n == 0:
+            return self.forward(images, layer=layer, feature_type=feature_type)
+        m = self.model
+        H, W = images.shape[-2:]
+        P = (H // m.patch) * (W // m.patch)
+        shape = {"cls": (n, m.dim), "reg": (n, m.n_reg, m.dim), "patch": (n, P, m.dim)}[feature_type]
+        with torch.inference_mode():
+            out = torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+            at = 0
+            for b in ops.plan_vit_batches(n, P + 1 + m.n_reg, int(batch_size)):
+                m.forward(images[at:at + b], layer=layer, feature_type=feature_type, out=out[at:at + b])
+                at += b
+        return out

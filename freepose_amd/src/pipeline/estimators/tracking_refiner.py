@@ -86,21 +86,36 @@ class TrackingRefiner:
         return f[0].float()
 
     def pose_confidence(self, mesh, photo, K, transform):
-        cropped_photo, _new_bbox, new_K = self._crop_image(mesh, photo, K, transform)
-        rendered, rendered_depth = self._render(mesh, 518, 518, new_K.numpy(), transform)
-        valid = (rendered_depth > 0).float().cpu().numpy()
-        render_valid_37x37_mask = refiner_utils.cubic_resize(valid, (37, 37)) > 0.5           # cv2.INTER_CUBIC (:78)
+        return self.pose_confidences(mesh, [photo], K, [transform])[0]
+
+    def pose_confidences(self, mesh, frames, K, transforms, window=16):
+        """pose_confidence (reference :70-96) for a list of (frame, pose) pairs: [n, 37, 37] masked patch cosines between the photo crop and
+        the render of `mesh` under the pose.  The reference visits the pairs one by one with two B = 1 ViT-B forwards each
+        (n_inliers_per_pose :98-103); they are independent, so the photo crops and renders of `window` pairs share ONE ViT call — a crop's
+        features do not depend on its batch: the same confidences, pair for pair."""
         g = self.feats_size
-        photo_feats = self._patch_features(cropped_photo.clamp(0, 1))
-        render_feats = self._patch_features(rendered.permute(2, 0, 1).float().div(255))
-        photo_feats = photo_feats / torch.linalg.norm(photo_feats, dim=-1, keepdim=True)
-        render_feats = render_feats / torch.linalg.norm(render_feats, dim=-1, keepdim=True)
-        cosine_sim = (photo_feats * render_feats).sum(-1).view(g, g).cpu()
-        cosine_sim = cosine_sim * torch.from_numpy(render_valid_37x37_mask).float()
-        return cosine_sim.numpy()
+        out = []
+        pairs = list(zip(frames, transforms))
+        for w0 in range(0, len(pairs), max(1, int(window))):
+            chunk = pairs[w0:w0 + max(1, int(window))]
+            crops, valids = [], []
+            for photo, transform in chunk:
+                cropped_photo, _new_bbox, new_K = self._crop_image(mesh, photo, K, transform)
+                rendered, rendered_depth = self._render(mesh, 518, 518, new_K.numpy(), transform)
+                valids.append(rendered_depth > 0)
+                crops.append(cropped_photo.clamp(0, 1).to(torch.bfloat16))
+                crops.append(rendered.permute(2, 0, 1).float().div(255).to(torch.bfloat16))
+            feats = self.dinov2(torch.stack([c.cuda() for c in crops]), layer=len_blocks(self.dinov2), feature_type="patch").float()   # [2n, 1369, D]
+            feats = feats / torch.linalg.norm(feats, dim=-1, keepdim=True)
+            cos = (feats[0::2] * feats[1::2]).sum(-1).view(len(chunk), g, g).cpu()
+            valid = torch.stack(valids).float().cpu().numpy()                                   # one device -> host copy per window
+            for i in range(len(chunk)):
+                render_valid_37x37_mask = refiner_utils.cubic_resize(valid[i], (37, 37)) > 0.5  # cv2.INTER_CUBIC (:78)
+                out.append((cos[i] * torch.from_numpy(render_valid_37x37_mask).float()).numpy())
+        return np.stack(out) if out else np.zeros((0, g, g), np.float32)
 
     def n_inliers_per_pose(self, mesh, frames, K, transforms):
-        confidences = np.stack([self.pose_confidence(mesh, frame, K, transform) for frame, transform in zip(frames, transforms)])
+        confidences = self.pose_confidences(mesh, frames, K, transforms)
         thr = self._get_threshold_for_confidence(confidences)
         return (confidences > thr).sum(-1).sum(-1), thr
 

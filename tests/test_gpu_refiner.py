@@ -73,5 +73,10 @@ def test_pose_confidence_prefers_the_true_pose():
     assert good[good != 0].mean() > 0.9 and good[good != 0].mean() > bad[bad != 0].mean() + 0.05
     n, thr = tr.n_inliers_per_pose(mesh, [photo, photo], K, [T_true, T_wrong])
     assert n.shape == (2,) and n[0] > n[1] and 0 < thr < 1
+    # the pairs of a clip share ViT calls (windows of 16 pairs = 32 crops): pair for pair the confidences of the one-by-one calls
+    many = tr.pose_confidences(mesh, [photo] * 5, K, [T_true, T_wrong, T_true, T_wrong, T_true], window=3)
+    assert many.shape == (5, 37, 37)
+    for i, ref in enumerate((good, bad, good, bad, good)):
+        assert np.array_equal(many[i], ref), i
     with pytest.raises(NotImplementedError):
         tr.refine

@@ -60,7 +60,7 @@ def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, 
             return f, img, masks, boxes
     order = list(range(len(frames)) if frame_ids is None else frame_ids)
     depth = getattr(args, "read_ahead", 2)
-    window = max(1, getattr(args, "query_window", 8)) if rescoring else 1
+    window = max(1, getattr(args, "query_window", 8))
 
     def windows():
         """lists of up to `window` consecutive frames, each (f, boxes, Proposals): the next frames are decoded on a background thread
@@ -81,11 +81,13 @@ def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, 
         qn = {}
         if window > 1:
             with torch.inference_mode():
-                todo = [(f, o) for f, _, _ in chunk for o in obj_ids if not (f == order[0])]
+                todo = [(f, o) for f, _, _ in chunk for o in obj_ids if not (rescoring and f == order[0])]
                 if todo:
                     by_f = {f: pr for f, _, pr in chunk}
                     crops = torch.stack([torch.as_tensor(by_f[f].proposals[o]) for f, o in todo]).to("cuda", torch.bfloat16)
-                    feats = ops.l2_normalize(model.feature_extractor(crops, layer=args.layer, feature_type="patch"))
+                    feats = model.feature_extractor(crops, layer=args.layer, feature_type="patch")
+                    if rescoring:                  # the fine step scores against the NORMALISED query (online_pose_estimator.py:58-60); the
+                        feats = ops.l2_normalize(feats)        # coarse estimator normalises its raw query itself (pose_estimator.py:87)
                     qn = {fo: feats[i:i + 1] for i, fo in enumerate(todo)}
         for f, boxes, proposals in chunk:
             outs = {}
@@ -106,6 +108,11 @@ def track_objects(model, templates, frames, props, meshes, mesh_ids, scales, K, 
                                             meshes[o], K, boxes[o], scales[o], prev_pose=None, neighborhood=15, layer=args.layer,
                                             batch_size=args.batch_size)
                         prev[o] = outs[o]["TCO"][0]
+                elif window > 1:       # coarse estimate per frame (frames independent): the frame's objects in one estimator step
+                    items = [dict(proposal=proposals.proposals[o], template_dict=templates.get_template_by_name(mesh_ids[o]), K=K, bbox=boxes[o],
+                                  est_scale=scales[o], query_feat=qn[(f, o)]) for o in obj_ids]
+                    for o, out in zip(obj_ids, model.forward_many(items, layer=args.layer, batch_size=args.batch_size)):
+                        outs[o] = out
                 else:
                     for o in obj_ids:
                         outs[o] = model(proposals.proposals[o], templates.get_template_by_name(mesh_ids[o]), K, boxes[o], scales[o],

@@ -104,6 +104,9 @@ def test_video_driver_one_rank_two_ranks_and_modes(workspace, monkeypatch):
     div.run(argv + ["--no_rescore"])
     text_c1 = out.read_text()
     out.unlink()
+    div.run(argv + ["--no_rescore", "--query_window", "1", "--read_ahead", "0"])      # per-frame query forwards: the same file
+    assert out.read_text() == text_c1
+    out.unlink()
     _run_ranks("scripts.dino_inference_video", argv + ["--no_rescore"], root, 2, 29572)
     assert out.read_text() == text_c1
     dfc = pd.read_csv(out)

@@ -47,7 +47,10 @@ class Proposals:
 
     def __init__(self, image, detections_output, target_size=350, scene_id=None, frame_id=None, bbox_extend=0.2,
                  mask_rgb=True):
-        self._image_u8 = torch.as_tensor(np.ascontiguousarray(image), dtype=torch.uint8)
+        arr = np.ascontiguousarray(image)
+        if not arr.flags.writeable:                      # (np.asarray of a PIL image: torch wants a writable buffer)
+            arr = arr.copy()
+        self._image_u8 = torch.as_tensor(arr, dtype=torch.uint8)
         self.masks = torch.as_tensor(detections_output["masks"]).bool()
         self.boxes = torch.as_tensor(detections_output["boxes"]).int()
         self.rgb_proposal_processor = CropResizePad(target_size=target_size, orig_size=(image.shape[0], image.shape[1]),

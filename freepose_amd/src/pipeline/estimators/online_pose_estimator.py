@@ -50,12 +50,25 @@ class _HypothesisStore:
             self.slot[g] = base + k
         return new, list(range(base, base + len(new)))
 
+    def _grow(self, rows, feats, ext, masks):
+        """device buffers for at least `rows` hypotheses: 128 to start with, doubled (contents kept) up to `cap` — a clip that stays near
+        its first pose never pays for the full store (1.8 MB per ViT-L hypothesis)"""
+        have = 0 if self.feats is None else self.feats.shape[0]
+        if rows <= have:
+            return
+        size = min(self.cap, max(128, 2 * have, rows))
+
+        def grown(old, like):
+            new = torch.empty((size,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+            if old is not None:
+                new[:have] = old
+            return new
+        self.feats, self.ext = grown(self.feats, feats), grown(self.ext, ext)
+        if self.need_masks:
+            self.masks = grown(self.masks, masks)
+
     def write(self, slots, feats, ext, masks):
-        if self.feats is None:
-            self.feats = torch.empty((self.cap,) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
-            self.ext = torch.empty((self.cap,) + tuple(ext.shape[1:]), dtype=ext.dtype, device=ext.device)
-            if self.need_masks:
-                self.masks = torch.empty((self.cap,) + tuple(masks.shape[1:]), dtype=masks.dtype, device=masks.device)
+        self._grow(max(slots) + 1, feats, ext, masks)
         idx = torch.as_tensor(slots, dtype=torch.long, device=feats.device)
         self.feats.index_copy_(0, idx, feats)
         self.ext.index_copy_(0, idx, ext)
@@ -72,7 +85,7 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
                  feature_extractor=None, hypothesis_cache=768, hypothesis_meshes=8):
         """`hypothesis_cache`: fine-grid hypotheses kept per mesh between frames (_HypothesisStore; 0 = recompute every hypothesis in
         every frame like the reference — same results); `hypothesis_meshes`: meshes that keep such a store (least recently used out).
-        768 hypotheses of a ViT-L @420^2 are 1.4 GB."""
+        768 hypotheses of a ViT-L @420^2 are 1.4 GB (the buffers start at 128 hypotheses and double as the object turns)."""
         super().__init__()
         self.hypothesis_cache, self.hypothesis_meshes = int(hypothesis_cache), int(hypothesis_meshes)
         self._hyp_stores = OrderedDict()             # (id(mesh), layer, masks?) -> _HypothesisStore

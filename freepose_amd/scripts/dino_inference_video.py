@@ -145,7 +145,7 @@ def main(args):
     else:
         model = DinoOnlinePoseEstimator(n_coarse_poses=args.n_views, n_fine_poses=args.n_fine_poses, cache_size=args.cache_size,
                                         save_all=args.save_all_cache, cache_dir=cache_dir, feature_extractor=extractor,
-                                        hypothesis_cache=args.hypothesis_cache)
+                                        hypothesis_cache=args.hypothesis_cache, hypothesis_meshes=args.hypothesis_meshes)
 
     props = json.loads((results_dir / args.proposals).read_text())
     n_objects = len(list(takewhile(lambda x: x["image_id"] == 0, props)))
@@ -219,6 +219,7 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)                           # self-launch N ranks, one per GPU (RCCL)
     ap.add_argument("--read_ahead", type=int, default=2)                     # frames decoded ahead on a thread (0 = the sequential loop)
     ap.add_argument("--hypothesis_cache", type=int, default=768)             # fine-grid hypotheses kept per mesh between frames (0 = recompute all, same CSV)
+    ap.add_argument("--hypothesis_meshes", type=int, default=8)              # meshes that keep such a store between frames (a frame's own objects always do)
     ap.add_argument("--query_window", type=int, default=8)                   # frames whose query crops share one ViT call (1 = one call per frame, same CSV)
     return ap
 

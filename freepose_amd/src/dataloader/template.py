@@ -41,6 +41,8 @@ class _Staged:
 
 
 class WebTemplateDataset:
+    MAX_PENDING = 4                                  # prefetches in flight or waiting to be fetched (oldest dropped beyond)
+
     def __init__(self, wds_dir: str, filelist_path: str, resolution: int = 420, bbox_extend: float = 0, crop: bool = True,
                  n_views: int = N_VIEWS, cache_meshes: int = 8, decode_threads: int | None = None):
         self.wds_dir = Path(wds_dir).resolve()
@@ -65,12 +67,14 @@ class WebTemplateDataset:
     def __len__(self):
         return len(self.frame_index)
 
-    def get_template_by_name(self, model_name):
-        idx = self.frame_index[self.frame_index == model_name].index[0]
-        return self.__getitem__(idx)
+    def _lookup(self, model_name):
+        """positions of `model_name` in the file list — ONE rule for every by-name entry: the name as given against the file list with
+        its underscores removed (the reference compares exactly so, template.py:35,63)"""
+        return self.frame_index[self.frame_index == model_name].index
 
-    def index_of(self, model_name) -> int:
-        return int(self.frame_index[self.frame_index == str(model_name).replace("_", "")].index[0])
+    def get_template_by_name(self, model_name):
+        idx = self._lookup(model_name)[0]
+        return self.__getitem__(idx)
 
     def _member_index(self, tar_path: Path):
         """{member name: (offset of its data in the tar, size)}; the reference's sidecar `shard-%06d.npy` (a pickled name -> TarInfo dict,
@@ -131,10 +135,11 @@ class WebTemplateDataset:
             return st
         keys = [(members[f"{name}_{k}.rgb.png"], members[f"{name}_{k}.depth.png"]) for k in range(self.n_views)]
         fd = os.open(tar_path.as_posix(), os.O_RDONLY)
+        pinned = None
         try:
             r0, d0 = self._decode_pair(os.pread(fd, keys[0][0][1], keys[0][0][0]), os.pread(fd, keys[0][1][1], keys[0][1][0]))
             T, (H, W) = len(keys), d0.shape
-            rgb_pin, dep_pin = self._buffers(T, H, W)
+            pinned = rgb_pin, dep_pin = self._buffers(T, H, W)
             rgb_np, dep_np = rgb_pin.numpy(), dep_pin.numpy().view(np.uint16)
             rgb_np[0], dep_np[0] = r0, d0
 
@@ -147,21 +152,24 @@ class WebTemplateDataset:
             futs = [pool.submit(work, k, min(k + step, T)) for k in range(1, T, step)]
             for f in futs:
                 f.result()
+            st.seconds = time.perf_counter() - t0
+            with torch.cuda.device(device):
+                with self._lock:
+                    if self._copy_stream is None:
+                        self._copy_stream = torch.cuda.Stream()
+                with torch.cuda.stream(self._copy_stream):
+                    st.rgb = rgb_pin.to("cuda", non_blocking=True)
+                    st.dep = dep_pin.to("cuda", non_blocking=True)
+                    st.event = torch.cuda.Event()
+                    st.event.record(self._copy_stream)
+            st.event.synchronize()                      # (this thread only: the pinned pair is free again once the copies are done)
         finally:
             os.close(fd)
-        st.seconds = time.perf_counter() - t0
-        with torch.cuda.device(device):
-            with self._lock:
-                if self._copy_stream is None:
-                    self._copy_stream = torch.cuda.Stream()
-            with torch.cuda.stream(self._copy_stream):
-                st.rgb = rgb_pin.to("cuda", non_blocking=True)
-                st.dep = dep_pin.to("cuda", non_blocking=True)
-                st.event = torch.cuda.Event()
-                st.event.record(self._copy_stream)
-        st.event.synchronize()                          # (this thread only: the pinned pair is free again once the copies are done)
-        with self._lock:
-            self._pinned[(T, H, W)].append((rgb_pin, dep_pin))
+            if pinned is not None:                      # also when a decode or a copy raised: the pair goes back to the pool
+                if st.event is not None:
+                    st.event.synchronize()
+                with self._lock:
+                    self._pinned[pinned[0].shape[:3]].append(pinned)
         st.n = T
         return st
 
@@ -173,14 +181,17 @@ class WebTemplateDataset:
             return
         _, bg = self._executors()
         dev = torch.cuda.current_device()
+        while len(self._pending) >= self.MAX_PENDING:   # prefetched but never fetched: each done one pins ~530 MB of device memory
+            old = next(iter(self._pending))
+            self._pending.pop(old).cancel()
         self._pending[idx] = bg.submit(self._stage, idx, dev)
 
     def prefetch_by_name(self, model_name):
         """prefetch() for a mesh named in a proposals file; names the file list does not hold are ignored (the lookup will raise later,
         where the reference's does)"""
-        sel = self.frame_index[self.frame_index == str(model_name)]
-        if len(sel.index):
-            self.prefetch(int(sel.index[0]))
+        sel = self._lookup(str(model_name))
+        if len(sel):
+            self.prefetch(int(sel[0]))
 
     def __getitem__(self, idx: int):
         idx = int(idx)
@@ -202,7 +213,13 @@ class WebTemplateDataset:
         self.decode_seconds += st.seconds
         if st.n == 0:
             return {"templates": None, "masks": None, "depths": None, "bboxes": None, "model_name": st.name, "tar_file": st.tar_file}
-        torch.cuda.current_stream().wait_event(st.event)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(st.event)
+        # the two device arrays were allocated on the loader's side stream: tell the caching allocator that THIS stream reads them, or
+        # their blocks return to the side stream's pool when _load drops them and the next prefetch's copy may overwrite them while the
+        # conversion / crop kernels below are still queued behind earlier ViT work
+        st.rgb.record_stream(cur)
+        st.dep.record_stream(cur)
         rgb_u8 = st.rgb                                                                   # [T,H,W,3] u8
         # metres, float32 (:72): the reference divides in float64 (numpy) and rounds to float32 — the same two IEEE operations here
         depth = ((st.dep.to(torch.int32) & 0xFFFF).to(torch.float64) / 1000).to(torch.float32)

@@ -138,14 +138,21 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
         return close
 
     def _hypothesis_store(self, mesh, layer, need_masks):
+        """the store of a mesh (created on first use, most recently used last).  Nothing is evicted here: a step resolves the stores of
+        ALL its objects first and trims afterwards (_trim_stores), so a frame that tracks more distinct meshes than `hypothesis_meshes`
+        keeps every store it is using for the duration of the step."""
         key = (id(mesh), int(layer), bool(need_masks), float(self.rendering_scale))
         st = self._hyp_stores.get(key)
         if st is None:
             st = self._hyp_stores[key] = _HypothesisStore(mesh, self.hypothesis_cache, need_masks)
-            while len(self._hyp_stores) > max(1, self.hypothesis_meshes):
-                self._hyp_stores.popitem(last=False)
         self._hyp_stores.move_to_end(key)
         return st
+
+    def _trim_stores(self, in_use=0):
+        """least recently used stores out, down to max(hypothesis_meshes, stores the current step uses)"""
+        bound = max(1, self.hypothesis_meshes, int(in_use))
+        while len(self._hyp_stores) > bound:
+            self._hyp_stores.popitem(last=False)
 
     def forward_fine(self, proposal, proposal_mask, template_dict, mesh, K, bbox, est_scale, prev_pose, neighborhood=15,
                      layer=22, mask_scores=False, query_feat=None):
@@ -165,18 +172,19 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
         if len(items) == 0:
             return []
         work, pieces = [], []
-        neighbourhoods, wanted = [], {}
+        neighbourhoods, stores, wanted = [], [], {}
         for it in items:
             close = self._neighbourhood(np.asarray(it["prev_pose"])[:3, :3], float(neighborhood))
             if len(close) == 0:
                 raise RuntimeError("no fine-grid rotation within the neighbourhood of the previous pose")
             neighbourhoods.append(close)
-            if self.hypothesis_cache > 0:
-                st = self._hypothesis_store(it["mesh"], layer, mask_scores)
+            st = self._hypothesis_store(it["mesh"], layer, mask_scores) if self.hypothesis_cache > 0 else None
+            stores.append(st)                          # resolved ONCE per item: the second loop must see the same object
+            if st is not None:
                 wanted.setdefault(id(st), (st, []))[1].extend(int(g) for g in close)
+        self._trim_stores(in_use=len(wanted))          # (after the step's stores were all touched: none of them is the LRU victim)
         usable = {k: st.make_room(ids) for k, (st, ids) in wanted.items()}       # (objects that share a mesh share its store)
-        for it, close in zip(items, neighbourhoods):
-            store = self._hypothesis_store(it["mesh"], layer, mask_scores) if self.hypothesis_cache > 0 else None
+        for it, close, store in zip(items, neighbourhoods, stores):
             if store is not None and not usable[id(store)]:
                 store = None
             todo, slots = store.reserve(close) if store is not None else ([int(g) for g in close], None)

@@ -12,7 +12,9 @@ Same constructor, `forward` signature and result dict.  What changed underneath:
 """
 from __future__ import annotations
 
+import os
 import shutil
+import tempfile
 from collections import OrderedDict
 from fcntl import LOCK_EX, LOCK_UN, flock
 from pathlib import Path
@@ -39,10 +41,14 @@ class DinoPoseEstimator(torch.nn.Module):
         # model_name -> bf16 [T,P,D] on the device, rows already F.normalize()d (the reference re-normalises the cached tensor on
         # every call, :85; the normalised bf16 tensor is the same bits every time, so it is stored once — SURVEY §8 f-1)
         self.feature_cache = OrderedDict()
+        self._layer_of = {}                          # model_name -> layer its cached rows were computed at (spill files carry it)
         self.cache_size = cache_size
         self.save_all = save_all
         self.cache_dir = Path(cache_dir)
         self.cache_dir.mkdir(parents=True, exist_ok=True)
+        # spill files of the device LRU belong to THIS estimator (they hold rows normalised at this run's layer / model / view count):
+        # a private directory, removed with the estimator whatever `save_all` says — a later run never finds another run's spill
+        self._spill_dir = Path(tempfile.mkdtemp(prefix=f".spill_{os.getpid()}_", dir=self.cache_dir))
 
     def _extract_features(self, proposals, layer=22, batch_size=128):
         if hasattr(self.feature_extractor, "forward_batched"):        # batches of about batch_size that fill whole GEMM rounds, no concatenation
@@ -63,20 +69,33 @@ class DinoPoseEstimator(torch.nn.Module):
 
     @staticmethod
     def _locked_save(obj, path):
-        with open(path, "wb") as f:
-            flock(f, LOCK_EX)
-            torch.save(obj, f)
-            f.flush()
-            flock(f, LOCK_UN)
+        """write-then-rename: a concurrent reader (another SLURM task on the same cache_dir, reference :43-48) sees the old file, no file
+        or the complete new one, never a truncated one; the exclusive flock is held on the temporary like the reference holds it on the
+        target"""
+        path = Path(path)
+        fd, tmp = tempfile.mkstemp(prefix=path.name + ".", suffix=".tmp", dir=path.parent)
+        try:
+            with os.fdopen(fd, "wb") as f:
+                flock(f, LOCK_EX)
+                torch.save(obj, f)
+                f.flush()
+                flock(f, LOCK_UN)
+            os.replace(tmp, path)
+        except BaseException:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
 
     def _store(self, key, features_normalized):
         self.feature_cache[key] = features_normalized
         self.feature_cache.move_to_end(key)
         while len(self.feature_cache) > self.cache_size:
             old_key, old = self.feature_cache.popitem(last=False)
-            path = self.cache_dir / f"{old_key}.evicted.pth"     # reference :50-53: the evicted entry goes to disk, a revisit reads it back
+            path = self._spill_dir / f"{old_key}.evicted.pth"    # reference :50-53: the evicted entry goes to disk, a revisit reads it back
             if not path.exists():
-                self._locked_save({"features_normalized": old.cpu()}, path)
+                self._locked_save({"features_normalized": old.cpu(), "layer": self._layer_of.pop(old_key, None)}, path)
         return features_normalized                     # the NORMALISED rows (also when cache_size evicted them at once)
 
     def _get_template_features(self, template_dict, layer=22, batch_size=128):
@@ -85,18 +104,25 @@ class DinoPoseEstimator(torch.nn.Module):
         if name in self.feature_cache:
             self.feature_cache.move_to_end(name)
             return self.feature_cache[name]
-        evicted = self.cache_dir / f"{name}.evicted.pth"
+        evicted = self._spill_dir / f"{name}.evicted.pth"
         if evicted.exists():                               # spilled by the LRU: already normalised, the bits the store held
-            return self._store(name, torch.load(evicted, map_location="cpu")["features_normalized"].to("cuda", dtype=torch.bfloat16))
+            blob = torch.load(evicted, map_location="cpu")
+            n_t = len(template_dict["templates"]) if template_dict.get("templates") is not None else None
+            if blob.get("layer") in (None, layer) and n_t in (None, blob["features_normalized"].shape[0]):
+                self._layer_of[name] = layer
+                return self._store(name, blob["features_normalized"].to("cuda", dtype=torch.bfloat16))
+            evicted.unlink()                               # rows of another layer / view count: recompute
         path = self.cache_dir / f"{name}.pth"
         if path.exists():
             feats = torch.load(path, map_location="cpu").to("cuda", dtype=torch.bfloat16)
         else:
             feats = self._extract_features(template_dict["templates"], layer=layer, batch_size=batch_size)
+        self._layer_of[name] = layer
         return self._cache_features(name, feats)           # normalised in place exactly once, whether or not the store kept it
 
     def __del__(self):
         try:
+            shutil.rmtree(self._spill_dir, ignore_errors=True)   # always: spill files are never another run's input
             if not self.save_all:
                 shutil.rmtree(self.cache_dir, ignore_errors=True)
         except Exception:
@@ -132,13 +158,17 @@ class DinoPoseEstimator(torch.nn.Module):
             sel = torch.stack([torch.as_tensor(depths[int(i)]) for i in top_indices[0].cpu()]).float()
         fx, fy, cx, cy = _intrinsics(template_dict["intrinsic"])
         ext = ops.depth_extents(sel, fx, fy, cx, cy)
-        return top_scores[0], top_indices[0], ext, query_feat
+        tm = template_dict["templates"]
+        # the winners' crops (reference :100) gathered now when they are on the device: the caller need not keep the 1.7 GB entry alive
+        retrieved = tm.index_select(0, top_indices[0].long()) if torch.is_tensor(tm) and tm.is_cuda else None
+        return top_scores[0], top_indices[0], ext, query_feat, retrieved
 
-    def _finish(self, proposal, template_dict, K, bbox, est_scale, top_scores, top_indices, ext, query_feat, return_query_feat):
+    def _finish(self, proposal, template_dict, K, bbox, est_scale, top_scores, top_indices, ext, query_feat, return_query_feat,
+                retrieved=None):
         """host side: the reference's float64 pose formula on the three winners (:104-112)"""
         top_indices = np.asarray(top_indices).astype(np.int64)
         out = {"TCO": [], "scores": np.asarray(top_scores), "proposal": proposal, "K": K, "bbox": bbox,
-               "retrieved_proposals": [template_dict["templates"][i] for i in top_indices]}
+               "retrieved_proposals": list(retrieved) if retrieved is not None else [template_dict["templates"][i] for i in top_indices]}
         ratio = float(est_scale) / 0.25   # cloud re-centred, /0.25 (render scale), *est_scale (reference :104-111)
         for j, i in enumerate(top_indices):
             out["TCO"].append(z_from_extents(bbox, ext[j, 4] * ratio, ext[j, 5] * ratio, K, self.mesh_poses[int(i)]))
@@ -150,9 +180,9 @@ class DinoPoseEstimator(torch.nn.Module):
                 query_feat=None):
         """`query_feat` (optional, [1,P,D]): patch features of `proposal` computed by the caller, e.g. for all proposals of
         an image in one ViT batch (a B = 1 forward is launch-bound; features do not depend on batch neighbours)."""
-        s, i, ext, query_feat = self._enqueue(proposal, template_dict, query_feat, layer, batch_size)
+        s, i, ext, query_feat, retrieved = self._enqueue(proposal, template_dict, query_feat, layer, batch_size)
         return self._finish(proposal, template_dict, K, bbox, est_scale, s.cpu().numpy(), i.cpu().numpy(), ext.cpu().numpy(), query_feat,
-                            return_query_feat)
+                            return_query_feat, retrieved)
 
     def forward_many(self, items, layer=22, batch_size=128, return_query_feat=False):
         """`forward` for several proposals (dicts with proposal, template_dict, K, bbox, est_scale [, query_feat]) — the proposals of one
@@ -165,18 +195,20 @@ class DinoPoseEstimator(torch.nn.Module):
             if callable(it["template_dict"]):             # in proposal order, so a mesh's decode still hides under its predecessor's ViT calls)
                 it["template_dict"] = it["template_dict"]()
             it["_queued"] = self._enqueue(it["proposal"], it["template_dict"], it.get("query_feat"), layer, batch_size)
+            if it["_queued"][4] is not None:              # winners' crops gathered: the window no longer pins this mesh's decoded entry
+                it["template_dict"] = None                # (WebTemplateDataset's own store, bounded by cache_meshes, decides what stays)
         queued = [it.pop("_queued") for it in items]
         k = queued[0][0].shape[0]
         if any(q[0].shape[0] != k for q in queued):       # (meshes with fewer than 3 templates: no common shape to pack)
             return [self._finish(it["proposal"], it["template_dict"], it["K"], it["bbox"], it["est_scale"], q[0].cpu().numpy(), q[1].cpu().numpy(),
-                                 q[2].cpu().numpy(), q[3], return_query_feat) for it, q in zip(items, queued)]
+                                 q[2].cpu().numpy(), q[3], return_query_feat, q[4]) for it, q in zip(items, queued)]
         packed = torch.cat([torch.cat([q[0].double(), q[1].double(), q[2].double().reshape(-1)]) for q in queued]).cpu().numpy()
         w = packed.size // len(items)
         outs = []
         for n, (it, q) in enumerate(zip(items, queued)):
             row = packed[n * w:(n + 1) * w]
             outs.append(self._finish(it["proposal"], it["template_dict"], it["K"], it["bbox"], it["est_scale"], row[:k].astype(np.float32),
-                                     row[k:2 * k], row[2 * k:].reshape(k, -1), q[3], return_query_feat))
+                                     row[k:2 * k], row[2 * k:].reshape(k, -1), q[3], return_query_feat, q[4]))
         return outs
 
     @staticmethod

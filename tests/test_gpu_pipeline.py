@@ -98,10 +98,20 @@ def test_pose_estimator_forward_matches_reference(golden_dir, tmp_path):
     raw = torch.load(tmp_path / "c1" / "m.pth")
     assert raw.dtype == torch.bfloat16 and raw.device.type == "cpu" and torch.equal(raw.cuda(), Counting(g).t[:16])   # the reference's file format
     est1.forward(torch.from_numpy(g["query"]), dict(td, model_name="other"), g["Kq"], torch.from_numpy(g["bbox"]), float(g["est_scale"]))
-    assert list(est1.feature_cache) == ["other"] and (tmp_path / "c1" / "m.evicted.pth").exists() and Counting.calls == 2
+    assert list(est1.feature_cache) == ["other"] and (est1._spill_dir / "m.evicted.pth").exists() and Counting.calls == 2
+    assert est1._spill_dir.parent == tmp_path / "c1" and not list((tmp_path / "c1").glob("*.tmp"))
     out1 = est1.forward(*args)                                       # "m" comes back from the spill file: no third template pass
     assert Counting.calls == 2 and list(est1.feature_cache) == ["m"] and np.array_equal(out1["scores"], g["scores_top3"])
-    assert (tmp_path / "c1" / "other.evicted.pth").exists()
+    assert (est1._spill_dir / "other.evicted.pth").exists()
+    # a spill file is never another run's input: rows spilled at one layer are not served at another, and the directory
+    # goes with the estimator even under save_all (the raw <name>.pth files stay)
+    blob = torch.load(est1._spill_dir / "other.evicted.pth")
+    assert blob["layer"] == 22 and blob["features_normalized"].shape[0] == 16
+    spill = est1._spill_dir
+    del est1
+    import gc
+    gc.collect()
+    assert not spill.exists() and (tmp_path / "c1" / "m.pth").exists()
 
 
 def _mesh():
@@ -252,6 +262,50 @@ def test_hypothesis_store_gives_the_recomputed_results(tmp_path):
     # the poses follow the planted rotation (sanity of the scenario itself)
     last = ref[-1][0][0]
     assert np.isfinite(last).all() and abs(np.linalg.det(last[:3, :3]) - 1) < 1e-6
+
+
+def test_more_tracked_meshes_than_hypothesis_stores(tmp_path):
+    """a frame that tracks more distinct meshes than `hypothesis_meshes` (the store of the first object was evicted while the
+    step still held it -> KeyError): every object keeps its store for the step, results == no store, and the LRU bound holds again once
+    a later frame tracks fewer"""
+    import warnings
+    from src.pipeline.estimators.online_pose_estimator import DinoOnlinePoseEstimator
+    from src.pipeline.retrieval.dino import DINOv2FeatureExtractor
+    from src.pipeline.retrieval.renderer import MeshRenderer
+    from freepose_amd.mesh_io import TriMesh
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fe = DINOv2FeatureExtractor("dinov2_vits14_reg", seed=4)
+    base = _mesh()
+    rng = np.random.default_rng(8)
+    meshes = [TriMesh(np.asarray(base.vertices, np.float32) * rng.uniform(0.5, 1.0, size=3).astype(np.float32), np.asarray(base.faces),
+                      rng.integers(0, 255, size=(len(base.vertices), 3), dtype=np.uint8)) for _ in range(5)]
+    K = np.array([[600.0, 0, 210], [0, 600.0, 210], [0, 0, 1]])
+
+    def run(cap, n_stores):
+        est = DinoOnlinePoseEstimator(n_coarse_poses=8, n_fine_poses=20000, cache_size=0, cache_dir=tmp_path / f"m{cap}", feature_extractor=fe,
+                                      hypothesis_cache=cap, hypothesis_meshes=n_stores)
+        out = []
+        for fr, use in enumerate(([0, 1, 2, 3, 4], [4, 3, 2, 1, 0], [2, 0])):
+            items = []
+            for o in use:
+                j = 500 + 37 * o
+                rj = est.renderer.render_from_poses(meshes[o], [est.fine_mesh_poses[j]], scale=0.25)
+                cj, _, mj, ej = MeshRenderer.generate_proposals(rj, return_extents=True)
+                ee = ej[0].cpu().numpy()
+                items.append(dict(proposal=cj[0].float(), proposal_mask=mj[0], template_dict=None, mesh=meshes[o], K=K,
+                                  bbox=torch.tensor([int(ee[0]), int(ee[1]), int(ee[2]), int(ee[3])]), est_scale=0.25,
+                                  prev_pose=est.fine_mesh_poses[j + fr]))
+            out.append([(o_["TCO"][0].copy(), float(o_["scores"][0])) for o_ in est.forward_fine_many(items)])
+            assert len(est._hyp_stores) <= max(n_stores, len(use)) or cap == 0
+        return out, est
+
+    ref, _ = run(0, 2)
+    got, est = run(768, 2)
+    for a, b in zip(ref, got):
+        for (Ta, sa), (Tb, sb) in zip(a, b):
+            assert np.array_equal(Ta, Tb) and sa == sb
+    assert len(est._hyp_stores) == 2                  # the last frame tracked two meshes: back within the bound
 
 
 def _png(arr, mode):

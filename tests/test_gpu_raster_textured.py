@@ -251,6 +251,14 @@ def test_web_template_dataset_matches_reference_golden(tmp_path, golden_dir):
     dr[1]
     dr.prefetch(1)
     assert not dr._pending
+    # prefetched but never fetched meshes do not pile up (each done one would pin ~530 MB of device memory): oldest dropped beyond the bound
+    db = WebTemplateDataset(str(tmp_path / "shards"), str(tmp_path / "mesh_cache.csv"), bbox_extend=0, cache_meshes=0)
+    db.MAX_PENDING = 1
+    db.prefetch(0)
+    db.prefetch(1)
+    assert set(db._pending) == {1}
+    for got, want in ((db[0], p0), (db[1], p1)):
+        assert torch.equal(got["templates"], want["templates"]) and torch.equal(got["depths"], want["depths"])
 
 
 @pytest.mark.parametrize("textured", [False, True])

@@ -1,9 +1,11 @@
 """End-to-end pose parity with the ViT in the loop (VERDICT r2 "missing" #1, north star: "output R,t poses match the reference
 within a stated tolerance on identical proposals ... within 2 deg / 2 mm").
 
-BASELINE config 4 at reduced size: ViT-L/14-reg layer 22 @420^2 (seeded random-init weights of the real architecture), 64 pose
-hypotheses of a TEXTURED mesh, 8 queries = renders of the same mesh at perturbed hypothesis poses.  FP_PARITY_FULL=1 runs the same test
-at the configuration's own size: 576 hypotheses, 518^2 crops.
+BASELINE config 4: ViT-L/14-reg layer 22 (seeded random-init weights of the real architecture), pose hypotheses of a TEXTURED mesh,
+queries = renders of the same mesh at perturbed hypothesis poses.  Two sizes, both in the default `-m gpu` run:
+  * reduced — 64 hypotheses, 8 queries, 420^2 crops, oracle ViT in bf16 (the reference's regime) AND fp32   (this file);
+  * the configuration's OWN size — 576 hypotheses, 518^2 crops, 2 queries, bf16 regime   (tests/test_gpu_zz_pose_parity_full.py, which
+    sorts last so its table ends the suite's output; FP_PARITY_QUERIES / FP_PARITY_FP32=1 widen it).
 
   oracle side (CPU, nothing from freepose_amd):  fo.rasterize -> fo.depth_extents -> fo.crop_resize_pad -> vit_ref.vit_forward
       (fp32, and the reference's bf16 regime: bf16 weights/activations, pose_estimator.py:21) -> fo.template_score
@@ -32,11 +34,7 @@ from tests._meshes import checker_gradient_texture, textured_cube
 
 pytestmark = pytest.mark.gpu
 
-N_HYP, N_QUERY, RES, LAYER = 64, 8, 420, 22
-# BASELINE config 4 at FULL size (576 hypotheses, 518^2 crops: ~10 min of CPU oracle ViT on a 16-thread host) is opt-in:
-#   FP_PARITY_FULL=1 python -m pytest tests/test_gpu_pose_parity.py -s          (log of one run: profiles/r04_pose_parity_full.log)
-if os.environ.get("FP_PARITY_FULL") == "1":
-    N_HYP, N_QUERY, RES = 576, int(os.environ.get("FP_PARITY_QUERIES", "6")), 518
+LAYER = 22
 MARGIN_ULP = 3          # bf16 ulps of lead that make an arg-max decisive (scores ~0.3-0.9: 1 ulp = 2^-9 .. 2^-8)
 SCORE_ULP = 3           # per-hypothesis |HIP score - oracle score| bound, bf16 ulps of the oracle score
 
@@ -65,20 +63,16 @@ def _rot(axis, deg):
 
 
 def _oracle_feats(sd, crops_f32, dtype, batch=8):
-    from oracle import vit_ref
-    out = []
-    nthr = torch.get_num_threads()
-    torch.set_num_threads(min(16, nthr))     # the fastest count on the 256-thread hosts of the pool (bench.py's cpu_baseline probe); all cores are several times slower
-    try:
-        with torch.inference_mode():
-            for i in range(0, crops_f32.shape[0], batch):
-                out.append(vit_ref.vit_forward(sd, crops_f32[i:i + batch], layer=LAYER, feature_type="patch", dtype=dtype).to(torch.bfloat16))
-    finally:
-        torch.set_num_threads(nthr)
-    return torch.cat(out)
+    from tests._oracle_pool import oracle_feats      # 16 torch threads per process (the fastest count on the pool's 256-thread hosts), several processes
+    return oracle_feats(sd, crops_f32, LAYER, dtype, batch)
 
 
 def test_pose_parity_vit_in_the_loop(capsys):
+    """reduced size, both regimes"""
+    run_pose_parity(capsys, 64, 8, 420, ("bf16", "fp32"))
+
+
+def run_pose_parity(capsys, N_HYP, N_QUERY, RES, regime_names):
     from freepose_amd import ops
     from freepose_amd.pipeline import HotPath
     from freepose_amd.retrieval import TemplateBank
@@ -140,9 +134,7 @@ def test_pose_parity_vit_in_the_loop(capsys):
     sd32 = {k: t.float() for k, t in sd.items()}
 
     report = {}
-    regimes = (("bf16", torch.bfloat16), ("fp32", torch.float32))
-    if os.environ.get("FP_PARITY_FULL") == "1" and os.environ.get("FP_PARITY_FP32") != "1":
-        regimes = regimes[:1]      # full size: the reference's own (bf16) regime; FP_PARITY_FP32=1 adds the fp32 oracle (~6 more minutes)
+    regimes = [(n, {"bf16": torch.bfloat16, "fp32": torch.float32}[n]) for n in regime_names]
     for regime, dtype in regimes:
         src = sd if dtype == torch.bfloat16 else sd32
         hf = fo.torch_to_bits(_oracle_feats(src, h_crops_t, dtype))
@@ -180,10 +172,10 @@ def test_pose_parity_vit_in_the_loop(capsys):
 
     with capsys.disabled():
         for regime, (agree, decisive, worst_ulp, rows) in report.items():
-            print(f"\n[pose parity, oracle ViT in {regime}] top-1 agreement {agree}/{N_QUERY} ({decisive} decisive at > {MARGIN_ULP} ulp), "
+            print(f"\n[pose parity, {N_HYP} hypotheses @{RES}^2, oracle ViT in {regime}] top-1 agreement {agree}/{N_QUERY} ({decisive} decisive at > {MARGIN_ULP} ulp), "
                   f"worst score difference {worst_ulp:.2f} bf16 ulp")
             print("  query planted oracle hip  lead[ulp] dscore[ulp]  re[deg] te[mm] (HIP vs oracle) | re[deg] te[mm] (HIP vs drawn pose)")
             for r in rows:
                 print("  %5d %7d %6d %3d  %9.1f %11.2f  %7.3f %6.3f                  | %7.2f %6.2f" % r)
-    # with 64 hypotheses (~45 deg apart) and 3-7 deg perturbations most queries must be decisive, or the test shows nothing
-    assert all(r[1] >= N_QUERY // 2 for r in report.values())
+    # with 3-7 deg perturbations of grid poses most queries must be decisive, or the test shows nothing
+    assert all(r[1] >= (N_QUERY + 1) // 2 for r in report.values())

@@ -79,6 +79,8 @@ SIGNATURES = {
     "fp_mesh_destroy": (c_int, [c_void_p]),
     "fp_rasterize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
                              c_int, c_void_p, c_void_p, c_void_p]),
+    "fp_rasterize_extents": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_int,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fp_depth_extents": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_void_p,
                                  c_void_p]),
     "fp_comm_unique_id": (c_int, [c_void_p]),

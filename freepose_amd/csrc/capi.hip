@@ -340,7 +340,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
     const fp_vit_arch& a = v->a;
     hipStream_t s = (hipStream_t)stream;
     FP_REQUIRE(B > 0 && H % a.patch == 0 && W % a.patch == 0, "vit_forward: B=%d H=%d W=%d (patch %d)", B, H, W, a.patch);
-    FP_REQUIRE(feature_type >= 0 && feature_type <= 2, "vit_forward: feature_type %d", feature_type);
+    FP_REQUIRE(feature_type >= 0 && feature_type <= 3, "vit_forward: feature_type %d", feature_type);
     FP_REQUIRE(v->cls && v->pos && v->pe_b && v->normw && v->normb && (a.n_reg == 0 || v->reg),
                "vit_forward: embedding / final-norm weights not set");
     // dino.py:18-21 breaks when blk_idx + 1 == layer: a layer outside [1, depth] (too large, zero or negative) never matches,
@@ -482,7 +482,7 @@ extern "C" int fp_vit_forward(fp_vit* v, const void* d_images, int B, int H, int
         else { rows_per_b = P; off = 1 + a.n_reg; }
         if (rows_per_b > 0)
             if ((rc = fp_layernorm(X, (bf16_t*)d_out, v->normw, v->normb, B * rows_per_b, D, a.ln_eps, rows_per_b, npad,
-                                   off, s)))
+                                   off, s, feature_type == 3)))
                 return rc;
     }
     return FP_OK;
@@ -526,8 +526,10 @@ extern "C" int fp_ffa(fp_ctx* ctx, const void* d_feats, const uint8_t* d_mask, i
     int rc;
     if (normalize || !tmp)
         if ((rc = ctx->get("ffa.tmp", (size_t)B * D * 2, (void**)&tmp))) return rc;
+    uint8_t* pm = nullptr;
+    if (cell > 1 && (rc = ctx->get("ffa.pm", (size_t)B * gh * gw, (void**)&pm))) return rc;
     if ((rc = fp_ffa_pool((const bf16_t*)d_feats, d_mask, tmp, normalize ? nullptr : d_out_f32, B, gh * gw, D, gh, gw,
-                          cell, s)))
+                          cell, pm, s)))
         return rc;
     if (normalize) {
         FP_REQUIRE(d_out_bf16, "ffa: normalize needs a bf16 output");

@@ -43,10 +43,10 @@ int fp_im2col_norm(const bf16_t* img, bf16_t* A, int B, int H, int W, int ps, in
 int fp_token_init(bf16_t* X, const bf16_t* cls, const bf16_t* pos0, const bf16_t* reg, int nreg, int B, int n_tok,
                   int npad, int D, hipStream_t s);
 int fp_layernorm(const bf16_t* X, bf16_t* Y, const bf16_t* gamma, const bf16_t* beta, int rows, int D, float eps,
-                 int rows_per_b, int in_stride_b, int in_off, hipStream_t s);
+                 int rows_per_b, int in_stride_b, int in_off, hipStream_t s, int l2_normalize = 0);
 int fp_posembed_aa(const bf16_t* src, bf16_t* dst, int G, int gh, int gw, int D, hipStream_t s);
 int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* out_f32, int B, int P, int D, int gh,
-                int gw, int cell, hipStream_t s);
+                int gw, int cell, uint8_t* pm_scratch, hipStream_t s);
 int fp_l2norm_rows(const bf16_t* X, bf16_t* Y, int rows, int D, hipStream_t s);
 // LayerNorm folded into the consuming GEMM (gemm_bf16.h FP_EPI_LN_*): row statistics and the one-off weight fold
 int fp_row_stats(const bf16_t* X, uint4* mfrag, float* rstd, int rows, int D, float eps, hipStream_t s);

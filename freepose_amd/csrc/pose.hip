@@ -146,6 +146,88 @@ __global__ __launch_bounds__(256) void crop_kernel(const void* __restrict__ imag
     }
 }
 
+// The renders' case (u8 HWC source with 3 channels, no mask, even target): the nearest source column of every output column and the
+// source row of the strip's rows are tabulated once per block in LDS, a thread then owns FOUR consecutive output pixels of a row in
+// all three channels — 12 byte loads in flight, the u8/255 table read in the output type, 4-/8-byte stores.  Same index rule and same
+// values as crop_kernel (bit-identical; the generic kernel keeps float sources, masks and odd targets).
+template <int SRC_U8, int OUT_BF16>
+__global__ __launch_bounds__(256) void crop_rgb_kernel(const uint8_t* __restrict__ images, int n_img, int H, int W,
+                                                       const CropParam* __restrict__ params, int target, void* __restrict__ outp) {
+    __shared__ float lut[256];
+    __shared__ __align__(8) short xs_s[2048 + 4];
+    __shared__ int ys_s[CROP_ROWS];
+    const int t = threadIdx.x;
+    lut[t] = (SRC_U8 == 1) ? (float)((double)t / 255.0) : __fdiv_rn((float)t, 255.0f);
+    if (OUT_BF16) lut[t] = __uint_as_float((uint32_t)f2bf(lut[t]));      // the table in the output type (bits in the low half)
+    const int i = blockIdx.y;
+    const CropParam p = params[i];
+    const int img = (n_img == 1) ? 0 : i;
+    const bool geom = (p.out == target) && p.cw > 0 && p.ch > 0;
+    const bool small1 = (p.h1 + p.w1) <= 128, small2 = (2 * p.out) <= 128;
+    const int row0 = blockIdx.x * CROP_ROWS;
+    const int nrow = min(CROP_ROWS, target - row0);
+    const int ngrp = (target + 3) >> 2;
+    for (int ox = t; ox < ngrp * 4; ox += blockDim.x) {
+        int xs = -1;
+        if (geom && ox < target) {
+            const int x1 = nearest_src(ox, p.S_w, p.out, p.inv2, small2) - p.pad_l;
+            if (x1 >= 0 && x1 < p.w1) xs = p.x0 + nearest_src(x1, p.cw, p.w1, p.inv1, small1);
+        }
+        xs_s[ox] = (short)xs;
+    }
+    if (t < nrow) {
+        int ys = -1;
+        if (geom) {
+            const int y1 = nearest_src(row0 + t, p.S_h, p.out, p.inv2, small2) - p.pad_t;
+            if (y1 >= 0 && y1 < p.h1) ys = p.y0 + nearest_src(y1, p.ch, p.h1, p.inv1, small1);
+        }
+        ys_s[t] = ys;
+    }
+    __syncthreads();
+    const uint8_t* base = images + (size_t)img * H * W * 3;
+    const size_t plane = (size_t)target * target;
+    for (int item = t; item < nrow * ngrp; item += blockDim.x) {
+        const int r = item / ngrp, g = item - r * ngrp;
+        const int oy = row0 + r, ox0 = g * 4;
+        const int ys = ys_s[r];
+        const uint2 xq = *(const uint2*)&xs_s[ox0];
+        const int xs[4] = {(int)(short)(xq.x & 0xffff), (int)(short)(xq.x >> 16), (int)(short)(xq.y & 0xffff), (int)(short)(xq.y >> 16)};
+        float v[3][4];
+        const uint8_t* rowp = base + (size_t)max(ys, 0) * W * 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = ys >= 0 && xs[k] >= 0;
+            const uint8_t* px = rowp + max(xs[k], 0) * 3;
+            const int b0 = px[0], b1 = px[1], b2 = px[2];
+            v[0][k] = ok ? lut[b0] : 0.f; v[1][k] = ok ? lut[b1] : 0.f; v[2][k] = ok ? lut[b2] : 0.f;
+        }
+        const int nval = min(4, target - ox0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t o = ((size_t)i * 3 + c) * plane + (size_t)oy * target + ox0;
+            if (OUT_BF16) {
+                bf16_t* op = (bf16_t*)outp + o;        // (target even, ox0 % 4 == 0: o is even -> 4-byte aligned)
+                const uint32_t lo = (__float_as_uint(v[c][0]) & 0xffffu) | (__float_as_uint(v[c][1]) << 16);
+                const uint32_t hi = (__float_as_uint(v[c][2]) & 0xffffu) | (__float_as_uint(v[c][3]) << 16);
+                if (nval == 4) {
+                    if ((o & 3) == 0) *(uint2*)op = make_uint2(lo, hi);
+                    else { ((uint32_t*)op)[0] = lo; ((uint32_t*)op)[1] = hi; }
+                } else {
+                    ((uint32_t*)op)[0] = lo;             // nval == 2 (target even)
+                }
+            } else {
+                float* op = (float*)outp + o;
+                if (nval == 4) {
+                    if ((o & 3) == 0) *(float4*)op = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+                    else { *(float2*)op = make_float2(v[c][0], v[c][1]); *(float2*)(op + 2) = make_float2(v[c][2], v[c][3]); }
+                } else {
+                    *(float2*)op = make_float2(v[c][0], v[c][1]);
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 struct Rot9 { double v[9]; };   // the previous rotation travels as a kernel argument (no staging copy, no host sync)
 __global__ void geodesic_flags_kernel(const double* __restrict__ grid, int G, const Rot9 Rprev,
@@ -313,6 +395,14 @@ int fp_crop_resize_pad_launch(const void* images, int src_u8, int n_img, int C, 
                        bbox_extend == 0.f ? 1 : 0, target, params);
     FP_LAUNCH_CHECK();
     dim3 grid(cdiv(target, CROP_ROWS), n), block(256);
+    if ((src_u8 == 1 || src_u8 == 2) && C == 3 && mask_mode == 0 && (target & 1) == 0 && target <= 2048 && W <= 32767) {
+#define FP_CROP_RGB(U, O) hipLaunchKernelGGL((crop_rgb_kernel<U, O>), grid, block, 0, s, (const uint8_t*)images, n_img, H, W, params, target, out)
+        if (src_u8 == 1) { if (out_bf16) FP_CROP_RGB(1, 1); else FP_CROP_RGB(1, 0); }
+        else { if (out_bf16) FP_CROP_RGB(2, 1); else FP_CROP_RGB(2, 0); }
+#undef FP_CROP_RGB
+        FP_LAUNCH_CHECK();
+        return FP_OK;
+    }
 #define FP_CROP(U, O) hipLaunchKernelGGL((crop_kernel<U, O>), grid, block, 0, s, images, n_img, C, H, W, params, target, masks, mask_mode, out)
     if (src_u8 == 1) { if (out_bf16) FP_CROP(1, 1); else FP_CROP(1, 0); }
     else if (src_u8 == 2) { if (out_bf16) FP_CROP(2, 1); else FP_CROP(2, 0); }

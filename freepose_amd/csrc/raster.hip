@@ -56,6 +56,7 @@ struct fp_mesh {
     fp_ctx* ctx = nullptr;
     float* verts = nullptr;    // [V,3]
     int32_t* faces = nullptr;  // [F,3]
+    int32_t* perm = nullptr;   // [F] slot -> face id, Morton order of the object-space centroids (tiled path: coherent 64-triangle chunks)
     uint8_t* colors = nullptr; // [V,4] rgba (a unused)
     float* uv = nullptr;       // [F,3,2] per-corner texture coordinates (textured meshes)
     uint8_t* tex = nullptr;    // rgba diffuse texture, all mip levels back to back (level k at texel offset lev_off[k])
@@ -474,45 +475,78 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Tiled path (images up to 704 px, meshes up to 32 768 triangles): the visibility keys of one screen tile live in LDS, so there is no global
-// visibility buffer (no 8 B/pixel clear, no L2 atomics, no resolve read).  Measured reason: the global-buffer path costs
-// 2.4-3.2 ms per 576 x 420^2 views REGARDLESS of the triangle count (1 280 ... 327 680): its triangle kernel is bound by the
-// ~70 M 64-bit L2 atomics (covered pixels x 2 surfaces), 1.44 ms for 1 280 as for 81 920 triangles.
-//   bin kernel : per (view, triangle) the tile range of its clipped pixel bbox as four nibbles (16 bit), and per chunk of 256
-//                consecutive triangles the OR of their tile masks (64 bit, tiles <= 8 x 8)
-//   tile kernel: one workgroup per (view, tile): LDS keys = ~0; chunks whose mask misses the tile are skipped with one
-//                scalar test; a lane whose triangle overlaps the tile rasterises it into LDS with ds_min_u64 — triangles
-//                with more than BIG_TILE_AREA candidate pixels inside the tile are handed to the whole wave (ballot loop);
-//                then the tile's pixels are resolved (same colour / depth arithmetic) and written once.
+// Tiled path (images up to 704 px, any triangle count): the visibility keys of one screen tile live in LDS, so there is no global
+// visibility buffer (no 8 B/pixel clear, no L2 atomics, no resolve read) — LDS triangle binning + per-wave depth test.
+//   upload      : the triangles are put in Morton order of their object-space centroids once per mesh (`perm`: slot -> face id), so
+//                 64 consecutive slots are neighbours on the surface and, under any pose, on the screen.  The visibility key still
+//                 carries the ORIGINAL face id: results do not depend on the order.
+//   bin kernel  : one wave per chunk of 64 slots.  Per (view, slot) the tile range of the triangle's clipped pixel bbox as four
+//                 nibbles (16 bit), and per chunk the OR of its triangles' tile masks (64 bit, tiles <= 8 x 8) by a wave reduction.
+//   tile kernel : one workgroup per (view, tile), all tiles of a view on one XCD (its screen-space vertices stay in that L2).
+//                 The chunk masks are read 1024 at a time (coalesced) and the chunks that touch the tile compacted into an LDS hit
+//                 list; each WAVE then takes hit chunks on its own — a lane whose triangle overlaps the tile rasterises it into LDS
+//                 with ds_min_u64, triangles with more than BIG_TILE_AREA candidate pixels in the tile are handed to the whole
+//                 wave (ballot loop).  A tile no chunk touches is written as background at once.  Otherwise the tile's pixels are
+//                 resolved (same colour / depth arithmetic as the global path), packed into their own LDS slot, and flushed row by
+//                 row as whole dwords.  The epilogue also reduces what fp_depth_extents would compute from the depth image
+//                 (count, pixel bbox, fp64 cloud extents: min / max / integer sums, order-independent, hence bit-identical) to one
+//                 partial record per tile; raster_extents_kernel folds the <= 64 records of a view.  The depth image itself is
+//                 optional: the pose hot path needs only the extents (pose_estimator.py:104-112) and the crops.
 // Same tri_setup / tri_cover / tri_depth, same candidate pixel set (bbox ∩ tile over all tiles = bbox), same 64-bit key and
 // an order-independent minimum: the output is bit-identical to the global-buffer path and to the oracle.
-constexpr int BIN_CHUNK = 256;
-constexpr int BIG_TILE_AREA = 48;
+constexpr int BIN_CHUNK = 64;
+constexpr int BIG_TILE_AREA = 32;
+constexpr int HITS_ROUND = 1024;         // chunk masks examined per round of the tile kernel (4 per thread)
 constexpr uint16_t TBOX_NONE = 0x000f;   // tx0 = 15 > tx1 = 0: overlaps nothing
+constexpr int PART_N = 10;               // doubles per (view, tile) extents record
 
-__global__ __launch_bounds__(BIN_CHUNK) void raster_bin_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
-                                                               int V, int F, int W, int Hh, int T,
-                                                               uint16_t* __restrict__ tbox, unsigned long long* __restrict__ cmask, int cull) {
-    __shared__ unsigned long long m_s;
-    const int h = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int f = chunk * BIN_CHUNK + threadIdx.x;
-    if (threadIdx.x == 0) m_s = 0ull;
-    __syncthreads();
-    if (f < F) {
-        const TriSetup t = tri_setup(sv_all + (size_t)h * V, faces, f, W, Hh);
-        uint16_t box = TBOX_NONE;
-        if (t.ok && !(cull && back_facing(t, sv_all + (size_t)h * V, faces, f))) {
+// Workgroup -> (item, view) with all items of a view on ONE XCD: workgroup L of a launch runs on XCD L % 8 (observed; a speed hint
+// only, MI355X_MICROARCH.md "Workgroup dispatch"), so within a group of 8 views the linear id walks the views fastest.
+__device__ __forceinline__ void view_major_ids(int nx, int Hn, int& item, int& h) {
+    const int L = blockIdx.y * nx + blockIdx.x;
+    const int full = Hn & ~7, per_group = 8 * nx;
+    if (L < (full >> 3) * per_group) {
+        const int g = L / per_group, r = L - g * per_group;
+        h = g * 8 + (r & 7); item = r >> 3;
+    } else {
+        const int r = L - (full >> 3) * per_group;
+        h = full + r / nx; item = r - (r / nx) * nx;
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long m) {
+    unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { lo |= __shfl_xor(lo, off, 64); hi |= __shfl_xor(hi, off, 64); }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void raster_bin_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
+                                                         const int32_t* __restrict__ perm, int V, int F, int W, int Hh, int T, int Hn,
+                                                         int nchunk, uint16_t* __restrict__ tbox,
+                                                         unsigned long long* __restrict__ cmask, int cull) {
+    int item, h;
+    view_major_ids(gridDim.x, Hn, item, h);
+    const int lane = threadIdx.x & 63;
+    const int chunk = item * 4 + (threadIdx.x >> 6);
+    if (chunk >= nchunk) return;                         // wave-uniform
+    const int slot = chunk * BIN_CHUNK + lane;
+    uint16_t box = TBOX_NONE;
+    unsigned long long m = 0ull;
+    if (slot < F) {
+        const int f = perm[slot];
+        const SVert* sv = sv_all + (size_t)h * V;
+        const TriSetup t = tri_setup(sv, faces, f, W, Hh);
+        if (t.ok && !(cull && back_facing(t, sv, faces, f))) {
             const int tx0 = t.bx0 / T, ty0 = t.by0 / T, tx1 = t.bx1 / T, ty1 = t.by1 / T;
             box = (uint16_t)(tx0 | (ty0 << 4) | (tx1 << 8) | (ty1 << 12));
-            unsigned long long m = 0ull;
-            for (int ty = ty0; ty <= ty1; ++ty)
-                for (int tx = tx0; tx <= tx1; ++tx) m |= 1ull << (ty * 8 + tx);
-            atomicOr(&m_s, m);
+            const unsigned long long row = ((1ull << (tx1 - tx0 + 1)) - 1ull) << tx0;    // <= 8 tiles per row
+            for (int ty = ty0; ty <= ty1; ++ty) m |= row << (ty * 8);
         }
-        tbox[(size_t)h * F + f] = box;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) cmask[(size_t)h * nchunk + chunk] = m_s;
+    tbox[((size_t)h * nchunk + chunk) * BIN_CHUNK + lane] = box;
+    m = wave_or64(m);
+    if (lane == 0) cmask[(size_t)h * nchunk + chunk] = m;
 }
 
 __device__ __forceinline__ void strad_pixel_tile(const Strad& q, int f, int px, int py, unsigned long long* tile, int X0, int Y0, int T) {
@@ -538,74 +572,224 @@ __device__ __forceinline__ void tile_pixel(const TriSetup& t, int f, int px, int
     atomicMin(slot, key);
 }
 
+struct ExtAcc {
+    int cnt, xmin, ymin, xmax, ymax;
+    double Xmin, Xmax, Ymin, Ymax;
+};
+__device__ __forceinline__ double shfl_xor_f64(double v, int off) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __shfl_xor((unsigned)b, off, 64), hi = __shfl_xor((unsigned)(b >> 32), off, 64);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
-                                                          ShadeArgs sh, const float* __restrict__ tables, int V, int F, int W, int Hh, int T,
-                                                          int ntx, const uint16_t* __restrict__ tbox,
+                                                          const int32_t* __restrict__ perm, ShadeArgs sh,
+                                                          const float* __restrict__ tables, int V, int F, int W, int Hh, int T,
+                                                          int ntx, int Hn, const uint16_t* __restrict__ tbox,
                                                           const unsigned long long* __restrict__ cmask, int nchunk,
-                                                          uint8_t* __restrict__ rgb, float* __restrict__ depth) {
-    extern __shared__ unsigned long long tile[];   // [T*T] visibility keys, then DEC/THR tables (512 floats)
+                                                          uint8_t* __restrict__ rgb, float* __restrict__ depth,
+                                                          double* __restrict__ part, double fx, double fy, double cx, double cy) {
+    extern __shared__ unsigned long long tile[];   // [T*T] visibility keys | DEC/THR tables (512 floats) | hit list | column / row factors
     float* tab = (float*)(tile + T * T);
-    tab[threadIdx.x] = tables[threadIdx.x];
-    tab[threadIdx.x + 256] = tables[threadIdx.x + 256];
-    const int h = blockIdx.y;
-    const int ty = blockIdx.x / ntx, tx = blockIdx.x - ty * ntx;
+    int* hits = (int*)(tab + 512);
+    double* ax = (double*)(hits + HITS_ROUND);
+    double* ay = ax + T;
+    __shared__ int nhit_s, total_s;
+    __shared__ double red_d[4][4];
+    __shared__ int red_i[4][5];
+    int tidx, h;
+    view_major_ids(gridDim.x, Hn, tidx, h);
+    const int ty = tidx / ntx, tx = tidx - ty * ntx;
     const int X0 = tx * T, Y0 = ty * T;
     const int X1 = min(W - 1, X0 + T - 1), Y1 = min(Hh - 1, Y0 + T - 1);
     const SVert* sv = sv_all + (size_t)h * V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tab[threadIdx.x] = tables[threadIdx.x];
+    tab[threadIdx.x + 256] = tables[threadIdx.x + 256];
+    if (threadIdx.x < T) ax[threadIdx.x] = ((double)(X0 + (int)threadIdx.x) - cx) / fx;
+    else if ((int)threadIdx.x < 2 * T) ay[threadIdx.x - T] = ((double)(Y0 + (int)threadIdx.x - T) - cy) / fy;
     for (int p = threadIdx.x; p < T * T; p += blockDim.x) tile[p] = ~0ull;
+    if (threadIdx.x == 0) { nhit_s = 0; total_s = 0; }
     __syncthreads();
     const int tbit = ty * 8 + tx;
-    const int lane = threadIdx.x & 63;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        if (!((cmask[(size_t)h * nchunk + chunk] >> tbit) & 1ull)) continue;   // workgroup-uniform
-        const int f = chunk * BIN_CHUNK + threadIdx.x;
-        bool mine = false, big = false;
-        TriSetup t;
-        int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
-        if (f < F) {
-            const unsigned box = tbox[(size_t)h * F + f];
+    const unsigned long long* cm = cmask + (size_t)h * nchunk;
+    const uint16_t* tb = tbox + (size_t)h * nchunk * BIN_CHUNK;
+    for (int base = 0; base < nchunk; base += HITS_ROUND) {
+        // ---- which of the next 1024 chunks touch this tile: coalesced mask reads, wave-compacted into the hit list
+#pragma unroll
+        for (int k = 0; k < HITS_ROUND / 256; ++k) {
+            const int c = base + k * 256 + (int)threadIdx.x;
+            const bool hit = c < nchunk && ((cm[c] >> tbit) & 1ull);
+            const unsigned long long bm = __ballot(hit);
+            if (bm) {                                                     // wave-uniform
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&nhit_s, __popcll(bm));
+                wbase = __shfl(wbase, 0, 64);
+                if (hit) hits[wbase + __popcll(bm & ((1ull << lane) - 1ull))] = c;
+            }
+        }
+        __syncthreads();
+        const int n = nhit_s;
+        // ---- every wave takes hit chunks on its own: one triangle per lane
+        for (int i = wave; i < n; i += 4) {
+            const int chunk = hits[i];
+            const int slot = chunk * BIN_CHUNK + lane;
+            bool mine = false, big = false;
+            TriSetup t;
+            int f = 0, x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+            const unsigned box = tb[slot];
             const int bx0 = box & 15, by0 = (box >> 4) & 15, bx1 = (box >> 8) & 15, by1 = (box >> 12) & 15;
-            if (bx0 <= tx && tx <= bx1 && by0 <= ty && ty <= by1) {
+            if (bx0 <= tx && tx <= bx1 && by0 <= ty && ty <= by1) {      // (TBOX_NONE overlaps nothing: covers slot >= F too)
+                f = perm[slot];
                 t = tri_setup(sv, faces, f, W, Hh);
                 x0 = max(t.bx0, X0); y0 = max(t.by0, Y0); x1 = min(t.bx1, X1); y1 = min(t.by1, Y1);
                 mine = t.ok && x0 <= x1 && y0 <= y1;
                 big = mine && ((x1 - x0 + 1) * (y1 - y0 + 1) > BIG_TILE_AREA || t.strad);   // straddlers always take the wave loop
             }
-        }
-        if (mine && !big)
-            for (int py = y0; py <= y1; ++py)
-                for (int px = x0; px <= x1; ++px) tile_pixel(t, f, px, py, tile, X0, Y0, T);
-        // triangles with many candidate pixels in this tile: the whole wave strides over them, one triangle at a time
-        unsigned long long bm = __ballot(big);
-        while (bm) {
-            const int src = __ffsll((long long)bm) - 1;
-            bm &= bm - 1;
-            const int fb = __shfl(f, src, 64);
-            const TriSetup tb = tri_setup(sv, faces, fb, W, Hh);
-            const int ax0 = max(tb.bx0, X0), ay0 = max(tb.by0, Y0), ax1 = min(tb.bx1, X1), ay1 = min(tb.by1, Y1);
-            const int bw = ax1 - ax0 + 1, n = bw * (ay1 - ay0 + 1);
-            if (tb.strad) {
-                const Strad sq = strad_setup(sv, faces, fb);
-                for (int i = lane; i < n; i += 64) strad_pixel_tile(sq, fb, ax0 + i % bw, ay0 + i / bw, tile, X0, Y0, T);
-                continue;
+            if (mine && !big)
+                for (int py = y0; py <= y1; ++py)
+                    for (int px = x0; px <= x1; ++px) tile_pixel(t, f, px, py, tile, X0, Y0, T);
+            // triangles with many candidate pixels in this tile: the whole wave strides over them, one triangle at a time
+            unsigned long long bm = __ballot(big);
+            while (bm) {
+                const int src = __ffsll((long long)bm) - 1;
+                bm &= bm - 1;
+                const int fb = __shfl(f, src, 64);
+                const TriSetup tbg = tri_setup(sv, faces, fb, W, Hh);
+                const int ax0 = max(tbg.bx0, X0), ay0 = max(tbg.by0, Y0), ax1 = min(tbg.bx1, X1), ay1 = min(tbg.by1, Y1);
+                const int bw = ax1 - ax0 + 1, np = bw * (ay1 - ay0 + 1);
+                if (tbg.strad) {
+                    const Strad sq = strad_setup(sv, faces, fb);
+                    for (int j = lane; j < np; j += 64) strad_pixel_tile(sq, fb, ax0 + j % bw, ay0 + j / bw, tile, X0, Y0, T);
+                    continue;
+                }
+                for (int j = lane; j < np; j += 64) tile_pixel(tbg, fb, ax0 + j % bw, ay0 + j / bw, tile, X0, Y0, T);
             }
-            for (int i = lane; i < n; i += 64) tile_pixel(tb, fb, ax0 + i % bw, ay0 + i / bw, tile, X0, Y0, T);
         }
+        __syncthreads();
+        if (threadIdx.x == 0) { total_s += n; nhit_s = 0; }
+        __syncthreads();
+    }
+    const int tw = X1 - X0 + 1, th = Y1 - Y0 + 1;
+    const bool touched = total_s > 0;                  // workgroup-uniform
+    ExtAcc e;
+    e.cnt = 0; e.xmin = 1 << 30; e.ymin = 1 << 30; e.xmax = -1; e.ymax = -1;
+    e.Xmin = 1e300; e.Xmax = -1e300; e.Ymin = 1e300; e.Ymax = -1e300;
+    if (touched) {
+        // ---- resolve: same arithmetic as raster_resolve_kernel; the result replaces the pixel's key in its own LDS slot
+        for (int p = threadIdx.x; p < tw * th; p += blockDim.x) {
+            const int ly = p / tw, lx = p - ly * tw;
+            const int px = X0 + lx, py = Y0 + ly;
+            float d;
+            uint8_t out[3];
+            resolve_pixel(sv, faces, sh, tab, tile[ly * T + lx], px, py, W, Hh, d, out);
+            tile[ly * T + lx] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)out[0] | ((unsigned)out[1] << 8) | ((unsigned)out[2] << 16);
+            if (d != 0.f) {   // fp_depth_extents: every non-zero depth joins the cloud, every positive one the mask
+                const double X = ax[lx] * (double)d, Y = ay[ly] * (double)d;
+                e.Xmin = fmin(e.Xmin, X); e.Xmax = fmax(e.Xmax, X); e.Ymin = fmin(e.Ymin, Y); e.Ymax = fmax(e.Ymax, Y);
+                if (d > 0.f) { ++e.cnt; e.xmin = min(e.xmin, px); e.xmax = max(e.xmax, px); e.ymin = min(e.ymin, py); e.ymax = max(e.ymax, py); }
+            }
+        }
+    } else {
+        for (int p = threadIdx.x; p < T * T; p += blockDim.x) tile[p] = 0ull;
     }
     __syncthreads();
-    // resolve the tile: same arithmetic as raster_resolve_kernel
-    const int tw = X1 - X0 + 1, th = Y1 - Y0 + 1;
-    for (int p = threadIdx.x; p < tw * th; p += blockDim.x) {
-        const int ly = p / tw, lx = p - ly * tw;
-        const int px = X0 + lx, py = Y0 + ly;
-        float d;
-        uint8_t out[3];
-        resolve_pixel(sv, faces, sh, tab, tile[ly * T + lx], px, py, W, Hh, d, out);
-        const size_t pix = (size_t)h * W * Hh + (size_t)py * W + px;
-        depth[pix] = d;
-        uint8_t* o = rgb + pix * 3;
-        o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+    // ---- flush: depth rows as floats; rgb rows as whole dwords (byte stores only for a row's unaligned ends)
+    if (depth) {
+        for (int p = threadIdx.x; p < tw * th; p += blockDim.x) {
+            const int ly = p / tw, lx = p - ly * tw;
+            depth[((size_t)h * Hh + Y0 + ly) * W + X0 + lx] = __uint_as_float((unsigned)(tile[ly * T + lx] >> 32));
+        }
     }
+    {
+        const int ndw = (tw * 3 + 3) / 4 + 1;                          // dwords that can hold a row's bytes at any alignment
+        for (int q = threadIdx.x; q < th * ndw; q += blockDim.x) {
+            const int ly = q / ndw, j = q - ly * ndw;
+            const size_t start = (((size_t)h * Hh + Y0 + ly) * W + X0) * 3;   // first byte of the tile row in the rgb buffer
+            const size_t a = (start & ~(size_t)3) + (size_t)j * 4;            // this thread's aligned dword
+            const long long o0 = (long long)a - (long long)start;              // row-relative offset of its first byte
+            if (o0 >= (long long)tw * 3) continue;
+            unsigned v = 0;
+            bool in[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long o = o0 + k;
+                in[k] = o >= 0 && o < (long long)tw * 3;
+                if (in[k]) {
+                    const int pix = (int)o / 3, ch = (int)o - pix * 3;
+                    v |= (unsigned)((tile[ly * T + pix] >> (8 * ch)) & 255ull) << (8 * k);
+                }
+            }
+            if (in[0] && in[3]) *(uint32_t*)(rgb + a) = v;
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (in[k]) rgb[a + k] = (uint8_t)(v >> (8 * k));
+            }
+        }
+    }
+    if (!part) return;
+    // ---- the tile's extents record
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        e.cnt += __shfl_xor(e.cnt, off, 64);
+        e.xmin = min(e.xmin, __shfl_xor(e.xmin, off, 64)); e.ymin = min(e.ymin, __shfl_xor(e.ymin, off, 64));
+        e.xmax = max(e.xmax, __shfl_xor(e.xmax, off, 64)); e.ymax = max(e.ymax, __shfl_xor(e.ymax, off, 64));
+        e.Xmin = fmin(e.Xmin, shfl_xor_f64(e.Xmin, off)); e.Xmax = fmax(e.Xmax, shfl_xor_f64(e.Xmax, off));
+        e.Ymin = fmin(e.Ymin, shfl_xor_f64(e.Ymin, off)); e.Ymax = fmax(e.Ymax, shfl_xor_f64(e.Ymax, off));
+    }
+    if (lane == 0) {
+        red_i[wave][0] = e.cnt; red_i[wave][1] = e.xmin; red_i[wave][2] = e.ymin; red_i[wave][3] = e.xmax; red_i[wave][4] = e.ymax;
+        red_d[wave][0] = e.Xmin; red_d[wave][1] = e.Xmax; red_d[wave][2] = e.Ymin; red_d[wave][3] = e.Ymax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            red_i[0][0] += red_i[w][0];
+            red_i[0][1] = min(red_i[0][1], red_i[w][1]); red_i[0][2] = min(red_i[0][2], red_i[w][2]);
+            red_i[0][3] = max(red_i[0][3], red_i[w][3]); red_i[0][4] = max(red_i[0][4], red_i[w][4]);
+            red_d[0][0] = fmin(red_d[0][0], red_d[w][0]); red_d[0][1] = fmax(red_d[0][1], red_d[w][1]);
+            red_d[0][2] = fmin(red_d[0][2], red_d[w][2]); red_d[0][3] = fmax(red_d[0][3], red_d[w][3]);
+        }
+        double* o = part + ((size_t)h * gridDim.x + tidx) * PART_N;
+        for (int k = 0; k < 5; ++k) o[k] = (double)red_i[0][k];
+        for (int k = 0; k < 4; ++k) o[5 + k] = red_d[0][k];
+    }
+}
+
+// folds the per-tile records of a view into fp_depth_extents' row (and the int32 box CropResizePad takes): same rule for views with
+// fewer than 100 mask pixels (renderer.py:116-117, template.py:75-77)
+__global__ void raster_extents_kernel(const double* __restrict__ part, int Hn, int ntile, int W, int Hh, double* __restrict__ ext,
+                                      int32_t* __restrict__ boxes) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= Hn) return;
+    int c = 0, bx0 = 1 << 30, by0 = 1 << 30, bx1 = -1, by1 = -1;
+    double Xmin = 1e300, Xmax = -1e300, Ymin = 1e300, Ymax = -1e300;
+    for (int t = 0; t < ntile; ++t) {
+        const double* p = part + ((size_t)v * ntile + t) * PART_N;
+        c += (int)p[0];
+        bx0 = min(bx0, (int)p[1]); by0 = min(by0, (int)p[2]); bx1 = max(bx1, (int)p[3]); by1 = max(by1, (int)p[4]);
+        Xmin = fmin(Xmin, p[5]); Xmax = fmax(Xmax, p[6]); Ymin = fmin(Ymin, p[7]); Ymax = fmax(Ymax, p[8]);
+    }
+    if (c < 100) {
+        const int lo = 105, hx = min(315, W) - 1, hy = min(315, Hh) - 1;
+        if (c == 0) { bx0 = lo; by0 = lo; bx1 = hx; by1 = hy; }
+        else { bx0 = min(bx0, lo); by0 = min(by0, lo); bx1 = max(bx1, hx); by1 = max(by1, hy); }
+    }
+    if (ext) {
+        double* o = ext + (size_t)v * 8;
+        o[0] = (double)bx0; o[1] = (double)by0; o[2] = (double)bx1; o[3] = (double)by1;
+        o[4] = Xmax > -1e299 ? Xmax - Xmin : 0.0;
+        o[5] = Ymax > -1e299 ? Ymax - Ymin : 0.0;
+        o[6] = (double)c; o[7] = 0.0;
+    }
+    if (boxes) { boxes[4 * v] = bx0; boxes[4 * v + 1] = by0; boxes[4 * v + 2] = bx1; boxes[4 * v + 3] = by1; }
+}
+
+// int32 boxes of an extents table (global-buffer path of fp_rasterize_extents)
+__global__ void ext_boxes_kernel(const double* __restrict__ ext, int Hn, int32_t* __restrict__ boxes) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= Hn) return;
+    for (int k = 0; k < 4; ++k) boxes[4 * v + k] = (int)ext[(size_t)v * 8 + k];
 }
 
 // vertex stage export (fp_project_vertices)
@@ -653,6 +837,33 @@ static int mesh_geometry(fp_ctx* ctx, const float* h_verts, int V, const int32_t
     FP_HIP(hipMalloc((void**)&m->faces, (size_t)F * 12));
     FP_HIP(hipMemcpy(m->verts, h_verts, (size_t)V * 12, hipMemcpyHostToDevice));
     FP_HIP(hipMemcpy(m->faces, h_faces, (size_t)F * 12, hipMemcpyHostToDevice));
+    {   // Morton order of the triangle centroids (10 bits per axis over the vertex bounding box), ties by face id
+        float lo[3] = {h_verts[0], h_verts[1], h_verts[2]}, hi[3] = {h_verts[0], h_verts[1], h_verts[2]};
+        for (int i = 0; i < V; ++i)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], h_verts[3 * i + a]); hi[a] = std::max(hi[a], h_verts[3 * i + a]); }
+        auto spread = [](uint32_t x) {   // 10 bits -> every third bit
+            x &= 0x3ffu; x = (x | (x << 16)) & 0x030000ffu; x = (x | (x << 8)) & 0x0300f00fu; x = (x | (x << 4)) & 0x030c30c3u; x = (x | (x << 2)) & 0x09249249u;
+            return x;
+        };
+        std::vector<std::pair<uint32_t, int32_t>> key((size_t)F);
+        for (int f = 0; f < F; ++f) {
+            uint32_t code = 0;
+            for (int a = 0; a < 3; ++a) {
+                const float c = (h_verts[3 * h_faces[3 * f] + a] + h_verts[3 * h_faces[3 * f + 1] + a] + h_verts[3 * h_faces[3 * f + 2] + a]) * (1.0f / 3.0f);
+                const float span = hi[a] - lo[a];
+                float u = span > 0.f ? (c - lo[a]) / span : 0.f;
+                if (!(u >= 0.f)) u = 0.f;                // (NaN vertices land in cell 0; they are dropped by the raster set-up anyway)
+                const uint32_t q = (uint32_t)std::min(1023.0f, u * 1024.0f);
+                code |= spread(q) << a;
+            }
+            key[f] = {code, f};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<int32_t> perm((size_t)F);
+        for (int f = 0; f < F; ++f) perm[f] = key[f].second;
+        FP_HIP(hipMalloc((void**)&m->perm, (size_t)F * 4));
+        FP_HIP(hipMemcpy(m->perm, perm.data(), (size_t)F * 4, hipMemcpyHostToDevice));
+    }
     int rc = mesh_tables(m);
     if (rc) return rc;
     *out = guard.release();
@@ -718,6 +929,7 @@ extern "C" int fp_mesh_destroy(fp_mesh* m) {
     if (!m) return FP_OK;
     if (m->verts) (void)hipFree(m->verts);
     if (m->faces) (void)hipFree(m->faces);
+    if (m->perm) (void)hipFree(m->perm);
     if (m->colors) (void)hipFree(m->colors);
     if (m->uv) (void)hipFree(m->uv);
     if (m->tex) (void)hipFree(m->tex);
@@ -754,12 +966,9 @@ extern "C" int fp_project_vertices(fp_ctx* ctx, const fp_mesh* mesh, const float
     return FP_OK;
 }
 
-extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx,
-                            float fy, float cx, float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, void* stream) {
-    FP_REQUIRE(ctx && mesh && d_poses && d_rgb && d_depth, "rasterize: null argument");
-    FP_REQUIRE(W > 0 && Hh > 0 && W <= 8192 && Hh <= 8192, "rasterize: bad image size");
-    if (Hn == 0) return FP_OK;
-    hipStream_t s = (hipStream_t)stream;
+// d_depth, d_ext, d_boxes: each may be null (at least rgb is always written)
+static int rasterize_impl(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx, float fy, float cx,
+                          float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, double* d_ext, int32_t* d_boxes, hipStream_t s) {
     const int V = mesh->V, F = mesh->F;
     SVert* sv;
     int rc;
@@ -767,28 +976,36 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
     hipLaunchKernelGGL(raster_vertex_kernel, dim3(cdiv(V, 256), Hn), dim3(256), 0, s, mesh->verts, V, d_poses, Hn, scale,
                        fx, fy, cx, cy, sv);
     FP_LAUNCH_CHECK();
+    const bool want_ext = d_ext || d_boxes;
 
     // tile edge: 64 px up to 512-px images, else the smallest multiple of 8 that covers the image with 8 x 8 tiles
     const int side = W > Hh ? W : Hh;
     const int T = side <= 512 ? 64 : (cdiv(side, 8) + 7) / 8 * 8;
-    // measured crossover (576 views, 420^2, profiles/r01_ab.md): tiled 1.7-2.2 ms vs 2.4-2.8 up to 20 k triangles, 2.8 vs 2.3 at
-    // 82 k, 7.6 vs 2.9 at 328 k — with ~1-pixel triangles set-up dominates and the tiled path does it twice (bin + tile).
-    // fp_ctx_set_option(ctx, "raster_tiled", v): -1 / unset = choose by triangle count, 0 = global visibility buffer, 1 = tiled
+    // fp_ctx_set_option(ctx, "raster_tiled", v): -1 / unset = tiled whenever the image fits 8 x 8 tiles of <= 88 px, 0 = global
+    // visibility buffer, 1 = tiled.  (Rounds 1-5 sent meshes above 32 768 triangles to the global buffer: the tile kernel of those
+    // rounds walked every chunk mask with a dependent scalar load; round 6's hit list + Morton-ordered chunks removed the reason.)
     const int mode = ctx->opt_raster_tiled;
-    const bool tiled = T <= 88 && (mode == 1 || (mode != 0 && F <= 32768));
+    const bool tiled = T <= 88 && mode != 0;
     if (tiled) {
-        const int ntx = cdiv(W, T), nty = cdiv(Hh, T), nchunk = cdiv(F, BIN_CHUNK);
+        const int ntx = cdiv(W, T), nty = cdiv(Hh, T), ntile = ntx * nty, nchunk = cdiv(F, BIN_CHUNK);
         uint16_t* tbox;
         unsigned long long* cmask;
-        if ((rc = ctx->get("raster.tbox", (size_t)Hn * F * 2, (void**)&tbox))) return rc;
+        double* part = nullptr;
+        if ((rc = ctx->get("raster.tbox", (size_t)Hn * nchunk * BIN_CHUNK * 2, (void**)&tbox))) return rc;
         if ((rc = ctx->get("raster.cmask", (size_t)Hn * nchunk * 8, (void**)&cmask))) return rc;
-        hipLaunchKernelGGL(raster_bin_kernel, dim3(nchunk, Hn), dim3(BIN_CHUNK), 0, s, sv, mesh->faces, V, F, W, Hh, T, tbox, cmask, mesh->cull);
+        if (want_ext && (rc = ctx->get("raster.part", (size_t)Hn * ntile * PART_N * 8, (void**)&part))) return rc;
+        hipLaunchKernelGGL(raster_bin_kernel, dim3(cdiv(nchunk, 4), Hn), dim3(256), 0, s, sv, mesh->faces, mesh->perm, V, F, W, Hh, T, Hn,
+                           nchunk, tbox, cmask, mesh->cull);
         FP_LAUNCH_CHECK();
-        const size_t lds = (size_t)T * T * 8 + 2048;   // visibility keys + DEC/THR tables
-        FP_DYN_LDS_ONCE(raster_tile_kernel, 88 * 88 * 8 + 2048);
-        hipLaunchKernelGGL(raster_tile_kernel, dim3(ntx * nty, Hn), dim3(256), lds, s, sv, mesh->faces, shade_args(mesh), mesh->tables,
-                           V, F, W, Hh, T, ntx, tbox, cmask, nchunk, d_rgb, d_depth);
+        const size_t lds = (size_t)T * T * 8 + 2048 + HITS_ROUND * 4 + (size_t)2 * T * 8;   // keys + DEC/THR tables + hit list + column / row factors
+        FP_DYN_LDS_ONCE(raster_tile_kernel, 88 * 88 * 8 + 2048 + HITS_ROUND * 4 + 2 * 88 * 8);
+        hipLaunchKernelGGL(raster_tile_kernel, dim3(ntile, Hn), dim3(256), lds, s, sv, mesh->faces, mesh->perm, shade_args(mesh), mesh->tables,
+                           V, F, W, Hh, T, ntx, Hn, tbox, cmask, nchunk, d_rgb, d_depth, part, (double)fx, (double)fy, (double)cx, (double)cy);
         FP_LAUNCH_CHECK();
+        if (want_ext) {
+            hipLaunchKernelGGL(raster_extents_kernel, dim3(cdiv(Hn, 64)), dim3(64), 0, s, part, Hn, ntile, W, Hh, d_ext, d_boxes);
+            FP_LAUNCH_CHECK();
+        }
         return FP_OK;
     }
 
@@ -796,6 +1013,7 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
     unsigned long long* zb;
     int* queue;
     const int qcap = 1 << 20;
+    if (!d_depth && (rc = ctx->get("raster.depth", (size_t)Hn * W * Hh * 4, (void**)&d_depth))) return rc;   // the extents are taken from it
     if ((rc = ctx->get("raster.zb", (size_t)Hn * W * Hh * 8, (void**)&zb))) return rc;
     if ((rc = ctx->get("raster.queue", (size_t)qcap * 8 + 64, (void**)&queue))) return rc;
     int* qcount = queue + 2 * qcap;
@@ -809,7 +1027,33 @@ extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_pos
     hipLaunchKernelGGL(raster_resolve_kernel, dim3(cdiv(W * Hh, 256), Hn), dim3(256), 0, s, sv, mesh->faces, shade_args(mesh),
                        mesh->tables, V, W, Hh, zb, d_rgb, d_depth);
     FP_LAUNCH_CHECK();
+    if (want_ext) {
+        double* ext = d_ext;
+        if (!ext && (rc = ctx->get("raster.ext", (size_t)Hn * 64, (void**)&ext))) return rc;
+        if ((rc = fp_depth_extents(ctx, d_depth, Hn, Hh, W, fx, fy, cx, cy, ext, s))) return rc;
+        if (d_boxes) {
+            hipLaunchKernelGGL(ext_boxes_kernel, dim3(cdiv(Hn, 64)), dim3(64), 0, s, ext, Hn, d_boxes);
+            FP_LAUNCH_CHECK();
+        }
+    }
     return FP_OK;
+}
+
+extern "C" int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx,
+                            float fy, float cx, float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, void* stream) {
+    FP_REQUIRE(ctx && mesh && d_poses && d_rgb && d_depth, "rasterize: null argument");
+    FP_REQUIRE(W > 0 && Hh > 0 && W <= 8192 && Hh <= 8192, "rasterize: bad image size");
+    if (Hn == 0) return FP_OK;
+    return rasterize_impl(ctx, mesh, d_poses, Hn, scale, fx, fy, cx, cy, W, Hh, d_rgb, d_depth, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int fp_rasterize_extents(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx,
+                                    float fy, float cx, float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, double* d_ext,
+                                    int32_t* d_boxes, void* stream) {
+    FP_REQUIRE(ctx && mesh && d_poses && d_rgb && (d_ext || d_boxes), "rasterize_extents: null argument");
+    FP_REQUIRE(W > 0 && Hh > 0 && W <= 8192 && Hh <= 8192, "rasterize_extents: bad image size");
+    if (Hn == 0) return FP_OK;
+    return rasterize_impl(ctx, mesh, d_poses, Hn, scale, fx, fy, cx, cy, W, Hh, d_rgb, d_depth, d_ext, d_boxes, (hipStream_t)stream);
 }
 
 extern "C" int fp_mesh_set_ambient(fp_mesh* mesh, float ambient) {

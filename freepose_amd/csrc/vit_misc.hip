@@ -73,7 +73,10 @@ __global__ void token_init_kernel(bf16_t* __restrict__ X, const bf16_t* __restri
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per output row. in_row = (r / rows_per_b) * in_stride_b + in_off + r % rows_per_b
-template <int MAXC>
+// L2 = 1: the row is written F.normalize()d (pose_estimator.py:85: the estimator normalises the template features it scores) — the
+// bf16-rounded LayerNorm outputs a lane holds ARE the canonical dot64 layout of l2norm_rows_kernel (lane l owns elements (c*64+l)*8+e),
+// so norm, rounding points and quotient are that kernel's, bit for bit, without a second pass over the features.
+template <int MAXC, int L2 = 0>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y,
                                                         const bf16_t* __restrict__ gamma,
                                                         const bf16_t* __restrict__ beta, int rows, int D,
@@ -112,6 +115,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
             }
         const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
         bf16_t* yr = Y + (size_t)r * D;
+        uint32_t keep[MAXC][4];
+        float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             const int ch = lane + 64 * c;
@@ -125,7 +130,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                     const float b = (v[c][2 * e + 1] - mean) * rstd * hi_bf(gw[e]) + hi_bf(bw[e]);
                     o[e] = pack_bf2(a, b);
                 }
-                *(uint4*)(yr + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+                if (L2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        keep[c][e] = o[e];
+                        const float lo = lo_bf(o[e]), hi = hi_bf(o[e]);
+                        acc = __fmaf_rn(lo, lo, acc);
+                        acc = __fmaf_rn(hi, hi, acc);
+                    }
+                } else {
+                    *(uint4*)(yr + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        if (L2) {
+            acc = wave_sum(acc);
+            const float n = fmaxf(rbf(fp_sqrt_rn(acc)), 1e-12f);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nch) {
+                    uint32_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(__fdiv_rn(lo_bf(keep[c][e]), n), __fdiv_rn(hi_bf(keep[c][e]), n));
+                    *(uint4*)(yr + ch * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
             }
         }
     }
@@ -183,52 +212,80 @@ __global__ void posembed_aa_kernel(const bf16_t* __restrict__ src, bf16_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// FFA descriptor. feats [B,P,D] bf16, mask u8 [B,Hm,Wm] (Hm = gh*cell, Wm = gw*cell) or patch mask
-// u8 [B,P] when cell == 1.  out [B,D] bf16.  Summation order is fixed (ascending patch index, one
-// fp32 accumulator per channel) so the oracle reproduces it bit for bit.
-__global__ __launch_bounds__(128) void ffa_kernel(const bf16_t* __restrict__ feats,
-                                                  const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
-                                                  float* __restrict__ out_f32, int P, int D, int gh, int gw,
-                                                  int cell) {
+// FFA descriptor. feats [B,P,D] bf16, mask u8 [B,Hm,Wm] (Hm = gh*cell, Wm = gw*cell) or patch mask u8 [B,P] when cell == 1;
+// out [B,D] bf16 = feat[mask].mean(0) (scripts/extract_retrieval_features.py:51-57).
+// Canonical summation order (round 6; the CPU checker restates it step for step): the P patches are cut into FFA_NB = 32
+// blocks of BL = ceil(P / 32) consecutive patch indices; within a block the masked rows are added in ascending patch order to an fp32
+// accumulator that starts at 0; the 32 block sums are then added in ascending block order, ((s0 + s1) + s2) + ...; divide by the mask
+// count, round to bf16.  (Rounds 1-5 used one accumulator over all P patches: a dependent chain of 1 369 additions that one crop —
+// the video query — paid 0.25 ms for.  torch's own order for the reference's mean is unspecified; the oracle is pinned to it to
+// 1 bf16 ulp either way.)
+//   ffa_cellmask_kernel : mask [Hm,Wm] -> patch mask [P] (any pixel of the cell x cell block: cv2.resize(INTER_AREA) > 0), one
+//                         workgroup per cell row, the row's `cell` mask lines staged in LDS by coalesced reads
+//   ffa_kernel          : one workgroup per (64-column slab, crop), thread (j, c2) sums block j of channel pair c2
+constexpr int FFA_NB = 32;
+
+__global__ __launch_bounds__(256) void ffa_cellmask_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ pm, int gh, int gw,
+                                                           int cell) {
+    extern __shared__ uint8_t rows[];   // [cell][Wm]
+    const int b = blockIdx.y, py = blockIdx.x, Wm = gw * cell;
+    const uint8_t* src = mask + ((size_t)b * gh * cell + (size_t)py * cell) * Wm;   // the cell row's lines are contiguous
+    for (int i = threadIdx.x; i < cell * Wm; i += blockDim.x) rows[i] = src[i];
+    __syncthreads();
+    for (int px = threadIdx.x; px < gw; px += blockDim.x) {
+        int any = 0;
+        for (int dy = 0; dy < cell; ++dy)
+            for (int dx = 0; dx < cell; ++dx) any |= rows[dy * Wm + px * cell + dx];
+        pm[(size_t)b * gh * gw + (size_t)py * gw + px] = any ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void ffa_kernel(const bf16_t* __restrict__ feats, const uint8_t* __restrict__ pmask,
+                                                   bf16_t* __restrict__ out, float* __restrict__ out_f32, int P, int D) {
     extern __shared__ uint8_t pm[];  // [P]
     __shared__ int cnt_s;
+    __shared__ float2 part[FFA_NB][32];
     const int b = blockIdx.y;
-    const int Wm = gw * cell;
     if (threadIdx.x == 0) cnt_s = 0;
     __syncthreads();
     int local = 0;
     for (int pidx = threadIdx.x; pidx < P; pidx += blockDim.x) {
-        const int py = pidx / gw, px = pidx % gw;
-        const uint8_t* mp = mask + (size_t)b * (gh * cell) * Wm + (size_t)(py * cell) * Wm + px * cell;
-        int any = 0;
-        for (int dy = 0; dy < cell; ++dy)
-            for (int dx = 0; dx < cell; ++dx) any |= mp[dy * Wm + dx];
-        pm[pidx] = any ? 1 : 0;
-        local += any ? 1 : 0;
+        const uint8_t m = pmask[(size_t)b * P + pidx] ? 1 : 0;
+        pm[pidx] = m;
+        local += m;
     }
-    atomicAdd(&cnt_s, local);
+    if (local) atomicAdd(&cnt_s, local);
     __syncthreads();
     const int cnt = cnt_s;
-    const int c2 = blockIdx.x * blockDim.x + threadIdx.x;  // pair of channels
-    if (c2 * 2 >= D) return;
-    const uint32_t* fp = (const uint32_t*)(feats + (size_t)b * P * D) + c2;
+    const int c2l = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int c2 = blockIdx.x * 32 + c2l;              // pair of channels
+    const bool live = c2 * 2 < D;
+    const int BL = (P + FFA_NB - 1) / FFA_NB;
+    const int p_lo = j * BL, p_hi = min(P, p_lo + BL);
     float a0 = 0.f, a1 = 0.f;
-    // the additions keep their order (ascending patch index, the oracle's); the loads do not wait for the mask test, so
-    // FFA_UNR rows are in flight per thread instead of one (a single crop has only D/2 threads to hide latency with)
-    constexpr int FFA_UNR = 16;
-    for (int p0 = 0; p0 < P; p0 += FFA_UNR) {
-        uint32_t w[FFA_UNR];
+    if (live) {
+        const uint32_t* fp = (const uint32_t*)(feats + (size_t)b * P * D) + c2;
+        // the additions keep their order; the loads do not wait for the mask test, so FFA_UNR rows are in flight per thread
+        constexpr int FFA_UNR = 16;
+        for (int p0 = p_lo; p0 < p_hi; p0 += FFA_UNR) {
+            uint32_t w[FFA_UNR];
 #pragma unroll
-        for (int u = 0; u < FFA_UNR; ++u) w[u] = (p0 + u < P) ? fp[(size_t)(p0 + u) * (D / 2)] : 0u;
+            for (int u = 0; u < FFA_UNR; ++u) w[u] = (p0 + u < p_hi) ? fp[(size_t)(p0 + u) * (D / 2)] : 0u;
 #pragma unroll
-        for (int u = 0; u < FFA_UNR; ++u)
-            if (p0 + u < P && pm[p0 + u]) {
-                a0 += lo_bf(w[u]);
-                a1 += hi_bf(w[u]);
-            }
+            for (int u = 0; u < FFA_UNR; ++u)
+                if (p0 + u < p_hi && pm[p0 + u]) {
+                    a0 += lo_bf(w[u]);
+                    a1 += hi_bf(w[u]);
+                }
+        }
     }
+    part[j][c2l] = make_float2(a0, a1);
+    __syncthreads();
+    if (j != 0 || !live) return;
+    float2 t = part[0][c2l];
+    for (int k = 1; k < FFA_NB; ++k) { t.x += part[k][c2l].x; t.y += part[k][c2l].y; }
     // mean of a bf16 tensor: fp32 accumulate, divide, round to bf16 (0/0 -> NaN like the reference)
-    const float m0 = a0 / (float)cnt, m1 = a1 / (float)cnt;
+    const float m0 = t.x / (float)cnt, m1 = t.y / (float)cnt;
     if (out) ((uint32_t*)(out + (size_t)b * D))[c2] = pack_bf2(m0, m1);
     if (out_f32) { out_f32[(size_t)b * D + 2 * c2] = rbf(m0); out_f32[(size_t)b * D + 2 * c2 + 1] = rbf(m1); }
 }
@@ -440,19 +497,15 @@ int fp_token_init(bf16_t* X, const bf16_t* cls, const bf16_t* pos0, const bf16_t
 }
 
 int fp_layernorm(const bf16_t* X, bf16_t* Y, const bf16_t* gamma, const bf16_t* beta, int rows, int D, float eps,
-                 int rows_per_b, int in_stride_b, int in_off, hipStream_t s) {
+                 int rows_per_b, int in_stride_b, int in_off, hipStream_t s, int l2_normalize) {
     FP_REQUIRE(D % 8 == 0 && D <= 8 * 64 * 3, "layernorm: D=%d unsupported", D);
     if (rows_per_b <= 0) { rows_per_b = rows; in_stride_b = 0; in_off = 0; }
     const int blocks = std::min(cdiv(rows, 4), 256 * 8);
-    if (D <= 512)
-        hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, s, X, Y, gamma, beta, rows, D, eps,
-                           rows_per_b, in_stride_b, in_off);
-    else if (D <= 1024)
-        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, s, X, Y, gamma, beta, rows, D, eps,
-                           rows_per_b, in_stride_b, in_off);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, s, X, Y, gamma, beta, rows, D, eps,
-                           rows_per_b, in_stride_b, in_off);
+#define FP_LN(C, L) hipLaunchKernelGGL((layernorm_kernel<C, L>), dim3(blocks), dim3(256), 0, s, X, Y, gamma, beta, rows, D, eps, rows_per_b, in_stride_b, in_off)
+    if (D <= 512) { if (l2_normalize) FP_LN(1, 1); else FP_LN(1, 0); }
+    else if (D <= 1024) { if (l2_normalize) FP_LN(2, 1); else FP_LN(2, 0); }
+    else { if (l2_normalize) FP_LN(3, 1); else FP_LN(3, 0); }
+#undef FP_LN
     FP_LAUNCH_CHECK();
     return FP_OK;
 }
@@ -466,10 +519,17 @@ int fp_posembed_aa(const bf16_t* src, bf16_t* dst, int G, int gh, int gw, int D,
 }
 
 int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* out_f32, int B, int P, int D, int gh,
-                int gw, int cell, hipStream_t s) {
+                int gw, int cell, uint8_t* pm_scratch, hipStream_t s) {
     FP_REQUIRE(gh * gw == P && D % 2 == 0 && cell >= 1, "ffa: bad shape P=%d gh=%d gw=%d", P, gh, gw);
-    hipLaunchKernelGGL(ffa_kernel, dim3(cdiv(D / 2, 128), B), dim3(128), P, s, feats, mask, out, out_f32, P, D, gh, gw,
-                       cell);
+    FP_REQUIRE(P <= 60000 && cell * cell * gw <= 60000, "ffa: P=%d cell=%d too large for the LDS staging", P, cell);
+    const uint8_t* pm = mask;
+    if (cell > 1) {
+        FP_REQUIRE(pm_scratch, "ffa: no patch-mask scratch");
+        hipLaunchKernelGGL(ffa_cellmask_kernel, dim3(gh, B), dim3(256), (size_t)cell * cell * gw, s, mask, pm_scratch, gh, gw, cell);
+        FP_LAUNCH_CHECK();
+        pm = pm_scratch;
+    }
+    hipLaunchKernelGGL(ffa_kernel, dim3(cdiv(D, 64), B), dim3(1024), P, s, feats, pm, out, out_f32, P, D);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -60,7 +60,9 @@ VIT_ARCHS = {
     # interpolate_offset=0.1 and are not used by the reference (dino.py:8, tracking_refiner.py:23).
     "dinov2_vits14_reg": (384, 12, 6, 4), "dinov2_vitb14_reg": (768, 12, 12, 4), "dinov2_vitl14_reg": (1024, 24, 16, 4),
 }
-FEATURE_TYPES = {"cls": 0, "reg": 1, "patch": 2}
+# "patch_normalized": patch features with every row F.normalize()d by the final-norm kernel itself (== l2_normalize(patch features), bit
+# for bit) — what the estimators score hypotheses with (pose_estimator.py:85-88): no separate normalisation pass over 1.6 GB
+FEATURE_TYPES = {"cls": 0, "reg": 1, "patch": 2, "patch_normalized": 3}
 
 
 class ViT:
@@ -102,7 +104,7 @@ class ViT:
         assert Cc == 3
         P = (H // self.patch) * (W // self.patch)
         ft = FEATURE_TYPES[feature_type]
-        shape = {0: (B, self.dim), 1: (B, self.n_reg, self.dim), 2: (B, P, self.dim)}[ft]
+        shape = {0: (B, self.dim), 1: (B, self.n_reg, self.dim), 2: (B, P, self.dim), 3: (B, P, self.dim)}[ft]
         if out is None:
             out = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
         else:
@@ -398,6 +400,24 @@ def rasterize(mesh: Mesh, poses: torch.Tensor, scale: float, fx: float, fy: floa
         check(lib.fp_rasterize(context(), mesh.handle, ptr(p), Hn, float(scale), float(fx), float(fy), float(cx), float(cy),
                                int(W), int(H), ptr(rgb), ptr(depth), current_stream()), "fp_rasterize")
     return rgb, depth
+
+
+def rasterize_extents(mesh: Mesh, poses: torch.Tensor, scale: float, fx: float, fy: float, cx: float, cy: float, W: int, H: int,
+                      want_depth: bool = False):
+    """rasterize() with the depth image's consumers fused into the tile epilogue: returns (rgb u8 [Hn,H,W,3], depth f32 [Hn,H,W] or
+    None, ext f64 [Hn,8] == depth_extents(depth), boxes i32 [Hn,4] == ext[:, :4]).  Without `want_depth` the depth image is never
+    written (the pose hot path needs only the extents)."""
+    lib = _lib.load()
+    p = _dev(torch.as_tensor(poses), torch.float32)
+    Hn = p.shape[0]
+    rgb = torch.empty((Hn, H, W, 3), dtype=torch.uint8, device=p.device)
+    depth = torch.empty((Hn, H, W), dtype=torch.float32, device=p.device) if want_depth else None
+    ext = torch.empty((Hn, 8), dtype=torch.float64, device=p.device)
+    boxes = torch.empty((Hn, 4), dtype=torch.int32, device=p.device)
+    if Hn:
+        check(lib.fp_rasterize_extents(context(), mesh.handle, ptr(p), Hn, float(scale), float(fx), float(fy), float(cx), float(cy),
+                                       int(W), int(H), ptr(rgb), ptr(depth), ptr(ext), ptr(boxes), current_stream()), "fp_rasterize_extents")
+    return rgb, depth, ext, boxes
 
 
 def project_vertices(mesh: Mesh, poses: torch.Tensor, scale: float, fx: float, fy: float, cx: float, cy: float):

@@ -102,23 +102,24 @@ class HotPath:
         return feats, s, i
 
     def render_hypotheses(self):
+        # the depth image is never written: its two consumers (depth>0 box, cloud extents) are reduced in the rasteriser's tile epilogue
         with self.clock.stage("rasterize"):
-            rgb, depth = ops.rasterize(self.mesh, self._poses_dev, self.render_scale, self.fx, self.fy, self.cx, self.cy,
-                                       self.render_res, self.render_res)
-        with self.clock.stage("depth_extents"):
-            ext = ops.depth_extents(depth, self.fx, self.fy, self.cx, self.cy)
+            rgb, _, ext, boxes = ops.rasterize_extents(self.mesh, self._poses_dev, self.render_scale, self.fx, self.fy, self.cx, self.cy,
+                                                       self.render_res, self.render_res)
         with self.clock.stage("crop_resize"):
-            crops = ops.crop_resize_pad(rgb, ext[:, :4].to(torch.int32), self.crop_res, 0.0, out_bf16=True)
+            crops = ops.crop_resize_pad(rgb, boxes, self.crop_res, 0.0, out_bf16=True)
         return crops, ext
 
-    def hypothesis_features(self, crops: torch.Tensor) -> torch.Tensor:
+    def hypothesis_features(self, crops: torch.Tensor, normalized: bool = False) -> torch.Tensor:
+        """patch features of the hypothesis crops; `normalized`: rows F.normalize()d by the ViT's final-norm kernel (what run() scores
+        with: the streaming template_dots_normed kernel then reads them once, same bits as normalising on the fly)"""
         g = self.crop_res // 14
         sizes = ops.plan_vit_batches(crops.shape[0], g * g + 5, self.vit_batch)   # whole GEMM tile rounds per batch
         with self.clock.stage("vit_hypotheses"):
             feats = torch.empty((crops.shape[0], g * g, self.vit.dim), dtype=torch.bfloat16, device=crops.device)
             i = 0
             for b in sizes:      # each chunk writes its slice of the result: no concatenation pass (1.6 GB for 576 crops)
-                self.vit(crops[i:i + b], layer=self.layer, feature_type="patch", out=feats[i:i + b])
+                self.vit(crops[i:i + b], layer=self.layer, feature_type="patch_normalized" if normalized else "patch", out=feats[i:i + b])
                 i += b
             return feats
 
@@ -128,10 +129,10 @@ class HotPath:
         out = []
         for b in range(crops.shape[0]):
             hyp_crops, ext = self.render_hypotheses()          # the retrieved mesh under all hypotheses
-            hyp_feats = self.hypothesis_features(hyp_crops)
+            hyp_feats = self.hypothesis_features(hyp_crops, normalized=True)
             with self.clock.stage("template_score"):
                 q = ops.l2_normalize(feats[b])
-                scores = ops.template_score(hyp_feats, q)
+                scores = ops.template_score(hyp_feats, q, normalized=True)
             with self.clock.stage("hypothesis_top3"):
                 idx_all = torch.arange(self.n_hyp, dtype=torch.int32, device=scores.device)
                 s3, i3 = ops.topk_merge(scores[None], idx_all[None], 3)

@@ -65,7 +65,10 @@ int fp_vit_destroy(fp_vit* vit);
  * d_bf16 is a device pointer to the bf16 tensor in its native layout; the caller keeps it alive.
  * patch_embed.proj.weight is copied into a K-padded private buffer. */
 int fp_vit_set_weight(fp_vit* vit, const char* name, const void* d_bf16, size_t numel, void* stream);
-/* feature_type: 0 = cls [B,dim], 1 = reg [B,n_reg,dim], 2 = patch [B,P,dim]  (dino.py:25-30).
+/* feature_type: 0 = cls [B,dim], 1 = reg [B,n_reg,dim], 2 = patch [B,P,dim]  (dino.py:25-30);
+ * 3 = patch features with every row F.normalize()d — what the estimators score (pose_estimator.py:85-88,
+ * online_pose_estimator.py:72-76 normalise the template / hypothesis features right after this call): the bits of
+ * fp_l2_normalize(feature_type 2), written by the final-norm kernel itself.
  * d_images: bf16 [B,3,H,W] in [0,1] (ImageNet normalisation is fused, dino.py:12,16);
  * runs blocks 0..layer-1 (all blocks if layer > depth, dino.py:18-21) then the final norm. */
 int fp_vit_forward(fp_vit* vit, const void* d_images, int B, int H, int W, int layer, int feature_type,
@@ -180,6 +183,14 @@ int fp_project_vertices(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, 
  * (metric eye depth, 0 = background).  Ambient-only shading, no culling (renderer.py:53-55,66). */
 int fp_rasterize(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx, float fy,
                  float cx, float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, void* stream);
+/* fp_rasterize with the consumers of the depth image fused into the tile epilogue (renderer.py:98-130 takes the
+ * depth>0 bounding box of every render, pose_estimator.py:104-112 the cloud extents of the winners): d_ext f64 [Hn,8] = exactly what
+ * fp_depth_extents gives on the depth image, d_boxes i32 [Hn,4] = its first four columns as CropResizePad takes them.  d_depth,
+ * d_ext, d_boxes may each be NULL (not d_ext and d_boxes both): without d_depth the 4 bytes per pixel are neither written nor read
+ * back.  Same bits as fp_rasterize + fp_depth_extents. */
+int fp_rasterize_extents(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses, int Hn, float scale, float fx, float fy,
+                         float cx, float cy, int W, int Hh, uint8_t* d_rgb, float* d_depth, double* d_ext, int32_t* d_boxes,
+                         void* stream);
 /* a9/K17: per view, bbox of depth>0 (with the <100 px fallback square) and metric extents of the
  * back-projected cloud (float64 like utils.py:122-145): out f64 [Hn,8] = {xmin,ymin,xmax,ymax (px), dx, dy (m),
  * count, 0}. */

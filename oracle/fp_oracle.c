@@ -125,14 +125,18 @@ void fpo_topk_merge(const float* cs, const int32_t* ci, int C, int k, float* out
 }
 
 /* FFA (scripts/extract_retrieval_features.py:51-57; extract_proposals_ground.py:129-134):
- * mask -> cv2.resize(INTER_AREA) > 0 == any pixel of the cell x cell block; feat[mask].mean(0) in bf16
- * (fp32 accumulate in ascending patch order, divide, round). out_bf may be NULL; out_f32 gets the bf16
- * value widened (the .float() of :57). */
+ * mask -> cv2.resize(INTER_AREA) > 0 == any pixel of the cell x cell block; feat[mask].mean(0) in bf16: fp32 accumulate, divide,
+ * round.  torch leaves the order of that sum unspecified; the canonical order (round 6, shared with csrc/vit_misc.hip ffa_kernel) is
+ * BLOCKED: the P patches are cut into 32 blocks of BL = ceil(P / 32) consecutive patch indices, the masked rows of a block are added
+ * in ascending patch order to an accumulator that starts at 0, the 32 block sums are added in ascending block order
+ * (((s0 + s1) + s2) + ...).  out_bf may be NULL; out_f32 gets the bf16 value widened (the .float() of :57). */
+#define FPO_FFA_NB 32
 void fpo_ffa(const bf16* feats, const uint8_t* mask, int B, int gh, int gw, int D, int cell, bf16* out_bf,
              float* out_f32) {
     const int P = gh * gw, Wm = gw * cell;
     uint8_t* pm = (uint8_t*)malloc(P);
     float* acc = (float*)malloc((size_t)D * 4);
+    float* blk = (float*)malloc((size_t)D * 4);
     for (int b = 0; b < B; ++b) {
         int cnt = 0;
         for (int p = 0; p < P; ++p) {
@@ -144,17 +148,23 @@ void fpo_ffa(const bf16* feats, const uint8_t* mask, int B, int gh, int gw, int 
             pm[p] = any ? 1 : 0;
             cnt += pm[p];
         }
-        for (int d = 0; d < D; ++d) acc[d] = 0.f;
-        for (int p = 0; p < P; ++p)
-            if (pm[p])
-                for (int d = 0; d < D; ++d) acc[d] += bf2f(feats[((size_t)b * P + p) * D + d]);
+        const int BL = (P + FPO_FFA_NB - 1) / FPO_FFA_NB;
+        for (int j = 0; j < FPO_FFA_NB; ++j) {
+            const int p_lo = j * BL, p_hi = (p_lo + BL < P) ? p_lo + BL : P;
+            for (int d = 0; d < D; ++d) blk[d] = 0.f;
+            for (int p = p_lo; p < p_hi; ++p)
+                if (pm[p])
+                    for (int d = 0; d < D; ++d) blk[d] += bf2f(feats[((size_t)b * P + p) * D + d]);
+            if (j == 0) for (int d = 0; d < D; ++d) acc[d] = blk[d];
+            else for (int d = 0; d < D; ++d) acc[d] += blk[d];
+        }
         for (int d = 0; d < D; ++d) {
             const float m = acc[d] / (float)cnt;
             if (out_bf) out_bf[(size_t)b * D + d] = f2bf(m);
             if (out_f32) out_f32[(size_t)b * D + d] = rbf(m);
         }
     }
-    free(pm); free(acc);
+    free(pm); free(acc); free(blk);
 }
 
 /* patchwise template score (src/pipeline/estimators/pose_estimator.py:85-88; online_pose_estimator.py:68-79):

@@ -310,8 +310,21 @@ def test_fuzz_rasterizer_and_extents(case):
             ops.set_option("raster_tiled", -1)
         assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32)), (tiled, nv, nf, n, W, H, fx, scale)
         assert np.array_equal(rgb_g.cpu().numpy(), rgb_o), (tiled, nv, nf, n, W, H, fx, scale)
+    ext_o = fo.depth_extents(d_o, fx, fx, W / 2, H / 2)
     ext_g = ops.depth_extents(d_g, fx, fx, W / 2, H / 2).cpu().numpy()
-    assert np.array_equal(ext_g, fo.depth_extents(d_o, fx, fx, W / 2, H / 2)), (nv, nf, n, W, H)
+    assert np.array_equal(ext_g, ext_o), (nv, nf, n, W, H)
+    # the fused form (round 6): extents and boxes from the tile epilogue, with and without the depth image, both strategies
+    for tiled in (1, 0):
+        for want_depth in (False, True):
+            ops.set_option("raster_tiled", tiled)
+            try:
+                rgb_f, d_f, ext_f, box_f = ops.rasterize_extents(mesh, torch.from_numpy(poses), scale, fx, fx, W / 2, H / 2, W, H, want_depth=want_depth)
+            finally:
+                ops.set_option("raster_tiled", -1)
+            assert np.array_equal(rgb_f.cpu().numpy(), rgb_o) and np.array_equal(ext_f.cpu().numpy(), ext_o), (tiled, want_depth, nv, nf, n, W, H)
+            assert np.array_equal(box_f.cpu().numpy(), ext_o[:, :4].astype(np.int32)) and (d_f is None) == (not want_depth)
+            if want_depth:
+                assert np.array_equal(d_f.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
 
 
 @pytest.mark.parametrize("case", range(max(1, ITERS // 3)))

@@ -63,8 +63,20 @@ def _rot(axis, deg):
 
 
 def _oracle_feats(sd, crops_f32, dtype, batch=8):
-    from tests._oracle_pool import oracle_feats      # 16 torch threads per process (the fastest count on the pool's 256-thread hosts), several processes
-    return oracle_feats(sd, crops_f32, LAYER, dtype, batch)
+    from oracle import vit_ref
+    out = []
+    nthr = torch.get_num_threads()
+    # 16 threads: the fastest count on the pool's hosts (bench.py's cpu_baseline probe).  More threads are slower, and so are several
+    # pinned 16-thread worker processes (measured in round 6: 0.38 s per crop with one worker, 0.53 s per crop and worker with eight —
+    # the box's CPU quota, not its 256 logical CPUs, sets the rate), so the oracle runs in this process.
+    torch.set_num_threads(min(16, nthr))
+    try:
+        with torch.inference_mode():
+            for i in range(0, crops_f32.shape[0], batch):
+                out.append(vit_ref.vit_forward(sd, crops_f32[i:i + batch], layer=LAYER, feature_type="patch", dtype=dtype).to(torch.bfloat16))
+    finally:
+        torch.set_num_threads(nthr)
+    return torch.cat(out)
 
 
 def test_pose_parity_vit_in_the_loop(capsys):

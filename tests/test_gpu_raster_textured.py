@@ -114,6 +114,34 @@ def test_textured_dense_mesh_and_repeat_wrap_bit_exact():
         ops.set_option("raster_tiled", -1)
 
 
+def test_dense_mesh_any_face_order_on_the_tiled_path():
+    """81 920 triangles (the bench's mesh size; rounds 1-5 sent anything above 32 768 to the global atomics buffer) with the faces in
+    RANDOM order: the tiled strategy (Morton-ordered 64-triangle chunks, LDS hit lists) is the default one at any triangle count and
+    gives the oracle's bits; so do the extents / boxes of the fused epilogue; and the face order does not matter (ids ride in the key)"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    import bench
+    v, f, col = bench.synthetic_mesh(6)
+    assert len(f) == 81920
+    rng = np.random.default_rng(5)
+    f = np.ascontiguousarray(f[rng.permutation(len(f))]).astype(np.int32)
+    poses = _poses(3)
+    poses[1, :3, 3] = [0.05, -0.02, 0.6]
+    rgb_o, d_o = fo.rasterize(v, f, col, poses, 0.25, 600, 600, 210, 210, 420, 420)
+    ext_o = fo.depth_extents(d_o, 600, 600, 210, 210)
+    mesh = ops.Mesh(v, f, col)
+    rgb_g, d_g = ops.rasterize(mesh, torch.from_numpy(poses), 0.25, 600, 600, 210, 210, 420, 420)          # default strategy
+    assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32)) and np.array_equal(rgb_g.cpu().numpy(), rgb_o)
+    try:
+        for mode in (1, 0):
+            ops.set_option("raster_tiled", mode)
+            rgb_f, d_f, ext_f, box_f = ops.rasterize_extents(mesh, torch.from_numpy(poses), 0.25, 600, 600, 210, 210, 420, 420, want_depth=bool(mode))
+            assert np.array_equal(rgb_f.cpu().numpy(), rgb_o) and np.array_equal(ext_f.cpu().numpy(), ext_o)
+            assert np.array_equal(box_f.cpu().numpy(), ext_o[:, :4].astype(np.int32))
+    finally:
+        ops.set_option("raster_tiled", -1)
+
+
 def test_texel_pattern_known_answer_on_device():
     """same construction as the oracle's CPU known-answer test: texel centres land on pixel centres -> exact texels"""
     from freepose_amd import ops

@@ -154,3 +154,18 @@ def test_checkpoint_path_hub_layout_fp32_pth(tmp_path, monkeypatch):
         DINOv2FeatureExtractor(name)
     with pytest.warns(RuntimeWarning):
         DINOv2FeatureExtractor(name, allow_random_weights=True)
+
+
+@pytest.mark.parametrize("model,H,B", [("dinov2_vits14_reg", 224, 3), ("dinov2_vitl14_reg", 518, 2), ("dinov2_vitb14_reg", 420, 1)])
+def test_patch_normalized_equals_normalizing_the_patch_features(model, H, B):
+    """feature_type 'patch_normalized' (round 6): the final-norm kernel writes F.normalize()d rows itself (pose_estimator.py:85-88
+    normalises the hypothesis features right after the ViT) — the bits of fp_l2_normalize on the plain patch features, and scoring with
+    the streaming kernel gives the on-the-fly kernel's bits"""
+    from freepose_amd import ops
+    vit = ops.ViT(model, ops.random_state_dict(model, seed=6))
+    img = _images(B, H, 9)
+    plain = vit(img, layer=22, feature_type="patch")
+    fused = vit(img, layer=22, feature_type="patch_normalized")
+    assert torch.equal(fused.view(torch.int16), ops.l2_normalize(plain).view(torch.int16))
+    q = ops.l2_normalize(plain[0])
+    assert torch.equal(ops.template_score(fused, q, normalized=True), ops.template_score(plain, q))

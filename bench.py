@@ -123,6 +123,12 @@ def cpu_baseline(args, mesh_arrays, bank_f32):
         if dtp < best[0]:
             best = (dtp, nt)
     ncores = best[1]
+    # SURVEY 8(d) asks for torch.set_num_threads(os.cpu_count()): reported beside the fastest count (one warm-up, one timed forward)
+    all_cores = None
+    if avail != ncores:
+        torch.set_num_threads(avail)
+        t_all = _median_time(lambda: vit_ref.vit_forward(sd_bf, x, layer=22, feature_type="patch", dtype=torch.bfloat16), 1, 1)
+        all_cores = {"cores": avail, "vit_per_crop_bf16": t_all}
     torch.set_num_threads(ncores)
     feats = [None]
 
@@ -155,6 +161,8 @@ def cpu_baseline(args, mesh_arrays, bank_f32):
                       f"{args.hyp} hypotheses; thread count = the fastest of 8/16/32/64/128 on a 6-block 224^2 probe, "
                       f"{avail} logical CPUs available",
             "seconds_per_proposal": per_prop, "value_bf16": 1.0 / per_prop_bf16, "seconds_per_proposal_bf16": per_prop_bf16,
+            "all_cores": None if all_cores is None else dict(all_cores, value_bf16=1.0 / ((1 + args.hyp) * all_cores["vit_per_crop_bf16"] + t_scan + t_score + t_raster),
+                                                             note="torch.set_num_threads(all logical CPUs): slower than the chosen count on this host; the other stages as above"),
             "stage_seconds": {"vit_per_crop_fp32": t_vit, "vit_per_crop_bf16": t_vit_bf16, "bank_scan_topk": t_scan,
                               "template_score": t_score, "raster": t_raster}}
 
@@ -642,6 +650,9 @@ def main():
 
     # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) and exit with their status
     parallel.self_launch(args.gpus, [str(Path(__file__).resolve())], sys.argv[1:])
+    # stdout carries EXACTLY one line, the JSON result of rank 0: whatever the legs print on the way (the CLI mains report their
+    # progress with print()) goes to stderr
+    result_stream, sys.stdout = sys.stdout, sys.stderr
     # FP_DIST_BACKEND=gloo lets several ranks share one GPU (flow test on a single-GPU box); the default is RCCL ("nccl")
     rank, world, local = parallel.init_from_env(os.environ.get("FP_DIST_BACKEND", "nccl"))
     if world != args.gpus:
@@ -723,7 +734,10 @@ def main():
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": _pmc_traffic()[0], "traffic_source": _pmc_traffic()[1], "csrc_sha16": csrc_hash(), "launches": prof["gemm_launches"],
                          "avg_launch_ms": prof["ms_gemm"] / max(prof["gemm_launches"], 1),
-                         "flops_per_launch": prof["gemm_flops"] / max(prof["gemm_launches"], 1)},
+                         "flops_per_launch": prof["gemm_flops"] / max(prof["gemm_launches"], 1),
+                         # the second MFMA-bound kernel of the step (attn_fwd_kernel, ~19 % of it): same definition — algorithmic
+                         # 4 n^2 D flops per block and crop over its HIP-event time on the launch stream
+                         "attention": _attention_roofline(args, prof, B * args.steps)},
             "stage_ms_rank0": {"vit_gemm": prof["ms_gemm"] / args.steps, "vit_attention": prof["ms_attn"] / args.steps,
                                "vit_other": prof["ms_other"] / args.steps},
             "vit_tflops_end_to_end": flops_vit / dt / 1e12,
@@ -735,10 +749,20 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, (mv, mf, mc), bank_f32)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_stream, flush=True)
+    sys.stdout = result_stream
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _attention_roofline(args, prof, n_prop):
+    g = args.res // 14
+    n_tok, crops = g * g + 5, (1 + args.hyp) * n_prop
+    fl = 22 * 4.0 * n_tok * n_tok * 1024 * crops
+    ach = fl / max(prof["ms_attn"], 1e-9) / 1e9
+    return {"bound": "mfma", "kernel": "attn_fwd_kernel (softmax(QK^T/8)V, 16 heads x 64)", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "ms": prof["ms_attn"], "flops": fl}
 
 
 def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
@@ -770,14 +794,15 @@ def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
         note = "LayerNorm read+write per call, im2col, token init"
     add("vit_layernorm_etc", prof["ms_other"], "hbm", other_bytes, note)
     add("ffa", stage_ms.get("ffa", 0), "hbm", P * D * 2.0 * n_prop,
-        "P*D*2 bytes per crop; one crop per call here = 512 threads summing in the oracle's fixed order: latency-bound")
+        "P*D*2 bytes per crop; cell-mask pooling + blocked masked mean (32 patch blocks x 16 column slabs per crop) + normalise: three small launches, latency-bound at one crop")
     add("bank_scan_topk", stage_ms.get("bank_scan_topk", 0), "hbm", args.bank * D * 2.0 * args.steps,
         f"one pass over the bf16 bank per step, shared by its Q = {args.proposals_per_step} queries; the stage is scan + exact "
         "top-100 select + merge (single-query select ~17 us, latency-bound); the scan kernel alone, measured with the bank evicted / "
         "resident: profiles/r03_scan_cold_warm.log (18.2 us = 5.2 TB/s after a clean 1 GiB read sweep, 15.7 us = 6.0 TB/s resident in the "
         "Infinity Cache; in this pipeline, behind the ViT's dirty activations: see the bank_scan_kernel row of profiles/r04_bench_kernel_stats.csv)")
-    add("rasterize", stage_ms.get("rasterize", 0), "hbm", (H * 420 * 420 * 7.0 + n_vert * 32.0 + n_tri * 12.0) * n_prop,
-        f"mandatory rgb+depth writes; {H * n_tri * n_prop / max(stage_ms.get('rasterize', 1e9), 1e-9) / 1e6:.1f} G triangle set-ups/s")
+    add("rasterize", stage_ms.get("rasterize", 0), "hbm", (H * 420 * 420 * 3.0 + n_vert * 32.0 + n_tri * 12.0) * n_prop,
+        f"mandatory rgb writes (the depth image is not written: boxes + cloud extents come from the tile epilogue, fp_rasterize_extents); "
+        f"{H * n_tri * n_prop / max(stage_ms.get('rasterize', 1e9), 1e-9) / 1e6:.1f} G triangle set-ups/s")
     add("depth_extents", stage_ms.get("depth_extents", 0), "hbm", H * 420 * 420 * 4.0 * n_prop, "depth read")
     add("crop_resize", stage_ms.get("crop_resize", 0), "hbm", H * 3.0 * args.res * args.res * 2 * n_prop, "bf16 crop writes (reads are a subset of the renders)")
     add("template_score", stage_ms.get("template_score", 0), "hbm", H * P * D * 2.0 * n_prop, "T*P*D*2 bytes")
@@ -801,7 +826,7 @@ def _pmc_traffic():
     """(HBM bytes per GEMM launch, where the figure comes from): a QUOTED constant — the committed rocprofv3 --pmc summary
     (tools/profile_job.sh -> profiles/), used only if it was taken on exactly these kernel sources (its csrc_sha16 equals
     csrc_hash()); PMC counters cannot be collected inside this run.  (None, reason) otherwise."""
-    for name in ("r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):
+    for name in ("r06_gemm_pmc.json", "r05_gemm_pmc.json", "r04_gemm_pmc.json", "r03_gemm_pmc.json", "r02_gemm_pmc.json"):
         p = ROOT / "profiles" / name
         if p.exists():
             try:

@@ -34,6 +34,7 @@ extern "C" int fp_lab_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_ring")) g_opts[FP_OPT_GEMM_RING] = value;   // cap on the 64x64 tier's K-tile ring depth
     else if (!strcmp(name, "gemm_sk")) g_opts[FP_OPT_GEMM_SK] = value;       // balanced tier: 1 never, 2 / 3 / 4 force a form (gemm_bf16.hip)
     else if (!strcmp(name, "gemm_sk_grid")) g_opts[FP_OPT_GEMM_SK_GRID] = value;
+    else if (!strcmp(name, "raster_dbg")) g_opts[FP_OPT_RASTER_DBG] = value;           // tile kernel ablation bits (raster.hip)
     else if (!strcmp(name, "gemm_stream_mb")) g_opts[FP_OPT_GEMM_STREAM_MB] = value;   // big tier: outputs above this many MiB are stored non-temporally
     else { fp_set_error("lab_set_option: unknown option '%s'", name); return FP_ERR_INVALID; }
     return FP_OK;
@@ -47,11 +48,24 @@ extern "C" int fp_lab_read_scratch(fp_ctx* ctx, void* host, size_t bytes) {
 }
 #endif
 
+#ifdef FP_LAB
+// lab build only: copy a named workspace of the context to the host (raster.dbg: the tile kernel's phase clocks)
+extern "C" int fp_lab_read_buffer(fp_ctx* ctx, const char* name, void* host, size_t bytes) {
+    FP_REQUIRE(ctx && name && host, "lab_read_buffer: null argument");
+    auto it = ctx->bufs.find(name);
+    FP_REQUIRE(it != ctx->bufs.end() && it->second.bytes >= bytes, "lab_read_buffer: no such buffer");
+    FP_HIP(hipDeviceSynchronize());
+    FP_HIP(hipMemcpy(host, it->second.p, bytes, hipMemcpyDeviceToHost));
+    return FP_OK;
+}
+#endif
+
 extern "C" int fp_ctx_set_option(fp_ctx* ctx, const char* name, int value) {
     FP_REQUIRE(ctx && name, "ctx_set_option: null argument");
     if (!strcmp(name, "ln_fused")) ctx->opt_ln_fused = value;
     else if (!strcmp(name, "raster_tiled")) ctx->opt_raster_tiled = value;
     else if (!strcmp(name, "gemm_row_split")) ctx->opt_row_split = value;
+    else if (!strcmp(name, "comm_timeout_s")) ctx->opt_comm_timeout_s = value;
 #ifdef FP_LAB
     else if (!strcmp(name, "gemm_stream_k")) ctx->opt_stream_k = value;   // lab: 0 = never lend the balanced tier its scratch
 #endif

@@ -9,6 +9,12 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+
 #include "../../include/freepose_hip.h"
 #include "internal.h"
 
@@ -87,11 +93,48 @@ extern "C" int fp_comm_init(fp_ctx* ctx, int nranks, int rank, const void* uniqu
     FP_REQUIRE(!ctx->comm, "comm_init: context already has a communicator");
     int rc = rccl_load();
     if (rc) return rc;
-    FP_HIP(hipSetDevice(ctx->device));
     fp_nccl_uid id;
     memcpy(&id, unique_id128, sizeof(id));
-    fp_nccl_comm c = nullptr;
-    FP_NCCL(g_rccl.init_rank(&c, nranks, id, rank));
+    bool blank = true;
+    for (size_t k = 0; k < sizeof(id); ++k) blank = blank && id.internal[k] == 0;
+    FP_REQUIRE(!blank, "comm_init: the unique id is all zero (fp_comm_unique_id of rank 0 never reached this rank)");
+    // ncclCommInitRank is a rendezvous of `nranks` ranks and waits for ever when they never all arrive — ranks that disagree on
+    // nranks or hold different ids, a rank that died before it got here.  It runs on a helper thread; after `comm_timeout_s` seconds
+    // (fp_ctx_set_option, default 180) the call returns FP_ERR_STATE with a message instead of hanging the job (the helper stays
+    // blocked inside RCCL and is abandoned: the process is expected to exit on this error).
+    struct Rendezvous {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        int rc = 0, hip_rc = 0;
+        fp_nccl_comm comm = nullptr;
+    };
+    auto st = std::make_shared<Rendezvous>();
+    const int device = ctx->device;
+    std::thread([st, device, nranks, rank, id]() {
+        int hip_rc = (int)hipSetDevice(device), rc = 0;
+        fp_nccl_comm c = nullptr;
+        if (hip_rc == 0) rc = g_rccl.init_rank(&c, nranks, id, rank);
+        std::lock_guard<std::mutex> lk(st->m);
+        st->rc = rc; st->hip_rc = hip_rc; st->comm = c; st->done = true;
+        st->cv.notify_all();
+    }).detach();
+    const int limit_s = ctx->opt_comm_timeout_s > 0 ? ctx->opt_comm_timeout_s : 180;
+    {
+        std::unique_lock<std::mutex> lk(st->m);
+        if (!st->cv.wait_for(lk, std::chrono::seconds(limit_s), [&] { return st->done; })) {
+            fp_set_error("comm_init: the rendezvous of %d ranks (this is rank %d) did not complete within %d s — do all ranks pass the same "
+                         "nranks and the unique id of rank 0, and did every rank get here?", nranks, rank, limit_s);
+            return FP_ERR_STATE;
+        }
+    }
+    FP_REQUIRE(st->hip_rc == 0, "comm_init: hipSetDevice(%d) failed on the rendezvous thread", device);
+    if (st->rc != 0) {
+        fp_set_error("ncclCommInitRank failed: %s", g_rccl.errstr ? g_rccl.errstr(st->rc) : "rccl error");
+        return FP_ERR_HIP;
+    }
+    FP_HIP(hipSetDevice(ctx->device));
+    fp_nccl_comm c = st->comm;
     ctx->comm = c;
     ctx->comm_rank = rank;
     ctx->comm_size = nranks;

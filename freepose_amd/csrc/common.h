@@ -211,6 +211,6 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // LAB BUILD ONLY (libfreepose_hip_lab.so, loaded by tools/): process-global experiment toggles set through fp_lab_set_option or the
 // FP_* environment variables; a value < 0 means "use the built-in default".  The product library has neither: its three run-time
 // options ("ln_fused", "raster_tiled", "gemm_row_split") live in the fp_ctx (fp_ctx_set_option).
-enum { FP_OPT_GEMM_VARIANT = 0, FP_OPT_ATTN_SLOTS = 1, FP_OPT_GEMM_DBG = 2, FP_OPT_ATTN_VARIANT = 3, FP_OPT_TOPK_SELECT = 4, FP_OPT_GEMM_RING = 5, FP_OPT_GEMM_SK = 6, FP_OPT_GEMM_SK_GRID = 7, FP_OPT_GEMM_STREAM_MB = 8, FP_OPT_COUNT = 12 };
+enum { FP_OPT_GEMM_VARIANT = 0, FP_OPT_ATTN_SLOTS = 1, FP_OPT_GEMM_DBG = 2, FP_OPT_ATTN_VARIANT = 3, FP_OPT_TOPK_SELECT = 4, FP_OPT_GEMM_RING = 5, FP_OPT_GEMM_SK = 6, FP_OPT_GEMM_SK_GRID = 7, FP_OPT_GEMM_STREAM_MB = 8, FP_OPT_RASTER_DBG = 9, FP_OPT_COUNT = 12 };
 int fp_opt_get(int key, int dflt);
 #endif

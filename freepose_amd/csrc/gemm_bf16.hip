@@ -125,7 +125,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(FpGemmArgs p) {
     auto set_tile = [&](int t, int& tm0, int& tn0) {
         int tile_m, tile_n;
         if constexpr (SK) fp_gemm_tile_of_id<4>(t, tiles_m, tiles_n, tile_m, tile_n);   // t is already a logical tile id
-        else fp_gemm_tile<(VAR & 512) ? 8 : 4>(t, ntiles, tiles_m, tiles_n, tile_m, tile_n);
+        else fp_gemm_tile<(VAR & 1024) ? 16 : (VAR & 512) ? 8 : 4>(t, ntiles, tiles_m, tiles_n, tile_m, tile_n);   // (lab: 512 / 1024 = strips of 8 / 16 n-tiles)
         tm0 = tile_m * BM;
         tn0 = tile_n * BN;
 #pragma unroll
@@ -845,6 +845,7 @@ int launch_epi(const FpGemmArgs& a, hipStream_t stream) {
                     case 64: return launch_cfg<256, 256, 4, 4, EPI, 4 | 64>(a, stream);
                     case 96:
                         if ((var & 128) && (var & 512)) return launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128 | 512>(a, stream);
+                        if ((var & 128) && (var & 1024)) return launch_cfg<256, 256, 4, 4, EPI, 4 | 96 | 128 | 1024>(a, stream);   // whole-N sweep of fc1 (round 6)
                         return (var & 128) ? launch_cfg<256, 256, 4, 4, EPI, FP_GEMM_VAR_BIG>(a, stream)
                                            : launch_cfg<256, 256, 4, 4, EPI, 4 | 96>(a, stream);
                     default: return launch_cfg<256, 256, 4, 4, EPI, 4>(a, stream);

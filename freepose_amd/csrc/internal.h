@@ -20,6 +20,7 @@ struct fp_ctx {
     // run-time options of THIS context (fp_ctx_set_option); -1 = built-in default
     int opt_ln_fused = -1;       // 1 (default): LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward; 0: separate kernel
     int opt_raster_tiled = -1;   // default: by triangle count / image size; 1 / 0 force the LDS-tiled / global-buffer strategy
+    int opt_comm_timeout_s = -1; // seconds fp_comm_init waits for the rendezvous of all ranks before it fails (default 180)
     int opt_row_split = -1;      // 1 (default): GEMM launches between the tile tiers are split by rows; 0: never
     int opt_stream_k = -1;       // 1 (default): small GEMM launches may run on the balanced tier (K slices summed in K order: results depend
                                  // on the launch size in the last place); 0: never — every tier then gives the same bits for a row

@@ -57,6 +57,7 @@ struct fp_mesh {
     float* verts = nullptr;    // [V,3]
     int32_t* faces = nullptr;  // [F,3]
     int32_t* perm = nullptr;   // [F] slot -> face id, Morton order of the object-space centroids (tiled path: coherent 64-triangle chunks)
+    int32_t* fsort = nullptr;  // [F,3] faces[perm[slot]]: the corner ids in slot order (read coalesced by the bin / tile kernels)
     uint8_t* colors = nullptr; // [V,4] rgba (a unused)
     float* uv = nullptr;       // [F,3,2] per-corner texture coordinates (textured meshes)
     uint8_t* tex = nullptr;    // rgba diffuse texture, all mip levels back to back (level k at texel offset lev_off[k])
@@ -117,6 +118,7 @@ struct TriSetup {
     bool ok;
     bool swapped;            // corners 1 and 2 were exchanged (per-corner attributes follow)
     bool strad;              // straddles the near plane: homogeneous rasterisation over the whole frame (struct Strad)
+    bool small;              // spans < 128 px in x and y: every edge function at a candidate pixel fits 32 bits (tri_cover32)
 };
 
 // homogeneous edge functions of a triangle that straddles the near plane (contract in the header)
@@ -166,16 +168,14 @@ __device__ __forceinline__ bool strad_pixel(const Strad& q, int px, int py, floa
 
 __device__ __forceinline__ bool topleft(int dx, int dy) { return (dy < 0) || (dy == 0 && dx > 0); }
 
-__device__ __forceinline__ TriSetup tri_setup(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, int f,
-                                              int W, int Hh) {
+// set-up from the three screen-space vertices already in registers (callers that batch their gathers load them first)
+__device__ __forceinline__ TriSetup tri_setup_v(SVert a, SVert b, SVert c, int i0, int i1, int i2, int W, int Hh) {
     TriSetup t;
-    int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
-    SVert a = sv[i0], b = sv[i1], c = sv[i2];
     const int nfront = (a.zc > ZNEAR) + (b.zc > ZNEAR) + (c.zc > ZNEAR);
     t.ok = nfront == 3;
     t.strad = nfront == 1 || nfront == 2;
     if (t.strad) {   // near-plane straddler: candidate pixels = the whole frame, original corner order, no fixed-point set-up
-        t.ok = true; t.swapped = false; t.area2 = 1;
+        t.ok = true; t.swapped = false; t.area2 = 1; t.small = false;
         t.x0 = t.y0 = t.x1 = t.y1 = t.x2 = t.y2 = 0;
         t.iz0 = t.iz1 = t.iz2 = 0.f;
         t.i0 = i0; t.i1 = i1; t.i2 = i2;
@@ -202,7 +202,13 @@ __device__ __forceinline__ TriSetup tri_setup(const SVert* __restrict__ sv, cons
     t.bx1 = min(W - 1, (mxx - 128) >> 8);
     t.by1 = min(Hh - 1, (mxy - 128) >> 8);
     if (t.bx1 < t.bx0 || t.by1 < t.by0) t.ok = false;
+    t.small = (mxx - mnx) < 32768 && (mxy - mny) < 32768;
     return t;
+}
+__device__ __forceinline__ TriSetup tri_setup(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, int f,
+                                              int W, int Hh) {
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    return tri_setup_v(sv[i0], sv[i1], sv[i2], i0, i1, i2, W, Hh);
 }
 
 // edge functions at the pixel centre; returns coverage and the three (non-negative) weights
@@ -217,6 +223,28 @@ __device__ __forceinline__ bool tri_cover(const TriSetup& t, int px, int py, lon
     if (w1 == 0 && !topleft(t.x0 - t.x2, t.y0 - t.y2)) return false;
     if (w2 == 0 && !topleft(t.x1 - t.x0, t.y1 - t.y0)) return false;
     return true;
+}
+
+// The same edge functions for a `small` triangle at one of its candidate pixels (centre inside the vertex bounding box): every
+// difference is below 2^15 in magnitude, so the products fit 24 x 24 -> 32-bit multiplies (v_mul_i32_i24, full rate; a 64-bit product
+// is four quarter-rate multiplies) and the sums 32 bits: the SAME integers as tri_cover, hence the same coverage, the same float
+// conversions and the same depth bits — what the dense meshes' ~1-pixel triangles spend their time on.
+__device__ __forceinline__ bool tri_cover32(const TriSetup& t, int px, int py, int& w0, int& w1, int& w2) {
+    const int sx = px * 256 + 128, sy = py * 256 + 128;
+    w0 = __mul24(t.x2 - t.x1, sy - t.y1) - __mul24(t.y2 - t.y1, sx - t.x1);
+    w1 = __mul24(t.x0 - t.x2, sy - t.y2) - __mul24(t.y0 - t.y2, sx - t.x2);
+    w2 = __mul24(t.x1 - t.x0, sy - t.y0) - __mul24(t.y1 - t.y0, sx - t.x0);
+    if ((w0 | w1 | w2) < 0) return false;
+    if (w0 == 0 && !topleft(t.x2 - t.x1, t.y2 - t.y1)) return false;
+    if (w1 == 0 && !topleft(t.x0 - t.x2, t.y0 - t.y2)) return false;
+    if (w2 == 0 && !topleft(t.x1 - t.x0, t.y1 - t.y0)) return false;
+    return true;
+}
+__device__ __forceinline__ float tri_depth32(const TriSetup& t, int w0, int w1, int w2, float& b0, float& b1, float& b2) {
+    const float fa = (float)(int)t.area2;      // (a small triangle's doubled area is below 2^31: the same float as from the 64-bit value)
+    b0 = (float)w0 / fa; b1 = (float)w1 / fa; b2 = (float)w2 / fa;
+    const float izp = fmaf(b2, t.iz2, fmaf(b1, t.iz1, b0 * t.iz0));
+    return 1.0f / izp;
 }
 
 __device__ __forceinline__ float tri_depth(const TriSetup& t, long long w0, long long w1, long long w2, float& b0,
@@ -310,12 +338,32 @@ __device__ __forceinline__ float log2p(float t) {
 }
 
 // tab: DEC[256] then THR[256] (LDS copy)
-__device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetup& t, int f, float q0, float q1, float q2,
+// per-triangle shading attributes, loaded by the caller (so a batch of pixels can have all its gathers in flight at once):
+// vertex colours as rgba words of the triangle's ORIGINAL corners (face order) or the six per-corner uv floats
+struct TriAttr { uint32_t cw[3]; float tc[6]; };
+__device__ __forceinline__ TriAttr load_attr(const ShadeArgs& s, int f, int v0, int v1, int v2) {
+    TriAttr a;
+    a.cw[0] = a.cw[1] = a.cw[2] = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.tc[k] = 0.f;
+    if (s.uv) {
+        const float2* tc = (const float2*)(s.uv + (size_t)f * 6);
+        const float2 t0 = tc[0], t1 = tc[1], t2 = tc[2];
+        a.tc[0] = t0.x; a.tc[1] = t0.y; a.tc[2] = t1.x; a.tc[3] = t1.y; a.tc[4] = t2.x; a.tc[5] = t2.y;
+    } else if (s.colors) {
+        const uint32_t* cw = (const uint32_t*)s.colors;
+        a.cw[0] = cw[v0]; a.cw[1] = cw[v1]; a.cw[2] = cw[v2];
+    }
+    return a;
+}
+
+// `at`: attributes in FACE order (corner k of faces[3f + k]); t.swapped says whether set-up exchanged corners 1 and 2
+__device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetup& t, const TriAttr& at, float q0, float q1, float q2,
                                                float dd, const float* tab, uint8_t (&out)[3], bool lod0 = false) {
     const float* dec = tab;
     const float* thr = tab + 256;
     if (s.uv) {
-        const float* tc = s.uv + (size_t)f * 6;
+        const float* tc = at.tc;
         const int k1 = t.swapped ? 2 : 1, k2 = t.swapped ? 1 : 2;
         const float u0 = tc[0], u1 = tc[2 * k1], u2 = tc[2 * k2];
         const float v0 = tc[1], v1 = tc[2 * k1 + 1], v2 = tc[2 * k2 + 1];
@@ -366,10 +414,10 @@ __device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetu
             }
         }
     } else {
+        const uint32_t w0 = at.cw[0], w1 = at.cw[t.swapped ? 2 : 1], w2 = at.cw[t.swapped ? 1 : 2];   // (white = 255 when the mesh has no colours)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float c0 = 255.f, c1 = 255.f, c2 = 255.f;
-            if (s.colors) { c0 = (float)s.colors[4 * t.i0 + c]; c1 = (float)s.colors[4 * t.i1 + c]; c2 = (float)s.colors[4 * t.i2 + c]; }
+            const float c0 = (float)((w0 >> (8 * c)) & 255u), c1 = (float)((w1 >> (8 * c)) & 255u), c2 = (float)((w2 >> (8 * c)) & 255u);
             const float cv = fmaf(q2, c2, fmaf(q1, c1, q0 * c0)) * dd;
             if (s.shade) out[c] = encode_gamma(s.ambient * (cv * (1.0f / 255.f)), thr);
             else out[c] = (uint8_t)fmaxf(fminf(s.ambient * cv + 0.5f, 255.0f), 0.f);
@@ -377,28 +425,45 @@ __device__ __forceinline__ void shade_fragment(const ShadeArgs& s, const TriSetu
     }
 }
 
-// resolve one pixel whose visibility key is `key`: depth and colour of the winning triangle
-__device__ __forceinline__ void resolve_pixel(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, const ShadeArgs& s,
-                                              const float* tab, unsigned long long key, int px, int py, int W, int Hh, float& d,
-                                              uint8_t (&out)[3]) {
+// resolve one pixel whose visibility key is `key`: depth and colour of the winning triangle.  `t` / `at`: the winner's set-up and
+// attributes (loaded by the caller; ignored for a background pixel)
+__device__ __forceinline__ void resolve_pixel_v(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, const ShadeArgs& s,
+                                                const float* tab, unsigned long long key, const TriSetup& t, const TriAttr& at, int px,
+                                                int py, float& d, uint8_t (&out)[3]) {
     d = 0.f;
     out[0] = out[1] = out[2] = 0;
     if (key == ~0ull) return;
     const int f = (int)(unsigned)(key & 0xffffffffu);
     d = __uint_as_float((unsigned)(key >> 32));
-    const TriSetup t = tri_setup(sv, faces, f, W, Hh);
     float b0, b1, b2;
     if (t.strad) {   // near-plane straddler: true (3-D) barycentrics, level-0 texture
         const Strad q = strad_setup(sv, faces, f);
         float ds;
         strad_pixel(q, px, py, ds, b0, b1, b2);
-        shade_fragment(s, t, f, b0, b1, b2, 1.0f, tab, out, true);
+        shade_fragment(s, t, at, b0, b1, b2, 1.0f, tab, out, true);
         return;
     }
-    long long w0, w1, w2;
-    tri_cover(t, px, py, w0, w1, w2);
-    const float dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
-    shade_fragment(s, t, f, b0 * t.iz0, b1 * t.iz1, b2 * t.iz2, dd, tab, out);
+    float dd;
+    if (t.small) {
+        int w0, w1, w2;
+        tri_cover32(t, px, py, w0, w1, w2);
+        dd = tri_depth32(t, w0, w1, w2, b0, b1, b2);
+    } else {
+        long long w0, w1, w2;
+        tri_cover(t, px, py, w0, w1, w2);
+        dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
+    }
+    shade_fragment(s, t, at, b0 * t.iz0, b1 * t.iz1, b2 * t.iz2, dd, tab, out);
+}
+__device__ __forceinline__ void resolve_pixel(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, const ShadeArgs& s,
+                                              const float* tab, unsigned long long key, int px, int py, int W, int Hh, float& d,
+                                              uint8_t (&out)[3]) {
+    if (key == ~0ull) { d = 0.f; out[0] = out[1] = out[2] = 0; return; }
+    const int f = (int)(unsigned)(key & 0xffffffffu);
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    const TriAttr at = load_attr(s, f, i0, i1, i2);
+    const TriSetup t = tri_setup_v(sv[i0], sv[i1], sv[i2], i0, i1, i2, W, Hh);
+    resolve_pixel_v(sv, faces, s, tab, key, t, at, px, py, d, out);
 }
 
 __global__ __launch_bounds__(256) void raster_tri_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
@@ -484,9 +549,10 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __rest
 //                 nibbles (16 bit), and per chunk the OR of its triangles' tile masks (64 bit, tiles <= 8 x 8) by a wave reduction.
 //   tile kernel : one workgroup per (view, tile), all tiles of a view on one XCD (its screen-space vertices stay in that L2).
 //                 The chunk masks are read 1024 at a time (coalesced) and the chunks that touch the tile compacted into an LDS hit
-//                 list; each WAVE then takes hit chunks on its own — a lane whose triangle overlaps the tile rasterises it into LDS
-//                 with ds_min_u64, triangles with more than BIG_TILE_AREA candidate pixels in the tile are handed to the whole
-//                 wave (ballot loop).  A tile no chunk touches is written as background at once.  Otherwise the tile's pixels are
+//                 list; each WAVE then takes hit chunks on its own (one triangle per lane, the next chunks' reads in flight): the
+//                 candidate pixels of the chunk's triangles are flattened over the wave's lanes and depth-tested into LDS with
+//                 ds_min_u64 — 32-bit edge functions for triangles below 128 px (all of a dense mesh's), a whole-wave loop for the
+//                 rest and for near-plane straddlers.  A tile no chunk touches is written as background at once.  Otherwise the tile's pixels are
 //                 resolved (same colour / depth arithmetic as the global path), packed into their own LDS slot, and flushed row by
 //                 row as whole dwords.  The epilogue also reduces what fp_depth_extents would compute from the depth image
 //                 (count, pixel bbox, fp64 cloud extents: min / max / integer sums, order-independent, hence bit-identical) to one
@@ -495,7 +561,7 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __rest
 // Same tri_setup / tri_cover / tri_depth, same candidate pixel set (bbox ∩ tile over all tiles = bbox), same 64-bit key and
 // an order-independent minimum: the output is bit-identical to the global-buffer path and to the oracle.
 constexpr int BIN_CHUNK = 64;
-constexpr int BIG_TILE_AREA = 32;
+constexpr int BIG_TILE_AREA = 32;       // candidate pixels in the tile above which a triangle is handed to the whole wave
 constexpr int HITS_ROUND = 1024;         // chunk masks examined per round of the tile kernel (4 per thread)
 constexpr uint16_t TBOX_NONE = 0x000f;   // tx0 = 15 > tx1 = 0: overlaps nothing
 constexpr int PART_N = 10;               // doubles per (view, tile) extents record
@@ -522,9 +588,9 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long m) {
 }
 
 __global__ __launch_bounds__(256) void raster_bin_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
-                                                         const int32_t* __restrict__ perm, int V, int F, int W, int Hh, int T, int Hn,
-                                                         int nchunk, uint16_t* __restrict__ tbox,
-                                                         unsigned long long* __restrict__ cmask, int cull) {
+                                                         const int32_t* __restrict__ perm, const int32_t* __restrict__ fsort, int V,
+                                                         int F, int W, int Hh, int T, int Hn, int nchunk,
+                                                         uint16_t* __restrict__ tbox, unsigned long long* __restrict__ cmask, int cull) {
     int item, h;
     view_major_ids(gridDim.x, Hn, item, h);
     const int lane = threadIdx.x & 63;
@@ -534,10 +600,10 @@ __global__ __launch_bounds__(256) void raster_bin_kernel(const SVert* __restrict
     uint16_t box = TBOX_NONE;
     unsigned long long m = 0ull;
     if (slot < F) {
-        const int f = perm[slot];
         const SVert* sv = sv_all + (size_t)h * V;
-        const TriSetup t = tri_setup(sv, faces, f, W, Hh);
-        if (t.ok && !(cull && back_facing(t, sv, faces, f))) {
+        const int i0 = fsort[3 * slot], i1 = fsort[3 * slot + 1], i2 = fsort[3 * slot + 2];   // the slot's corners, read in slot order
+        const TriSetup t = tri_setup_v(sv[i0], sv[i1], sv[i2], i0, i1, i2, W, Hh);
+        if (t.ok && !(cull && back_facing(t, sv, faces, perm[slot]))) {
             const int tx0 = t.bx0 / T, ty0 = t.by0 / T, tx1 = t.bx1 / T, ty1 = t.by1 / T;
             box = (uint16_t)(tx0 | (ty0 << 4) | (tx1 << 8) | (ty1 << 12));
             const unsigned long long row = ((1ull << (tx1 - tx0 + 1)) - 1ull) << tx0;    // <= 8 tiles per row
@@ -559,10 +625,16 @@ __device__ __forceinline__ void strad_pixel_tile(const Strad& q, int f, int px, 
 }
 
 __device__ __forceinline__ void tile_pixel(const TriSetup& t, int f, int px, int py, unsigned long long* tile, int X0, int Y0, int T) {
-    long long w0, w1, w2;
-    if (!tri_cover(t, px, py, w0, w1, w2)) return;
-    float b0, b1, b2;
-    const float d = tri_depth(t, w0, w1, w2, b0, b1, b2);
+    float b0, b1, b2, d;
+    if (t.small) {
+        int w0, w1, w2;
+        if (!tri_cover32(t, px, py, w0, w1, w2)) return;
+        d = tri_depth32(t, w0, w1, w2, b0, b1, b2);
+    } else {
+        long long w0, w1, w2;
+        if (!tri_cover(t, px, py, w0, w1, w2)) return;
+        d = tri_depth(t, w0, w1, w2, b0, b1, b2);
+    }
     if (!(d > 0.f)) return;
     const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)f;
     unsigned long long* slot = &tile[(py - Y0) * T + (px - X0)];
@@ -582,13 +654,56 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int off) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// the set-up a lane holds, handed to the whole wave (lane `src` is wave-uniform: v_readlane, no memory round trip)
+__device__ __forceinline__ int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ TriSetup bcast_setup(const TriSetup& t, int src) {
+    TriSetup r;
+    r.x0 = rl_i(t.x0, src); r.y0 = rl_i(t.y0, src); r.x1 = rl_i(t.x1, src); r.y1 = rl_i(t.y1, src); r.x2 = rl_i(t.x2, src); r.y2 = rl_i(t.y2, src);
+    r.iz0 = rl_f(t.iz0, src); r.iz1 = rl_f(t.iz1, src); r.iz2 = rl_f(t.iz2, src);
+    const unsigned lo = (unsigned)rl_i((int)(unsigned)(unsigned long long)t.area2, src), hi = (unsigned)rl_i((int)(unsigned)((unsigned long long)t.area2 >> 32), src);
+    r.area2 = (long long)(((unsigned long long)hi << 32) | lo);
+    r.bx0 = rl_i(t.bx0, src); r.by0 = rl_i(t.by0, src); r.bx1 = rl_i(t.bx1, src); r.by1 = rl_i(t.by1, src);
+    r.i0 = rl_i(t.i0, src); r.i1 = rl_i(t.i1, src); r.i2 = rl_i(t.i2, src);
+    const int flags = rl_i((t.ok ? 1 : 0) | (t.swapped ? 2 : 0) | (t.strad ? 4 : 0) | (t.small ? 8 : 0), src);
+    r.ok = flags & 1; r.swapped = flags & 2; r.strad = flags & 4; r.small = flags & 8;
+    return r;
+}
+
+// what a lane needs of its triangle in a hit chunk: level 1 = coalesced reads in slot order (tile box, corner ids, face id),
+// level 2 = the gathered screen-space vertices.  The chunk loop keeps the level-1 reads of chunk i+2 and the gathers of chunk i+1 in
+// flight while chunk i is rasterised (a wave otherwise walks its ~30 chunks of an 82 k-triangle mesh one memory round trip at a time).
+struct ChunkL1 { unsigned box; int i0, i1, i2, f; };
+struct ChunkL2 { SVert a, b, c; };
+constexpr int RES_BATCH = 2;             // pixels a thread resolves together (their gathers are issued back to back)
+
 __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
-                                                          const int32_t* __restrict__ perm, ShadeArgs sh,
+                                                          const int32_t* __restrict__ perm, const int32_t* __restrict__ fsort, ShadeArgs sh,
                                                           const float* __restrict__ tables, int V, int F, int W, int Hh, int T,
                                                           int ntx, int Hn, const uint16_t* __restrict__ tbox,
                                                           const unsigned long long* __restrict__ cmask, int nchunk,
                                                           uint8_t* __restrict__ rgb, float* __restrict__ depth,
-                                                          double* __restrict__ part, double fx, double fy, double cx, double cy) {
+                                                          double* __restrict__ part, double fx, double fy, double cx, double cy,
+                                                          int dbg_arg, unsigned long long* dbg_buf) {
+#ifdef FP_LAB   // lab build: ablation bits for tools/raster_ablate.py (1 = no rasterisation, 2 = no shading, 4 = no flush, 8 = no mask scan),
+    // bits 8.. = the per-lane / whole-wave threshold (0 = the product's), dbg_buf = per-phase shader-clock sums of all workgroups
+    const int dbg = dbg_arg & 255;
+    const int big_area = (dbg_arg >> 8) ? (dbg_arg >> 8) : BIG_TILE_AREA;
+    unsigned long long tstamp = __builtin_readcyclecounter();
+#define FP_RASTER_PHASE(k)                                                                                   \
+    do {                                                                                                     \
+        if (dbg_buf && threadIdx.x == 0) {                                                                   \
+            const unsigned long long now__ = __builtin_readcyclecounter();                                   \
+            atomicAdd(&dbg_buf[k], now__ - tstamp);                                                          \
+            tstamp = now__;                                                                                  \
+        }                                                                                                    \
+    } while (0)
+#else
+    constexpr int dbg = 0;
+    constexpr int big_area = BIG_TILE_AREA;
+    (void)dbg_arg; (void)dbg_buf;
+#define FP_RASTER_PHASE(k) do {} while (0)
+#endif
     extern __shared__ unsigned long long tile[];   // [T*T] visibility keys | DEC/THR tables (512 floats) | hit list | column / row factors
     float* tab = (float*)(tile + T * T);
     int* hits = (int*)(tab + 512);
@@ -611,10 +726,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
     for (int p = threadIdx.x; p < T * T; p += blockDim.x) tile[p] = ~0ull;
     if (threadIdx.x == 0) { nhit_s = 0; total_s = 0; }
     __syncthreads();
+    FP_RASTER_PHASE(0);                                // init
     const int tbit = ty * 8 + tx;
     const unsigned long long* cm = cmask + (size_t)h * nchunk;
     const uint16_t* tb = tbox + (size_t)h * nchunk * BIN_CHUNK;
-    for (int base = 0; base < nchunk; base += HITS_ROUND) {
+    for (int base = 0; base < ((dbg & 8) ? 0 : nchunk); base += HITS_ROUND) {
         // ---- which of the next 1024 chunks touch this tile: coalesced mask reads, wave-compacted into the hit list
 #pragma unroll
         for (int k = 0; k < HITS_ROUND / 256; ++k) {
@@ -629,33 +745,56 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
             }
         }
         __syncthreads();
-        const int n = nhit_s;
-        // ---- every wave takes hit chunks on its own: one triangle per lane
-        for (int i = wave; i < n; i += 4) {
-            const int chunk = hits[i];
-            const int slot = chunk * BIN_CHUNK + lane;
-            bool mine = false, big = false;
-            TriSetup t;
-            int f = 0, x0 = 0, y0 = 0, x1 = -1, y1 = -1;
-            const unsigned box = tb[slot];
+        FP_RASTER_PHASE(1);                            // mask scan
+        const int n = (dbg & 1) ? 0 : nhit_s;
+        // ---- every wave takes hit chunks on its own: one triangle per lane, software-pipelined over the wave's chunks
+        auto level1 = [&](int i, ChunkL1& c) {
+            c.box = TBOX_NONE; c.i0 = c.i1 = c.i2 = 0; c.f = 0;
+            if (i < n) {
+                const int slot = hits[i] * BIN_CHUNK + lane;
+                c.box = tb[slot];                                        // (TBOX_NONE for slots >= F)
+                if (slot < F) { c.i0 = fsort[3 * slot]; c.i1 = fsort[3 * slot + 1]; c.i2 = fsort[3 * slot + 2]; c.f = perm[slot]; }
+            }
+        };
+        auto overlaps = [&](unsigned box) {
             const int bx0 = box & 15, by0 = (box >> 4) & 15, bx1 = (box >> 8) & 15, by1 = (box >> 12) & 15;
-            if (bx0 <= tx && tx <= bx1 && by0 <= ty && ty <= by1) {      // (TBOX_NONE overlaps nothing: covers slot >= F too)
-                f = perm[slot];
-                t = tri_setup(sv, faces, f, W, Hh);
+            return bx0 <= tx && tx <= bx1 && by0 <= ty && ty <= by1;
+        };
+        auto level2 = [&](const ChunkL1& c, ChunkL2& g) {
+            if (overlaps(c.box)) { g.a = sv[c.i0]; g.b = sv[c.i1]; g.c = sv[c.i2]; }
+            else { g.a = g.b = g.c = SVert{0, 0, 0.f, 0.f}; }
+        };
+        ChunkL1 c0, c1, c2;
+        ChunkL2 g0, g1;
+        level1(wave, c0);
+        level1(wave + 4, c1);
+        level2(c0, g0);
+        for (int i = wave; i < n; i += 4) {
+            level1(i + 8, c2);
+            level2(c1, g1);
+            bool mine = false, big = false;
+            TriSetup t = {};
+            const int f = c0.f;
+            int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+            if (overlaps(c0.box)) {
+                t = tri_setup_v(g0.a, g0.b, g0.c, c0.i0, c0.i1, c0.i2, W, Hh);
                 x0 = max(t.bx0, X0); y0 = max(t.by0, Y0); x1 = min(t.bx1, X1); y1 = min(t.by1, Y1);
                 mine = t.ok && x0 <= x1 && y0 <= y1;
-                big = mine && ((x1 - x0 + 1) * (y1 - y0 + 1) > BIG_TILE_AREA || t.strad);   // straddlers always take the wave loop
+                big = mine && ((x1 - x0 + 1) * (y1 - y0 + 1) > big_area || t.strad);   // straddlers always take the wave loop
             }
             if (mine && !big)
                 for (int py = y0; py <= y1; ++py)
                     for (int px = x0; px <= x1; ++px) tile_pixel(t, f, px, py, tile, X0, Y0, T);
-            // triangles with many candidate pixels in this tile: the whole wave strides over them, one triangle at a time
+            // triangles with many candidate pixels in this tile, and near-plane straddlers: the whole wave strides over them, one triangle
+            // at a time, the owner lane's set-up broadcast by v_readlane.  (Round 6 also measured the candidates of a chunk FLATTENED over
+            // the lanes — counts prefix-summed, owner found by binary search, set-up fetched by ds_bpermute: 14 permutes per item cost what
+            // the idle lanes did; 2.32 / 3.03 / 6.29 ms against 1.70 / 3.13 / 5.26 at 1 280 / 81 920 / 327 680 triangles.  Not shipped.)
             unsigned long long bm = __ballot(big);
             while (bm) {
                 const int src = __ffsll((long long)bm) - 1;
                 bm &= bm - 1;
-                const int fb = __shfl(f, src, 64);
-                const TriSetup tbg = tri_setup(sv, faces, fb, W, Hh);
+                const int fb = rl_i(f, src);
+                const TriSetup tbg = bcast_setup(t, src);          // (was a second set-up from memory: two dependent gathers per triangle)
                 const int ax0 = max(tbg.bx0, X0), ay0 = max(tbg.by0, Y0), ax1 = min(tbg.bx1, X1), ay1 = min(tbg.by1, Y1);
                 const int bw = ax1 - ax0 + 1, np = bw * (ay1 - ay0 + 1);
                 if (tbg.strad) {
@@ -665,8 +804,14 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
                 }
                 for (int j = lane; j < np; j += 64) tile_pixel(tbg, fb, ax0 + j % bw, ay0 + j / bw, tile, X0, Y0, T);
             }
+            c0 = c1; c1 = c2; g0 = g1;
         }
+#ifdef FP_LAB
+        if (dbg_buf && lane == 0 && wave == 0) atomicAdd(&dbg_buf[6], (unsigned long long)(__builtin_readcyclecounter() - tstamp));   // wave 0's own chunk loop
+        if (dbg_buf && threadIdx.x == 0) atomicAdd(&dbg_buf[7], (unsigned long long)n);
+#endif
         __syncthreads();
+        FP_RASTER_PHASE(2);                            // chunk loop (until the slowest wave is done)
         if (threadIdx.x == 0) { total_s += n; nhit_s = 0; }
         __syncthreads();
     }
@@ -676,25 +821,65 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
     e.cnt = 0; e.xmin = 1 << 30; e.ymin = 1 << 30; e.xmax = -1; e.ymax = -1;
     e.Xmin = 1e300; e.Xmax = -1e300; e.Ymin = 1e300; e.Ymax = -1e300;
     if (touched) {
-        // ---- resolve: same arithmetic as raster_resolve_kernel; the result replaces the pixel's key in its own LDS slot
-        for (int p = threadIdx.x; p < tw * th; p += blockDim.x) {
-            const int ly = p / tw, lx = p - ly * tw;
-            const int px = X0 + lx, py = Y0 + ly;
-            float d;
-            uint8_t out[3];
-            resolve_pixel(sv, faces, sh, tab, tile[ly * T + lx], px, py, W, Hh, d, out);
-            tile[ly * T + lx] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)out[0] | ((unsigned)out[1] << 8) | ((unsigned)out[2] << 16);
-            if (d != 0.f) {   // fp_depth_extents: every non-zero depth joins the cloud, every positive one the mask
-                const double X = ax[lx] * (double)d, Y = ay[ly] * (double)d;
-                e.Xmin = fmin(e.Xmin, X); e.Xmax = fmax(e.Xmax, X); e.Ymin = fmin(e.Ymin, Y); e.Ymax = fmax(e.Ymax, Y);
-                if (d > 0.f) { ++e.cnt; e.xmin = min(e.xmin, px); e.xmax = max(e.xmax, px); e.ymin = min(e.ymin, py); e.ymax = max(e.ymax, py); }
+        // ---- resolve: same arithmetic as raster_resolve_kernel; the result replaces the pixel's key in its own LDS slot.
+        // RES_BATCH pixels per thread at a time: keys -> corner ids -> vertices + attributes, each level's loads issued for the whole
+        // batch before the first is used (a pixel at a time, the three dependent gathers bound the whole kernel: 2 ms per 576 views
+        // whatever the triangle count)
+        for (int pb = threadIdx.x; pb < tw * th; pb += blockDim.x * RES_BATCH) {
+            unsigned long long key[RES_BATCH];
+            int lxs[RES_BATCH], lys[RES_BATCH], ids[RES_BATCH][3];
+            SVert va[RES_BATCH], vb[RES_BATCH], vc[RES_BATCH];
+            TriAttr at[RES_BATCH];
+#pragma unroll
+            for (int k = 0; k < RES_BATCH; ++k) {
+                const int p = pb + k * (int)blockDim.x;
+                key[k] = ~0ull; lxs[k] = lys[k] = 0;
+                if (p < tw * th) { lys[k] = p / tw; lxs[k] = p - lys[k] * tw; key[k] = tile[lys[k] * T + lxs[k]]; }
+            }
+#pragma unroll
+            for (int k = 0; k < RES_BATCH; ++k) {
+                ids[k][0] = ids[k][1] = ids[k][2] = 0;
+                if (key[k] != ~0ull) {
+                    const int f = (int)(unsigned)(key[k] & 0xffffffffu);
+                    ids[k][0] = faces[3 * f]; ids[k][1] = faces[3 * f + 1]; ids[k][2] = faces[3 * f + 2];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RES_BATCH; ++k) {
+                if (key[k] != ~0ull) {
+                    va[k] = sv[ids[k][0]]; vb[k] = sv[ids[k][1]]; vc[k] = sv[ids[k][2]];
+                    at[k] = load_attr(sh, (int)(unsigned)(key[k] & 0xffffffffu), ids[k][0], ids[k][1], ids[k][2]);
+                } else {
+                    va[k] = vb[k] = vc[k] = SVert{0, 0, 0.f, 0.f};
+                    at[k] = TriAttr{};
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RES_BATCH; ++k) {
+                const int p = pb + k * (int)blockDim.x;
+                if (p >= tw * th) continue;
+                const int lx = lxs[k], ly = lys[k], px = X0 + lx, py = Y0 + ly;
+                float d = 0.f;
+                uint8_t out[3] = {0, 0, 0};
+                if (key[k] != ~0ull && !(dbg & 2)) {
+                    const TriSetup t = tri_setup_v(va[k], vb[k], vc[k], ids[k][0], ids[k][1], ids[k][2], W, Hh);
+                    resolve_pixel_v(sv, faces, sh, tab, key[k], t, at[k], px, py, d, out);
+                }
+                tile[ly * T + lx] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)out[0] | ((unsigned)out[1] << 8) | ((unsigned)out[2] << 16);
+                if (d != 0.f) {   // fp_depth_extents: every non-zero depth joins the cloud, every positive one the mask
+                    const double X = ax[lx] * (double)d, Y = ay[ly] * (double)d;
+                    e.Xmin = fmin(e.Xmin, X); e.Xmax = fmax(e.Xmax, X); e.Ymin = fmin(e.Ymin, Y); e.Ymax = fmax(e.Ymax, Y);
+                    if (d > 0.f) { ++e.cnt; e.xmin = min(e.xmin, px); e.xmax = max(e.xmax, px); e.ymin = min(e.ymin, py); e.ymax = max(e.ymax, py); }
+                }
             }
         }
     } else {
         for (int p = threadIdx.x; p < T * T; p += blockDim.x) tile[p] = 0ull;
     }
     __syncthreads();
+    FP_RASTER_PHASE(3);                                // resolve
     // ---- flush: depth rows as floats; rgb rows as whole dwords (byte stores only for a row's unaligned ends)
+    if (dbg & 4) return;
     if (depth) {
         for (int p = threadIdx.x; p < tw * th; p += blockDim.x) {
             const int ly = p / tw, lx = p - ly * tw;
@@ -727,6 +912,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
             }
         }
     }
+    FP_RASTER_PHASE(4);                                // flush
     if (!part) return;
     // ---- the tile's extents record
 #pragma unroll
@@ -863,6 +1049,11 @@ static int mesh_geometry(fp_ctx* ctx, const float* h_verts, int V, const int32_t
         for (int f = 0; f < F; ++f) perm[f] = key[f].second;
         FP_HIP(hipMalloc((void**)&m->perm, (size_t)F * 4));
         FP_HIP(hipMemcpy(m->perm, perm.data(), (size_t)F * 4, hipMemcpyHostToDevice));
+        std::vector<int32_t> fsort((size_t)F * 3);
+        for (int k = 0; k < F; ++k)
+            for (int a = 0; a < 3; ++a) fsort[3 * (size_t)k + a] = h_faces[3 * (size_t)perm[k] + a];
+        FP_HIP(hipMalloc((void**)&m->fsort, (size_t)F * 12));
+        FP_HIP(hipMemcpy(m->fsort, fsort.data(), (size_t)F * 12, hipMemcpyHostToDevice));
     }
     int rc = mesh_tables(m);
     if (rc) return rc;
@@ -930,6 +1121,7 @@ extern "C" int fp_mesh_destroy(fp_mesh* m) {
     if (m->verts) (void)hipFree(m->verts);
     if (m->faces) (void)hipFree(m->faces);
     if (m->perm) (void)hipFree(m->perm);
+    if (m->fsort) (void)hipFree(m->fsort);
     if (m->colors) (void)hipFree(m->colors);
     if (m->uv) (void)hipFree(m->uv);
     if (m->tex) (void)hipFree(m->tex);
@@ -994,13 +1186,23 @@ static int rasterize_impl(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses
         if ((rc = ctx->get("raster.tbox", (size_t)Hn * nchunk * BIN_CHUNK * 2, (void**)&tbox))) return rc;
         if ((rc = ctx->get("raster.cmask", (size_t)Hn * nchunk * 8, (void**)&cmask))) return rc;
         if (want_ext && (rc = ctx->get("raster.part", (size_t)Hn * ntile * PART_N * 8, (void**)&part))) return rc;
-        hipLaunchKernelGGL(raster_bin_kernel, dim3(cdiv(nchunk, 4), Hn), dim3(256), 0, s, sv, mesh->faces, mesh->perm, V, F, W, Hh, T, Hn,
+        hipLaunchKernelGGL(raster_bin_kernel, dim3(cdiv(nchunk, 4), Hn), dim3(256), 0, s, sv, mesh->faces, mesh->perm, mesh->fsort, V, F, W, Hh, T, Hn,
                            nchunk, tbox, cmask, mesh->cull);
         FP_LAUNCH_CHECK();
+        unsigned long long* dbg_buf = nullptr;
+#ifdef FP_LAB
+        const int raster_dbg = fp_opt_get(FP_OPT_RASTER_DBG, 0);
+        if (raster_dbg & (1 << 30)) {                      // phase clocks: summed over all workgroups into "raster.dbg" (fp_lab_read_buffer)
+            if ((rc = ctx->get("raster.dbg", 64, (void**)&dbg_buf))) return rc;
+            FP_HIP(hipMemsetAsync(dbg_buf, 0, 64, s));
+        }
+#else
+        const int raster_dbg = 0;
+#endif
         const size_t lds = (size_t)T * T * 8 + 2048 + HITS_ROUND * 4 + (size_t)2 * T * 8;   // keys + DEC/THR tables + hit list + column / row factors
         FP_DYN_LDS_ONCE(raster_tile_kernel, 88 * 88 * 8 + 2048 + HITS_ROUND * 4 + 2 * 88 * 8);
-        hipLaunchKernelGGL(raster_tile_kernel, dim3(ntile, Hn), dim3(256), lds, s, sv, mesh->faces, mesh->perm, shade_args(mesh), mesh->tables,
-                           V, F, W, Hh, T, ntx, Hn, tbox, cmask, nchunk, d_rgb, d_depth, part, (double)fx, (double)fy, (double)cx, (double)cy);
+        hipLaunchKernelGGL(raster_tile_kernel, dim3(ntile, Hn), dim3(256), lds, s, sv, mesh->faces, mesh->perm, mesh->fsort, shade_args(mesh), mesh->tables,
+                           V, F, W, Hh, T, ntx, Hn, tbox, cmask, nchunk, d_rgb, d_depth, part, (double)fx, (double)fy, (double)cx, (double)cy, raster_dbg & ~(1 << 30), dbg_buf);
         FP_LAUNCH_CHECK();
         if (want_ext) {
             hipLaunchKernelGGL(raster_extents_kernel, dim3(cdiv(Hn, 64)), dim3(64), 0, s, part, Hn, ntile, W, Hh, d_ext, d_boxes);

@@ -190,7 +190,8 @@ class DinoOnlinePoseEstimator(torch.nn.Module):
             todo, slots = store.reserve(close) if store is not None else ([int(g) for g in close], None)
             crops = masks = ext = None
             if todo:                                   # hypotheses not seen for this mesh yet (all of them without a store)
-                renders = self.renderer.render_from_poses(it["mesh"], self.fine_mesh_poses[todo], scale=self.rendering_scale)
+                renders = self.renderer.render_from_poses(it["mesh"], self.fine_mesh_poses[todo], scale=self.rendering_scale,
+                                                          depth=mask_scores)   # (masks are depth > 0; extents come from the tile epilogue)
                 crops, _, masks, ext = MeshRenderer.generate_proposals(renders, out_bf16=True, return_extents=True, need_masks=mask_scores)
             proposal, query_feat = it["proposal"], it.get("query_feat")
             # the query crop rides in the same ViT batch as the hypothesis crops: a separate B = 1 forward is launch-bound

@@ -58,8 +58,11 @@ class RenderBatch(Sequence):
     """Device-resident renders; `batch[i]` -> (rgb uint8 [H,W,3], depth float32 [H,W], third) as numpy, like the
     reference's result tuples (third = pose for render_from_poses, rotation for render)."""
 
-    def __init__(self, rgb: torch.Tensor, depth: torch.Tensor, thirds, intrinsics):
+    def __init__(self, rgb: torch.Tensor, depth: torch.Tensor, thirds, intrinsics, extents=None, boxes=None):
         self.rgb, self.depth, self.thirds, self.intrinsics = rgb, depth, list(thirds), intrinsics
+        # what fp_depth_extents would give on `depth` (f64 [n,8]) and its box columns (i32 [n,4]): written by the rasteriser's tile
+        # epilogue (fp_rasterize_extents), so generate_proposals needs no pass over the depth images — `depth` itself may be None
+        self.extents, self.boxes = extents, boxes
 
     def __len__(self):
         return self.rgb.shape[0]
@@ -68,6 +71,8 @@ class RenderBatch(Sequence):
         if isinstance(i, slice):
             return [self[j] for j in range(*i.indices(len(self)))]
         i = int(i)
+        if self.depth is None:
+            raise RuntimeError("this batch was rendered without its depth images (render_from_poses(..., depth=False))")
         return self.rgb[i].cpu().numpy(), self.depth[i].cpu().numpy(), self.thirds[i]
 
 
@@ -97,24 +102,26 @@ class MeshRenderer:
             self._mesh_cache.pop(next(iter(self._mesh_cache)))
         return dm
 
-    def _render(self, mesh, poses, thirds, scale=1.0, cull_faces=False) -> RenderBatch:
+    def _render(self, mesh, poses, thirds, scale=1.0, cull_faces=False, depth=True) -> RenderBatch:
         poses = np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4)
         dm = self._device_mesh(mesh)
         before = getattr(dm, "cull", 0)
         dm.set_cull(1 if cull_faces else 0)          # reference :63-66 / :90-93: SKIP_CULL_FACES unless cull_faces
         try:
-            rgb, depth = ops.rasterize(dm, torch.from_numpy(poses), scale, self.fx, self.fy, self.cx,
-                                       self.cy, self.resolution, self.resolution)
+            rgb, dimg, ext, boxes = ops.rasterize_extents(dm, torch.from_numpy(poses), scale, self.fx, self.fy, self.cx,
+                                                          self.cy, self.resolution, self.resolution, want_depth=depth)
         finally:
             dm.set_cull(before)                       # a caller's own ops.Mesh keeps the mode it had
-        return RenderBatch(rgb, depth, thirds, (self.fx, self.fy, self.cx, self.cy))
+        return RenderBatch(rgb, dimg, thirds, (self.fx, self.fy, self.cx, self.cy), ext, boxes)
 
     def render(self, mesh, cull_faces=False, scale=1.0):
         return self._render(mesh, self.mesh_poses, self.rotations, scale, cull_faces)
 
-    def render_from_poses(self, mesh, poses, cull_faces=False, scale=1.0):
+    def render_from_poses(self, mesh, poses, cull_faces=False, scale=1.0, depth=True):
+        """`depth=False`: the depth images are not written (their box / extents still are: RenderBatch.extents) — for callers that go
+        straight to generate_proposals(..., need_masks=False)"""
         poses = list(poses)
-        return self._render(mesh, poses, poses, scale, cull_faces)
+        return self._render(mesh, poses, poses, scale, cull_faces, depth)
 
     @staticmethod
     def mask_to_bbox(mask):
@@ -130,11 +137,16 @@ class MeshRenderer:
             depth = torch.from_numpy(np.stack([r[1] for r in res]).astype(np.float32)).cuda()
             res = RenderBatch(rgb, depth, [r[2] for r in res], (600.0, 600.0, 210.0, 210.0))
         fx, fy, cx, cy = res.intrinsics
-        ext = ops.depth_extents(res.depth, fx, fy, cx, cy)
-        boxes = ext[:, :4].to(torch.int32)
+        if res.extents is not None:                   # from the rasteriser's tile epilogue: the same bits
+            ext, boxes = res.extents, res.boxes
+        else:
+            ext = ops.depth_extents(res.depth, fx, fy, cx, cy)
+            boxes = ext[:, :4].to(torch.int32)
         crops = ops.crop_resize_pad(res.rgb, boxes, resolution, float(bbox_extend), out_bf16=out_bf16)
         masks = None
         if need_masks:
+            if res.depth is None:
+                raise RuntimeError("masks need the depth images: render with depth=True")
             masks = res.depth > 0
             small = ext[:, 6] < 100
             if bool(small.any()):

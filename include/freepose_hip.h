@@ -33,8 +33,9 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * value < 0 restores the default.
  *   "ln_fused":       1 (default) LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward on a ViT of this context,
  *                     0 the separate LayerNorm kernel (same reference rounding points; used by the parity tests)
- *   "raster_tiled":   unset = LDS-tiled rasteriser for meshes up to 32 768 triangles and images up to 704 px, global
- *                     visibility-buffer strategy otherwise; 1 / 0 force one of them (both bit-identical)
+ *   "raster_tiled":   unset = LDS-tiled rasteriser for images up to 704 px (any triangle count), global visibility-buffer
+ *                     strategy for larger ones; 1 / 0 force one of them (both bit-identical)
+ *   "comm_timeout_s": seconds fp_comm_init waits for the rendezvous of all ranks (default 180) before it returns FP_ERR_STATE
  *   "gemm_row_split": 1 (default) a GEMM launch between the tile tiers runs whole rounds of the resident grid on 256x256 tiles and
  *                     the remaining rows on the finer tiers; 0 never splits (bit-identical; tests/test_gpu_kernels.py)
  * The measurement variants of earlier rounds (alternative GEMM main loops, attention ring depths, ...) are not in this library:
@@ -202,6 +203,9 @@ int fp_depth_extents(fp_ctx* ctx, const float* d_depth, int Hn, int Hh, int W, f
  * entry points serve hosts without it.  librccl is opened lazily on first use. ------------------------------------------- */
 /* rank 0 creates the 128-byte RCCL unique id (ncclGetUniqueId) and hands it to the other ranks through the host's own channel */
 int fp_comm_unique_id(void* out_id128);
+/* collective over all `nranks` ranks (ncclCommInitRank).  Fails — status + fp_last_error(), never a hang — on a bad rank / nranks,
+ * an all-zero id, a context that already has a communicator, or when the rendezvous does not complete within "comm_timeout_s"
+ * (ranks that disagree on nranks or on the id, a rank that never arrives). */
 int fp_comm_init(fp_ctx* ctx, int nranks, int rank, const void* unique_id128);
 int fp_comm_destroy(fp_ctx* ctx);
 int fp_comm_size(const fp_ctx* ctx);

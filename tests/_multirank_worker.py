@@ -87,7 +87,7 @@ def main():
     fq[:, 0] = bank_f32[777] + 0.002 * fq[:, 0]          # object 0 looks like bank row 777 in every frame
     frame_q = [ops.l2_normalize(torch.from_numpy(fq[f]).cuda().to(torch.bfloat16)) for f in range(n_frames)]
     mine = parallel.shard_items(n_frames, rank, world)
-    rows_sh, best_sh = full.soft_vote([frame_q[f] for f in mine], k=50, frame_ids=mine)
+    rows_sh, best_sh = full.soft_vote([frame_q[f] for f in mine], k=50, frame_ids=mine, n_obj=n_obj)   # (a rank without frames joins with 0 rows)
     votes = [full.frame_votes(q, 50) for q in frame_q]
     ref_rows, ref_best, _ = _soft_vote_local(votes, full.N)
     assert np.array_equal(rows_sh, ref_rows) and np.array_equal(best_sh, ref_best), (rows_sh, ref_rows, best_sh, ref_best)
@@ -103,7 +103,7 @@ def main():
         s2, i2 = sharded.topk(qd, 100)
         assert torch.equal(i2.cpu(), i_full.cpu()) and torch.equal(s2.cpu(), s_full.cpu())
         assert torch.equal(parallel.all_gather_rows(rows), allr)
-        r2, b2 = full.soft_vote([frame_q[f] for f in mine], k=50, frame_ids=mine)
+        r2, b2 = full.soft_vote([frame_q[f] for f in mine], k=50, frame_ids=mine, n_obj=n_obj)
         assert np.array_equal(r2, ref_rows) and np.array_equal(b2, ref_best)
         if rank == 0:
             print("MULTIRANK_ONE_STACK_OK", world, flush=True)

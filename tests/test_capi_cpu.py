@@ -127,6 +127,19 @@ def test_no_compute_entry_points_work_without_gpu():
         assert lib.fp_ctx_create(0, ctypes.byref(h)) != 0  # no device: loud failure, not a fallback
 
 
+def test_comm_entry_points_refuse_bad_arguments_without_a_gpu():
+    """fp_comm_init never hangs on a call it can refuse: null context / id, nranks < 1, rank outside [0, nranks) -> status + message
+    (the rendezvous timeout itself needs a device: tests/test_gpu_comm.py)"""
+    import ctypes as C
+    from freepose_amd import _lib
+    lib = _lib.load()
+    uid = (C.c_char * 128)()
+    for ctx, nranks, rank, ident in ((None, 2, 0, uid), (None, 0, 0, uid), (None, 2, 5, uid), (None, 2, 0, None)):
+        assert lib.fp_comm_init(ctx, nranks, rank, ident) == 1 and b"comm_init" in lib.fp_last_error()
+    assert lib.fp_comm_size(None) == 1 and lib.fp_comm_rank(None) == 0 and lib.fp_comm_destroy(None) == 0
+    assert lib.fp_comm_unique_id(None) != 0
+
+
 def test_missing_extension_fails_loudly(tmp_path):
     from freepose_amd import _lib
     with pytest.raises(RuntimeError, match="no CPU fallback"):

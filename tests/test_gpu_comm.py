@@ -98,3 +98,38 @@ def test_rccl_two_ranks(tmp_path):
             pytest.skip(f"single-GPU box and RCCL refuses two ranks on one device: {refused[0][:200]}")
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert "MULTIRANK_BANK_OK 2" in r.stdout and "MULTIRANK_CABI_OK 2" in r.stdout and "MULTIRANK_ONE_STACK_OK 2" in r.stdout
+
+
+def test_comm_init_fails_cleanly_when_the_ranks_never_all_arrive():
+    """the first 8-GPU lease must not hang on a launcher mistake: fp_comm_init is a rendezvous of `nranks` ranks —
+    ranks that disagree on nranks (here: rank 0 believes in 2 ranks, nobody else exists) would wait for ever inside ncclCommInitRank.
+    With "comm_timeout_s" the call returns FP_ERR_STATE + a message instead; a blank id and a bad rank are refused at once; the
+    context keeps working without a communicator.  Runs in its own process (the abandoned rendezvous thread stays inside RCCL)."""
+    code = r"""
+import ctypes as C, sys, time, os
+import torch
+from freepose_amd import _lib, ops
+lib = _lib.load()
+ctx = ops.context()
+blank = (C.c_char * 128)()
+assert lib.fp_comm_init(ctx, 2, 0, blank) != 0 and b"all zero" in lib.fp_last_error()
+uid = (C.c_char * 128)()
+_lib.check(lib.fp_comm_unique_id(uid), "uid")
+assert lib.fp_comm_init(ctx, 2, 2, uid) != 0 and b"bad argument" in lib.fp_last_error()
+_lib.check(lib.fp_ctx_set_option(ctx, b"comm_timeout_s", 3), "opt")
+t = time.time()
+rc = lib.fp_comm_init(ctx, 2, 0, uid)
+dt = time.time() - t
+msg = lib.fp_last_error().decode()
+assert rc == 3 and "rendezvous of 2 ranks" in msg and "same nranks" in msg, (rc, msg)
+assert 2.5 <= dt <= 30, dt
+assert lib.fp_comm_size(ctx) == 1 and lib.fp_comm_rank(ctx) == 0
+x = torch.arange(64, dtype=torch.float32, device="cuda"); y = torch.empty_like(x)
+_lib.check(lib.fp_allgather_bytes(ctx, _lib.ptr(x), 256, _lib.ptr(y), _lib.current_stream()), "copy")
+torch.cuda.synchronize()
+assert torch.equal(x, y)
+print("COMM_TIMEOUT_OK %.1f" % dt, flush=True)
+os._exit(0)
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "COMM_TIMEOUT_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-2500:])

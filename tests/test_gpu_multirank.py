@@ -82,3 +82,36 @@ def test_bench_self_launches_its_ranks():
     assert out["n_ranks"] == 2 and out["value"] > 0 and out["steps"] == 1
     assert out["shared_devices"] == shared and out["n_gpus"] == out["devices_distinct"] == (1 if shared else 2)
     assert out["backend"] == ("gloo" if shared else "nccl") and out["rccl_version"]
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """the driver's N = 8 launch shape, end to end, before an 8-GPU node ever sees it: eight ranks share the one
+    GPU over gloo and run the whole bench flow — rendezvous on 127.0.0.1, proposal sharding, result all-gather, barriers, MAX-reduced
+    timing, one JSON line from rank 0 — and BOTH video legs (16 frames chunked over 8 ranks; 8 objects dealt one per rank).  Ranks with
+    an EMPTY shard are the worker's case below (5 frames over 8 ranks)."""
+    env = dict(os.environ, FP_DIST_BACKEND="gloo", FP_ALLOW_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29568", str(ROOT / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--hyp", "24",
+           "--bank", "2000", "--mesh-sub", "3", "--vit-batch", "8", "--video-frames", "16"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    out = json.loads(lines[0])
+    assert out["n_ranks"] == 8 and out["shared_devices"] == (_n_gpus() < 8) and len(out["ranks"]) == 8
+    assert {r["rank"] for r in out["ranks"]} == set(range(8)) and len(out["ms_per_step_ranks"]["all"]) == 8
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["config"]["proposals_per_step_per_gpu"] == 1
+    vw = out["video_workload"]
+    assert "frame chunks" in vw["sharding"] and vw["value"] > 0
+    assert vw["object_sharded"]["objects_per_rank"] == [1] * 8 and vw["object_sharded"]["value"] > 0
+
+
+def test_sharded_bank_topk_eight_ranks_on_one_gpu():
+    """bank-row sharding, variable-row gathers and the frame-sharded soft vote (5 frames over 8 ranks: three ranks hold no frame) at
+    the node's rank count"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FP_ALLOW_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29569", str(ROOT / "tests" / "_multirank_worker.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert "MULTIRANK_BANK_OK 8" in r.stdout

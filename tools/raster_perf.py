@@ -49,3 +49,9 @@ for res in (420, 518):
     t = timed(lambda: ops.crop_resize_pad(rgb, boxes, res, 0.0, out_bf16=True))
     by = n_views * 3 * res * res * 2
     print(f"crop_resize_pad {n_views} x {res}^2 bf16: {t:.3f} ms = {by / t / 1e6:.0f} GB/s of output", flush=True)
+# FFA of one crop and of a bank-build batch (ViT-L @518^2: 1369 patches x 1024)
+feats = torch.randn(256, 1369, 1024, device="cuda").to(torch.bfloat16)
+masks = (torch.rand(256, 518, 518, device="cuda") > 0.6)
+for B in (1, 5, 256):
+    t = timed(lambda: ops.ffa(feats[:B], masks[:B], cell=14, normalize=True), it=20)
+    print(f"ffa (cell mask + masked mean + normalise) B={B}: {t * 1e3:.1f} us = {B * 1369 * 1024 * 2 / t / 1e6:.0f} GB/s", flush=True)

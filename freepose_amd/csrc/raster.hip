@@ -58,6 +58,9 @@ struct fp_mesh {
     int32_t* faces = nullptr;  // [F,3]
     int32_t* perm = nullptr;   // [F] slot -> face id, Morton order of the object-space centroids (tiled path: coherent 64-triangle chunks)
     int32_t* fsort = nullptr;  // [F,3] faces[perm[slot]]: the corner ids in slot order (read coalesced by the bin / tile kernels)
+    std::vector<int32_t> h_vmap;   // host copy of vmap (per-vertex attributes are stored by device id)
+    int32_t* vmap = nullptr;   // [V] caller's vertex id -> device vertex id (vertices are stored in order of first use by the Morton-sorted
+                               // triangles, so the 3 x 64 vertex gathers of a chunk hit a few cache lines instead of one line each)
     uint8_t* colors = nullptr; // [V,4] rgba (a unused)
     float* uv = nullptr;       // [F,3,2] per-corner texture coordinates (textured meshes)
     uint8_t* tex = nullptr;    // rgba diffuse texture, all mip levels back to back (level k at texel offset lev_off[k])
@@ -240,9 +243,14 @@ __device__ __forceinline__ bool tri_cover32(const TriSetup& t, int px, int py, i
     if (w2 == 0 && !topleft(t.x1 - t.x0, t.y1 - t.y0)) return false;
     return true;
 }
-__device__ __forceinline__ float tri_depth32(const TriSetup& t, int w0, int w1, int w2, float& b0, float& b1, float& b2) {
-    const float fa = (float)(int)t.area2;      // (a small triangle's doubled area is below 2^31: the same float as from the 64-bit value)
-    b0 = (float)w0 / fa; b1 = (float)w1 / fa; b2 = (float)w2 / fa;
+// b_i = float(w_i) / float(area2), the IEEE quotient, WITHOUT its ~12-instruction expansion per weight: the reciprocal of the area is
+// taken once per triangle in double (rd = RN(1 / fa)), each weight is then one fp64 multiply rounded to float.  The double product is
+// within 2^-52 (relative) of the exact quotient; a quotient of two 24-bit significands is never closer than 2^-49 to a rounding
+// midpoint of the float grid (|x/n - m| >= 1 / (N k) for a 25-bit midpoint significand k), so rounding the product gives the
+// correctly rounded quotient: the bits of the division (and of the oracle).
+__device__ __forceinline__ double tri_rcp_area(const TriSetup& t) { return 1.0 / (double)(float)(int)t.area2; }
+__device__ __forceinline__ float tri_depth32(const TriSetup& t, double rd, int w0, int w1, int w2, float& b0, float& b1, float& b2) {
+    b0 = (float)((double)(float)w0 * rd); b1 = (float)((double)(float)w1 * rd); b2 = (float)((double)(float)w2 * rd);
     const float izp = fmaf(b2, t.iz2, fmaf(b1, t.iz1, b0 * t.iz0));
     return 1.0f / izp;
 }
@@ -447,7 +455,7 @@ __device__ __forceinline__ void resolve_pixel_v(const SVert* __restrict__ sv, co
     if (t.small) {
         int w0, w1, w2;
         tri_cover32(t, px, py, w0, w1, w2);
-        dd = tri_depth32(t, w0, w1, w2, b0, b1, b2);
+        dd = tri_depth32(t, tri_rcp_area(t), w0, w1, w2, b0, b1, b2);
     } else {
         long long w0, w1, w2;
         tri_cover(t, px, py, w0, w1, w2);
@@ -467,12 +475,13 @@ __device__ __forceinline__ void resolve_pixel(const SVert* __restrict__ sv, cons
 }
 
 __global__ __launch_bounds__(256) void raster_tri_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
-                                                         int V, int F, int W, int Hh,
+                                                         const int32_t* __restrict__ perm, int V, int F, int W, int Hh,
                                                          unsigned long long* __restrict__ zb_all,
                                                          int* __restrict__ queue, int* __restrict__ qcount, int qcap, int cull) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int h = blockIdx.y;
-    if (f >= F) return;
+    if (slot >= F) return;
+    const int f = perm[slot];     // Morton order of the centroids: a wave's 64 triangles (and their atomics) are neighbours on the screen whatever the file's face order
     const SVert* sv = sv_all + (size_t)h * V;
     unsigned long long* zb = zb_all + (size_t)h * W * Hh;
     const TriSetup t = tri_setup(sv, faces, f, W, Hh);
@@ -629,7 +638,7 @@ __device__ __forceinline__ void tile_pixel(const TriSetup& t, int f, int px, int
     if (t.small) {
         int w0, w1, w2;
         if (!tri_cover32(t, px, py, w0, w1, w2)) return;
-        d = tri_depth32(t, w0, w1, w2, b0, b1, b2);
+        d = tri_depth32(t, tri_rcp_area(t), w0, w1, w2, b0, b1, b2);
     } else {
         long long w0, w1, w2;
         if (!tri_cover(t, px, py, w0, w1, w2)) return;
@@ -677,6 +686,49 @@ struct ChunkL1 { unsigned box; int i0, i1, i2, f; };
 struct ChunkL2 { SVert a, b, c; };
 constexpr int RES_BATCH = 2;             // pixels a thread resolves together (their gathers are issued back to back)
 
+// A lane's own (small) triangle against its <= 32 candidate pixels in the tile, in two passes: coverage of every candidate first (a few
+// integer operations each) into a bit mask, then depth + LDS minimum for the covered ones only.  The wave waits for its slowest lane in
+// both loops, so the expensive part now runs max-over-lanes(COVERED pixels) times (~1-4 for the ~1.4-pixel triangles of an 82 k mesh)
+// instead of max-over-lanes(candidates) (~12): the chunk loop was 2/3 of the kernel on that mesh.
+__device__ __forceinline__ void tile_tri_small(const TriSetup& t, int f, int x0, int y0, int x1, int y1, unsigned long long* tile,
+                                               int X0, int Y0, int T) {
+    const int A0 = t.x2 - t.x1, B0 = t.y2 - t.y1, A1 = t.x0 - t.x2, B1 = t.y0 - t.y2, A2 = t.x1 - t.x0, B2 = t.y1 - t.y0;
+    const bool tl0 = topleft(A0, B0), tl1 = topleft(A1, B1), tl2 = topleft(A2, B2);
+    const int bw = x1 - x0 + 1;
+    unsigned mask = 0u;
+    int k = 0;
+    for (int py = y0; py <= y1; ++py) {
+        const int sy = py * 256 + 128;
+        for (int px = x0; px <= x1; ++px, ++k) {
+            const int sx = px * 256 + 128;
+            const int w0 = __mul24(A0, sy - t.y1) - __mul24(B0, sx - t.x1);
+            const int w1 = __mul24(A1, sy - t.y2) - __mul24(B1, sx - t.x2);
+            const int w2 = __mul24(A2, sy - t.y0) - __mul24(B2, sx - t.x0);
+            const bool in = (w0 | w1 | w2) >= 0 && (w0 != 0 || tl0) && (w1 != 0 || tl1) && (w2 != 0 || tl2);
+            mask |= (in ? 1u : 0u) << k;
+        }
+    }
+    if (!mask) return;
+    const double rd = tri_rcp_area(t);
+    const float rbw = 1.0f / (float)bw;
+    while (mask) {
+        const int kk = __ffs((int)mask) - 1;
+        mask &= mask - 1u;
+        const int ry = (int)(((float)kk + 0.5f) * rbw), rx = kk - ry * bw;      // kk / bw for kk < 32, bw <= 32
+        const int px = x0 + rx, py = y0 + ry;
+        const int sx = px * 256 + 128, sy = py * 256 + 128;
+        const int w0 = __mul24(A0, sy - t.y1) - __mul24(B0, sx - t.x1);
+        const int w1 = __mul24(A1, sy - t.y2) - __mul24(B1, sx - t.x2);
+        const int w2 = __mul24(A2, sy - t.y0) - __mul24(B2, sx - t.x0);
+        float b0, b1, b2;
+        const float d = tri_depth32(t, rd, w0, w1, w2, b0, b1, b2);
+        if (!(d > 0.f)) continue;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)f;
+        unsigned long long* slot = &tile[(py - Y0) * T + (px - X0)];
+        if (key < *(volatile unsigned long long*)slot) atomicMin(slot, key);
+    }
+}
+
 __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restrict__ sv_all, const int32_t* __restrict__ faces,
                                                           const int32_t* __restrict__ perm, const int32_t* __restrict__ fsort, ShadeArgs sh,
                                                           const float* __restrict__ tables, int V, int F, int W, int Hh, int T,
@@ -688,7 +740,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
 #ifdef FP_LAB   // lab build: ablation bits for tools/raster_ablate.py (1 = no rasterisation, 2 = no shading, 4 = no flush, 8 = no mask scan),
     // bits 8.. = the per-lane / whole-wave threshold (0 = the product's), dbg_buf = per-phase shader-clock sums of all workgroups
     const int dbg = dbg_arg & 255;
-    const int big_area = (dbg_arg >> 8) ? (dbg_arg >> 8) : BIG_TILE_AREA;
+    const int big_area = (dbg_arg >> 8) ? min(dbg_arg >> 8, 32) : BIG_TILE_AREA;   // (the per-lane coverage mask has 32 bits)
     unsigned long long tstamp = __builtin_readcyclecounter();
 #define FP_RASTER_PHASE(k)                                                                                   \
     do {                                                                                                     \
@@ -780,11 +832,10 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
                 t = tri_setup_v(g0.a, g0.b, g0.c, c0.i0, c0.i1, c0.i2, W, Hh);
                 x0 = max(t.bx0, X0); y0 = max(t.by0, Y0); x1 = min(t.bx1, X1); y1 = min(t.by1, Y1);
                 mine = t.ok && x0 <= x1 && y0 <= y1;
-                big = mine && ((x1 - x0 + 1) * (y1 - y0 + 1) > big_area || t.strad);   // straddlers always take the wave loop
+                // the wave loop: many candidate pixels, edge functions beyond 32 bits, near-plane straddlers
+                big = mine && ((x1 - x0 + 1) * (y1 - y0 + 1) > big_area || !t.small || t.strad);
             }
-            if (mine && !big)
-                for (int py = y0; py <= y1; ++py)
-                    for (int px = x0; px <= x1; ++px) tile_pixel(t, f, px, py, tile, X0, Y0, T);
+            if (mine && !big) tile_tri_small(t, f, x0, y0, x1, y1, tile, X0, Y0, T);
             // triangles with many candidate pixels in this tile, and near-plane straddlers: the whole wave strides over them, one triangle
             // at a time, the owner lane's set-up broadcast by v_readlane.  (Round 6 also measured the candidates of a chunk FLATTENED over
             // the lanes — counts prefix-summed, owner found by binary search, set-up fetched by ds_bpermute: 14 permutes per item cost what
@@ -886,7 +937,21 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
             depth[((size_t)h * Hh + Y0 + ly) * W + X0 + lx] = __uint_as_float((unsigned)(tile[ly * T + lx] >> 32));
         }
     }
-    {
+    if (((W * 3) & 3) == 0 && (tw & 3) == 0 && (T & 3) == 0) {
+        // rows start on a dword (W * 3 and X0 * 3 are multiples of 4) and hold whole groups of four pixels = three dwords: the
+        // packed results' low words are spliced with shifts, one 12-byte store per lane, adjacent lanes adjacent
+        const int nq = tw >> 2;
+        for (int q = threadIdx.x; q < th * nq; q += blockDim.x) {
+            const int ly = q / nq, qx = q - ly * nq;
+            const unsigned long long* src = &tile[ly * T + 4 * qx];
+            const unsigned p0 = (unsigned)src[0], p1 = (unsigned)src[1], p2 = (unsigned)src[2], p3 = (unsigned)src[3];
+            uint3 o;
+            o.x = (p0 & 0xffffffu) | (p1 << 24);
+            o.y = ((p1 >> 8) & 0xffffu) | (p2 << 16);
+            o.z = ((p2 >> 16) & 0xffu) | (p3 << 8);
+            *(uint3*)(rgb + (((size_t)h * Hh + Y0 + ly) * W + X0 + 4 * qx) * 3) = o;
+        }
+    } else {
         const int ndw = (tw * 3 + 3) / 4 + 1;                          // dwords that can hold a row's bytes at any alignment
         for (int q = threadIdx.x; q < th * ndw; q += blockDim.x) {
             const int ly = q / ndw, j = q - ly * ndw;
@@ -979,10 +1044,12 @@ __global__ void ext_boxes_kernel(const double* __restrict__ ext, int Hn, int32_t
 }
 
 // vertex stage export (fp_project_vertices)
-__global__ void raster_export_kernel(const SVert* __restrict__ sv, size_t n, int32_t* __restrict__ xy, float* __restrict__ zc) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void raster_export_kernel(const SVert* __restrict__ sv, const int32_t* __restrict__ vmap, int V, size_t n,
+                                     int32_t* __restrict__ xy, float* __restrict__ zc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (view, caller's vertex id)
     if (i >= n) return;
-    const SVert v = sv[i];
+    const size_t h = i / (size_t)V;
+    const SVert v = sv[h * (size_t)V + (size_t)vmap[i - h * (size_t)V]];
     const bool front = v.zc > ZNEAR;     // behind the near plane the fields hold homogeneous coordinates (straddler path), not pixels
     xy[2 * i] = front ? v.xi : 0; xy[2 * i + 1] = front ? v.yi : 0;
     zc[i] = v.zc;
@@ -1021,8 +1088,6 @@ static int mesh_geometry(fp_ctx* ctx, const float* h_verts, int V, const int32_t
     m->ctx = ctx; m->V = V; m->F = F;
     FP_HIP(hipMalloc((void**)&m->verts, (size_t)V * 12));
     FP_HIP(hipMalloc((void**)&m->faces, (size_t)F * 12));
-    FP_HIP(hipMemcpy(m->verts, h_verts, (size_t)V * 12, hipMemcpyHostToDevice));
-    FP_HIP(hipMemcpy(m->faces, h_faces, (size_t)F * 12, hipMemcpyHostToDevice));
     {   // Morton order of the triangle centroids (10 bits per axis over the vertex bounding box), ties by face id
         float lo[3] = {h_verts[0], h_verts[1], h_verts[2]}, hi[3] = {h_verts[0], h_verts[1], h_verts[2]};
         for (int i = 0; i < V; ++i)
@@ -1047,13 +1112,30 @@ static int mesh_geometry(fp_ctx* ctx, const float* h_verts, int V, const int32_t
         std::sort(key.begin(), key.end());
         std::vector<int32_t> perm((size_t)F);
         for (int f = 0; f < F; ++f) perm[f] = key[f].second;
+        // device vertex ids: order of first use along the sorted triangles (unreferenced vertices last).  Purely internal — outputs carry
+        // no vertex id, fp_project_vertices maps back — but a chunk's vertices are then neighbours in the per-view vertex array: the
+        // gathers of the bin / tile / resolve stages fetched one 128-byte line per 16-byte vertex before (3 x 64 lines per chunk).
+        std::vector<int32_t> vmap((size_t)V, -1);
+        int next = 0;
+        for (int k = 0; k < F; ++k)
+            for (int a = 0; a < 3; ++a) { int32_t& id = vmap[h_faces[3 * (size_t)perm[k] + a]]; if (id < 0) id = next++; }
+        for (int i = 0; i < V; ++i) if (vmap[i] < 0) vmap[i] = next++;
+        std::vector<float> verts((size_t)V * 3);
+        for (int i = 0; i < V; ++i)
+            for (int a = 0; a < 3; ++a) verts[3 * (size_t)vmap[i] + a] = h_verts[3 * (size_t)i + a];
+        std::vector<int32_t> faces((size_t)F * 3), fsort((size_t)F * 3);
+        for (size_t i = 0; i < (size_t)F * 3; ++i) faces[i] = vmap[h_faces[i]];
+        for (int k = 0; k < F; ++k)
+            for (int a = 0; a < 3; ++a) fsort[3 * (size_t)k + a] = faces[3 * (size_t)perm[k] + a];
+        FP_HIP(hipMemcpy(m->verts, verts.data(), (size_t)V * 12, hipMemcpyHostToDevice));
+        FP_HIP(hipMemcpy(m->faces, faces.data(), (size_t)F * 12, hipMemcpyHostToDevice));
         FP_HIP(hipMalloc((void**)&m->perm, (size_t)F * 4));
         FP_HIP(hipMemcpy(m->perm, perm.data(), (size_t)F * 4, hipMemcpyHostToDevice));
-        std::vector<int32_t> fsort((size_t)F * 3);
-        for (int k = 0; k < F; ++k)
-            for (int a = 0; a < 3; ++a) fsort[3 * (size_t)k + a] = h_faces[3 * (size_t)perm[k] + a];
         FP_HIP(hipMalloc((void**)&m->fsort, (size_t)F * 12));
         FP_HIP(hipMemcpy(m->fsort, fsort.data(), (size_t)F * 12, hipMemcpyHostToDevice));
+        FP_HIP(hipMalloc((void**)&m->vmap, (size_t)V * 4));
+        FP_HIP(hipMemcpy(m->vmap, vmap.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+        m->h_vmap = std::move(vmap);
     }
     int rc = mesh_tables(m);
     if (rc) return rc;
@@ -1069,7 +1151,10 @@ extern "C" int fp_mesh_upload(fp_ctx* ctx, const float* h_verts, int V, const in
     MeshGuard guard{m};
     if (h_colors) {
         std::vector<uint8_t> rgba((size_t)V * 4, 255);
-        for (int i = 0; i < V; ++i) { rgba[4 * i] = h_colors[3 * i]; rgba[4 * i + 1] = h_colors[3 * i + 1]; rgba[4 * i + 2] = h_colors[3 * i + 2]; }
+        for (int i = 0; i < V; ++i) {
+            const size_t d = (size_t)m->h_vmap[i];                   // vertex attributes live at the device id
+            rgba[4 * d] = h_colors[3 * i]; rgba[4 * d + 1] = h_colors[3 * i + 1]; rgba[4 * d + 2] = h_colors[3 * i + 2];
+        }
         FP_HIP(hipMalloc((void**)&m->colors, (size_t)V * 4));
         FP_HIP(hipMemcpy(m->colors, rgba.data(), (size_t)V * 4, hipMemcpyHostToDevice));
     }
@@ -1122,6 +1207,7 @@ extern "C" int fp_mesh_destroy(fp_mesh* m) {
     if (m->faces) (void)hipFree(m->faces);
     if (m->perm) (void)hipFree(m->perm);
     if (m->fsort) (void)hipFree(m->fsort);
+    if (m->vmap) (void)hipFree(m->vmap);
     if (m->colors) (void)hipFree(m->colors);
     if (m->uv) (void)hipFree(m->uv);
     if (m->tex) (void)hipFree(m->tex);
@@ -1153,7 +1239,7 @@ extern "C" int fp_project_vertices(fp_ctx* ctx, const fp_mesh* mesh, const float
                        fx, fy, cx, cy, sv);
     FP_LAUNCH_CHECK();
     const size_t n = (size_t)Hn * V;
-    hipLaunchKernelGGL(raster_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sv, n, d_xy, d_zc);
+    hipLaunchKernelGGL(raster_export_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sv, mesh->vmap, V, n, d_xy, d_zc);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }
@@ -1173,11 +1259,13 @@ static int rasterize_impl(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses
     // tile edge: 64 px up to 512-px images, else the smallest multiple of 8 that covers the image with 8 x 8 tiles
     const int side = W > Hh ? W : Hh;
     const int T = side <= 512 ? 64 : (cdiv(side, 8) + 7) / 8 * 8;
-    // fp_ctx_set_option(ctx, "raster_tiled", v): -1 / unset = tiled whenever the image fits 8 x 8 tiles of <= 88 px, 0 = global
-    // visibility buffer, 1 = tiled.  (Rounds 1-5 sent meshes above 32 768 triangles to the global buffer: the tile kernel of those
-    // rounds walked every chunk mask with a dependent scalar load; round 6's hit list + Morton-ordered chunks removed the reason.)
+    // fp_ctx_set_option(ctx, "raster_tiled", v): -1 / unset = tiled for images of up to 8 x 8 tiles of <= 88 px and meshes of up to
+    // 131 072 triangles, 0 = global visibility buffer, 1 = tiled.  Measured, 576 views @420^2 with boxes + extents (ms; tiled | global,
+    // profiles/r06_raster_perf.log): 1 280 triangles 1.64 | 2.57, 20 480: 1.65 | 2.70, 81 920: 2.28 | 2.40, 327 680: 5.04 | 2.81 —
+    // both are bound by vector instructions, the tiled path per triangle (set-up in the bin AND the tile kernel, ~1.6 tiles per chunk of
+    // 64), the global path per fragment (L2 atomics).  Rounds 1-5 stopped at 32 768 triangles.
     const int mode = ctx->opt_raster_tiled;
-    const bool tiled = T <= 88 && mode != 0;
+    const bool tiled = T <= 88 && (mode == 1 || (mode != 0 && F <= 131072));
     if (tiled) {
         const int ntx = cdiv(W, T), nty = cdiv(Hh, T), ntile = ntx * nty, nchunk = cdiv(F, BIN_CHUNK);
         uint16_t* tbox;
@@ -1221,7 +1309,7 @@ static int rasterize_impl(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses
     int* qcount = queue + 2 * qcap;
     FP_HIP(hipMemsetAsync(zb, 0xff, (size_t)Hn * W * Hh * 8, s));
     FP_HIP(hipMemsetAsync(qcount, 0, 4, s));
-    hipLaunchKernelGGL(raster_tri_kernel, dim3(cdiv(F, 256), Hn), dim3(256), 0, s, sv, mesh->faces, V, F, W, Hh, zb,
+    hipLaunchKernelGGL(raster_tri_kernel, dim3(cdiv(F, 256), Hn), dim3(256), 0, s, sv, mesh->faces, mesh->perm, V, F, W, Hh, zb,
                        queue, qcount, qcap, mesh->cull);
     FP_LAUNCH_CHECK();
     hipLaunchKernelGGL(raster_big_kernel, dim3(1024), dim3(256), 0, s, sv, mesh->faces, V, W, Hh, zb, queue, qcount, qcap);

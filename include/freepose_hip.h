@@ -33,8 +33,8 @@ int fp_ctx_destroy(fp_ctx* ctx);
  * value < 0 restores the default.
  *   "ln_fused":       1 (default) LayerNorm 1 / 2 folded into the qkv / fc1 GEMMs of fp_vit_forward on a ViT of this context,
  *                     0 the separate LayerNorm kernel (same reference rounding points; used by the parity tests)
- *   "raster_tiled":   unset = LDS-tiled rasteriser for images up to 704 px (any triangle count), global visibility-buffer
- *                     strategy for larger ones; 1 / 0 force one of them (both bit-identical)
+ *   "raster_tiled":   unset = LDS-tiled rasteriser for meshes up to 131 072 triangles and images up to 704 px, global
+ *                     visibility-buffer strategy otherwise; 1 / 0 force one of them (both bit-identical)
  *   "comm_timeout_s": seconds fp_comm_init waits for the rendezvous of all ranks (default 180) before it returns FP_ERR_STATE
  *   "gemm_row_split": 1 (default) a GEMM launch between the tile tiers runs whole rounds of the resident grid on 256x256 tiles and
  *                     the remaining rows on the finer tiers; 0 never splits (bit-identical; tests/test_gpu_kernels.py)

@@ -116,7 +116,7 @@ def test_textured_dense_mesh_and_repeat_wrap_bit_exact():
 
 def test_dense_mesh_any_face_order_on_the_tiled_path():
     """81 920 triangles (the bench's mesh size; rounds 1-5 sent anything above 32 768 to the global atomics buffer) with the faces in
-    RANDOM order: the tiled strategy (Morton-ordered 64-triangle chunks, LDS hit lists) is the default one at any triangle count and
+    RANDOM order: the tiled strategy (Morton-ordered 64-triangle chunks, LDS hit lists) is the default one up to 131 072 triangles and
     gives the oracle's bits; so do the extents / boxes of the fused epilogue; and the face order does not matter (ids ride in the key)"""
     from freepose_amd import ops
     from oracle import fp_oracle as fo

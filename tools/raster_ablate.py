@@ -50,7 +50,7 @@ for sub in subs:
     v, f, c = bench.synthetic_mesh(sub)
     m = ops.Mesh(v, f, c)
     ops.set_option("raster_tiled", 1)
-    for thr in (0, 8, 16, 64):
+    for thr in (0, 4, 8, 16):
         ops.set_option("raster_dbg", (1 << 30) | (thr << 8))
         ops.rasterize_extents(m, poses, 0.25, 600, 600, 210, 210, 420, 420)
         buf = (C.c_ulonglong * 8)()

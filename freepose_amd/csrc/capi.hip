@@ -114,8 +114,10 @@ void fp_ctx::release() {
     bufs.clear();
     if (sk_ws) (void)hipFree(sk_ws);
     if (sk_cnt) (void)hipFree(sk_cnt);
+    if (ffa_arrive) (void)hipFree(ffa_arrive);
     sk_ws = nullptr;
     sk_cnt = nullptr;
+    ffa_arrive = nullptr;
 }
 
 extern "C" int fp_ctx_create(int device, fp_ctx** out) {
@@ -542,13 +544,23 @@ extern "C" int fp_ffa(fp_ctx* ctx, const void* d_feats, const uint8_t* d_mask, i
         if ((rc = ctx->get("ffa.tmp", (size_t)B * D * 2, (void**)&tmp))) return rc;
     uint8_t* pm = nullptr;
     if (cell > 1 && (rc = ctx->get("ffa.pm", (size_t)B * gh * gw, (void**)&pm))) return rc;
-    if ((rc = fp_ffa_pool((const bf16_t*)d_feats, d_mask, tmp, normalize ? nullptr : d_out_f32, B, gh * gw, D, gh, gw,
-                          cell, pm, s)))
-        return rc;
-    if (normalize) {
-        FP_REQUIRE(d_out_bf16, "ffa: normalize needs a bf16 output");
-        if ((rc = fp_l2norm_rows(tmp, (bf16_t*)d_out_bf16, B, D, s))) return rc;
+    if (normalize) FP_REQUIRE(d_out_bf16, "ffa: normalize needs a bf16 output");
+    // up to FFA_FUSED_MAX crops (the queries of an image / a frame window) the masked-mean kernel normalises the rows itself (its last
+    // column-slab workgroup per crop); beyond (bank building) the row kernel does
+    constexpr int FFA_FUSED_MAX = 16;
+    int* arrive = nullptr;
+    if (normalize && B <= FFA_FUSED_MAX && D % 8 == 0 && (((uintptr_t)tmp | (uintptr_t)d_out_bf16) & 15) == 0) {
+        if (!ctx->ffa_arrive) {
+            FP_HIP(hipMalloc((void**)&ctx->ffa_arrive, FFA_FUSED_MAX * sizeof(int)));
+            FP_HIP(hipMemsetAsync(ctx->ffa_arrive, 0, FFA_FUSED_MAX * sizeof(int), s));
+        }
+        arrive = ctx->ffa_arrive;
     }
+    if ((rc = fp_ffa_pool((const bf16_t*)d_feats, d_mask, tmp, normalize ? nullptr : d_out_f32, B, gh * gw, D, gh, gw,
+                          cell, pm, s, arrive ? (bf16_t*)d_out_bf16 : nullptr, arrive)))
+        return rc;
+    if (normalize && !arrive)
+        if ((rc = fp_l2norm_rows(tmp, (bf16_t*)d_out_bf16, B, D, s))) return rc;
     return FP_OK;
 }
 

@@ -30,6 +30,7 @@ struct fp_ctx {
     static constexpr size_t SK_WS_BYTES = (size_t)64 << 20;
     static constexpr int SK_CNT_N = 16384;
     int sk_scratch(FpGemmArgs& g, hipStream_t s);   // lends the scratch to a launch (allocates on first use)
+    int* ffa_arrive = nullptr;   // per-crop arrival counters of the fused FFA launch (zero between calls: the last arriver resets its own)
     size_t total() const;
     void release();
 };
@@ -47,7 +48,7 @@ int fp_layernorm(const bf16_t* X, bf16_t* Y, const bf16_t* gamma, const bf16_t* 
                  int rows_per_b, int in_stride_b, int in_off, hipStream_t s, int l2_normalize = 0);
 int fp_posembed_aa(const bf16_t* src, bf16_t* dst, int G, int gh, int gw, int D, hipStream_t s);
 int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* out_f32, int B, int P, int D, int gh,
-                int gw, int cell, uint8_t* pm_scratch, hipStream_t s);
+                int gw, int cell, uint8_t* pm_scratch, hipStream_t s, bf16_t* out_norm = nullptr, int* arrive = nullptr);
 int fp_l2norm_rows(const bf16_t* X, bf16_t* Y, int rows, int D, hipStream_t s);
 // LayerNorm folded into the consuming GEMM (gemm_bf16.h FP_EPI_LN_*): row statistics and the one-off weight fold
 int fp_row_stats(const bf16_t* X, uint4* mfrag, float* rstd, int rows, int D, float eps, hipStream_t s);

@@ -784,10 +784,16 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
     const uint16_t* tb = tbox + (size_t)h * nchunk * BIN_CHUNK;
     for (int base = 0; base < ((dbg & 8) ? 0 : nchunk); base += HITS_ROUND) {
         // ---- which of the next 1024 chunks touch this tile: coalesced mask reads, wave-compacted into the hit list
+        unsigned long long mk[HITS_ROUND / 256];
+#pragma unroll
+        for (int k = 0; k < HITS_ROUND / 256; ++k) {                      // the round's four mask loads in flight together
+            const int c = base + k * 256 + (int)threadIdx.x;
+            mk[k] = c < nchunk ? cm[c] : 0ull;
+        }
 #pragma unroll
         for (int k = 0; k < HITS_ROUND / 256; ++k) {
             const int c = base + k * 256 + (int)threadIdx.x;
-            const bool hit = c < nchunk && ((cm[c] >> tbit) & 1ull);
+            const bool hit = (mk[k] >> tbit) & 1ull;
             const unsigned long long bm = __ballot(hit);
             if (bm) {                                                     // wave-uniform
                 int wbase = 0;

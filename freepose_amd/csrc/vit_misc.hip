@@ -240,13 +240,19 @@ __global__ __launch_bounds__(256) void ffa_cellmask_kernel(const uint8_t* __rest
     }
 }
 
+// `arrive` != null (small batches: the video / image queries, with a normalised descriptor asked for): the LAST column-slab workgroup of
+// a crop to arrive (one agent-scope counter per crop) normalises the finished row with l2norm_rows_kernel's arithmetic, so a query's
+// FFA is two launches (cell mask, this) instead of three — each costs ~5 us of launch gap at one crop.  (Round 6 also measured the mask
+// pooling INSIDE this kernel — every slab workgroup reading the crop's 268 KB mask: 34 us against 30 for the three launches.  Dropped.)
+// Same sums in the same order either way.
 __global__ __launch_bounds__(1024) void ffa_kernel(const bf16_t* __restrict__ feats, const uint8_t* __restrict__ pmask,
-                                                   bf16_t* __restrict__ out, float* __restrict__ out_f32, int P, int D) {
+                                                   bf16_t* __restrict__ out, float* __restrict__ out_f32, int P, int D,
+                                                   bf16_t* __restrict__ out_norm, int* __restrict__ arrive) {
     extern __shared__ uint8_t pm[];  // [P]
-    __shared__ int cnt_s;
+    __shared__ int cnt_s, last_s;
     __shared__ float2 part[FFA_NB][32];
     const int b = blockIdx.y;
-    if (threadIdx.x == 0) cnt_s = 0;
+    if (threadIdx.x == 0) { cnt_s = 0; last_s = 0; }
     __syncthreads();
     int local = 0;
     for (int pidx = threadIdx.x; pidx < P; pidx += blockDim.x) {
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(1024) void ffa_kernel(const bf16_t* __restrict__ fe
     if (live) {
         const uint32_t* fp = (const uint32_t*)(feats + (size_t)b * P * D) + c2;
         // the additions keep their order; the loads do not wait for the mask test, so FFA_UNR rows are in flight per thread
-        constexpr int FFA_UNR = 16;
+        constexpr int FFA_UNR = 32;      // a block of ceil(1369 / 32) = 43 patches in two rounds of loads, of 29 (P = 900) in one
         for (int p0 = p_lo; p0 < p_hi; p0 += FFA_UNR) {
             uint32_t w[FFA_UNR];
 #pragma unroll
@@ -281,13 +287,52 @@ __global__ __launch_bounds__(1024) void ffa_kernel(const bf16_t* __restrict__ fe
     }
     part[j][c2l] = make_float2(a0, a1);
     __syncthreads();
-    if (j != 0 || !live) return;
-    float2 t = part[0][c2l];
-    for (int k = 1; k < FFA_NB; ++k) { t.x += part[k][c2l].x; t.y += part[k][c2l].y; }
-    // mean of a bf16 tensor: fp32 accumulate, divide, round to bf16 (0/0 -> NaN like the reference)
-    const float m0 = t.x / (float)cnt, m1 = t.y / (float)cnt;
-    if (out) ((uint32_t*)(out + (size_t)b * D))[c2] = pack_bf2(m0, m1);
-    if (out_f32) { out_f32[(size_t)b * D + 2 * c2] = rbf(m0); out_f32[(size_t)b * D + 2 * c2 + 1] = rbf(m1); }
+    if (j == 0 && live) {
+        float2 t = part[0][c2l];
+        for (int k = 1; k < FFA_NB; ++k) { t.x += part[k][c2l].x; t.y += part[k][c2l].y; }
+        // mean of a bf16 tensor: fp32 accumulate, divide, round to bf16 (0/0 -> NaN like the reference)
+        const float m0 = t.x / (float)cnt, m1 = t.y / (float)cnt;
+        if (out) ((uint32_t*)(out + (size_t)b * D))[c2] = pack_bf2(m0, m1);
+        if (out_f32) { out_f32[(size_t)b * D + 2 * c2] = rbf(m0); out_f32[(size_t)b * D + 2 * c2 + 1] = rbf(m1); }
+    }
+    if (!arrive || !out_norm) return;
+    // ---- the last slab workgroup of this crop normalises the finished row (hand-off recipe of the CDNA guide, §6 G16: every wave drains
+    // its stores, barrier, ONE lane releases at agent scope and arrives on the counter; the last arriver acquires at agent scope, barrier,
+    // plain loads).  Nobody waits for anybody: no residency assumption.  The last arriver puts the counter back to zero for the next call.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int prev = __hip_atomic_fetch_add(&arrive[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == (int)gridDim.x - 1) {
+            __hip_atomic_store(&arrive[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            last_s = 1;
+        }
+    }
+    __syncthreads();
+    if (!last_s || threadIdx.x >= 64) return;
+    // one wave: l2norm_rows_kernel's arithmetic (lane l takes elements (c*64 + l)*8 + e, fmaf chain, xor-butterfly), 16-byte accesses
+    const int lane = threadIdx.x;
+    const bf16_t* xr = out + (size_t)b * D;
+    float acc = 0.f;
+    for (int base = lane * 8; base < D; base += 512) {
+        const uint4 q = *(const uint4*)(xr + base);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float lo = lo_bf(w[e]), hi = hi_bf(w[e]); acc = __fmaf_rn(lo, lo, acc); acc = __fmaf_rn(hi, hi, acc); }
+    }
+    acc = wave_sum(acc);
+    const float n = fmaxf(rbf(fp_sqrt_rn(acc)), 1e-12f);
+    for (int base = lane * 8; base < D; base += 512) {
+        const uint4 q = *(const uint4*)(xr + base);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf2(__fdiv_rn(lo_bf(w[e]), n), __fdiv_rn(hi_bf(w[e]), n));
+        *(uint4*)(out_norm + (size_t)b * D + base) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 // F.normalize(x, dim=-1) on bf16 rows with the reference's rounding points:
@@ -519,7 +564,7 @@ int fp_posembed_aa(const bf16_t* src, bf16_t* dst, int G, int gh, int gw, int D,
 }
 
 int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* out_f32, int B, int P, int D, int gh,
-                int gw, int cell, uint8_t* pm_scratch, hipStream_t s) {
+                int gw, int cell, uint8_t* pm_scratch, hipStream_t s, bf16_t* out_norm, int* arrive) {
     FP_REQUIRE(gh * gw == P && D % 2 == 0 && cell >= 1, "ffa: bad shape P=%d gh=%d gw=%d", P, gh, gw);
     FP_REQUIRE(P <= 60000 && cell * cell * gw <= 60000, "ffa: P=%d cell=%d too large for the LDS staging", P, cell);
     const uint8_t* pm = mask;
@@ -529,7 +574,8 @@ int fp_ffa_pool(const bf16_t* feats, const uint8_t* mask, bf16_t* out, float* ou
         FP_LAUNCH_CHECK();
         pm = pm_scratch;
     }
-    hipLaunchKernelGGL(ffa_kernel, dim3(cdiv(D, 64), B), dim3(1024), P, s, feats, pm, out, out_f32, P, D);
+    FP_REQUIRE(!arrive || (out && out_norm && D % 8 == 0), "ffa: the fused normalisation needs both bf16 buffers and D %% 8 == 0");
+    hipLaunchKernelGGL(ffa_kernel, dim3(cdiv(D, 64), B), dim3(1024), P, s, feats, pm, out, out_f32, P, D, out_norm, arrive);
     FP_LAUNCH_CHECK();
     return FP_OK;
 }

@@ -175,7 +175,8 @@ def ffa(feats: torch.Tensor, masks: torch.Tensor, cell: int = 14, normalize: boo
     lib = _lib.load()
     f = _dev(feats, torch.bfloat16)
     B, Pn, D = f.shape
-    m = _dev(masks).to(torch.uint8).contiguous()
+    m = _dev(masks)
+    m = (m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)).contiguous()   # (a bool tensor IS 0 / 1 bytes: no copy kernel)
     if cell == 1:
         gh, gw = 1, Pn
         m = m.reshape(B, 1, Pn)

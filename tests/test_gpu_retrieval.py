@@ -140,6 +140,42 @@ def test_ffa_bit_exact(B, gh, gw, D, cell):
     assert np.array_equal(fo.torch_to_bits(gn), fo.l2norm_rows(ob))
 
 
+def test_ffa_fused_normalisation_equals_the_row_kernel():
+    """up to 16 crops the masked-mean kernel normalises the rows itself (the last column-slab workgroup of a crop to arrive, one
+    agent-scope counter per crop); above, the row kernel does.  Same bits for the same crops — at mask storage of every byte alignment,
+    sparse single-pixel masks (one byte at a cell's corner), over repeated calls (the arrival counters return to zero), beside the oracle."""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    rng = np.random.Generator(np.random.PCG64(43))
+    gh = gw = 37
+    P, D, cell = gh * gw, 1024, 14
+    nbig = 20
+    feats = fo.to_bf16_bits(rng.standard_normal((nbig, P, D)).astype(np.float32))
+    mask = (rng.random((nbig, gh * cell, gw * cell)) < 0.0004).astype(np.uint8)          # a few isolated pixels per crop
+    mask[1] = 0
+    mask[1, 13, 13] = 1                                                                   # last byte of the first cell
+    mask[2] = 0
+    mask[2, -1, -1] = 1                                                                   # the very last byte of a crop's mask
+    mask[3, 100:300, 50:400] = 1
+    ob, of = fo.ffa(feats, mask, cell)
+    ft, mt = fo.bits_to_torch(feats).cuda(), torch.from_numpy(mask).cuda()
+    big = ops.ffa(ft, mt, cell=cell, normalize=True)                                      # 20 crops: cell mask, masked mean, row normalisation
+    big_raw = ops.ffa(ft, mt, cell=cell)
+    assert np.array_equal(fo.torch_to_bits(big_raw.cpu()), ob) and np.array_equal(fo.torch_to_bits(big.cpu()), fo.l2norm_rows(ob))
+    flat = torch.zeros(mt.numel() + 8, dtype=torch.uint8, device="cuda")
+    for rep in range(3):
+        for lo, n in ((0, 1), (1, 3), (4, 16), (19, 1)):                                  # 1 ... 16 crops: normalised by the masked-mean kernel
+            for off in ((0, 1, 2, 3) if n == 1 else (rep,)):                              # mask storage at every byte alignment
+                m = flat[off:off + n * mask[0].size].view(n, gh * cell, gw * cell)
+                m.copy_(mt[lo:lo + n])
+                got = ops.ffa(ft[lo:lo + n], m, cell=cell, normalize=True)
+                assert torch.equal(got.view(torch.int16), big[lo:lo + n].view(torch.int16)), (rep, lo, n, off)
+                raw = ops.ffa(ft[lo:lo + n], m, cell=cell)
+                assert torch.equal(raw.view(torch.int16), big_raw[lo:lo + n].view(torch.int16))
+                f32 = ops.ffa(ft[lo:lo + n], m, cell=cell, out_f32=True)
+                assert np.array_equal(f32.cpu().numpy()[~np.isnan(of[lo:lo + n])], of[lo:lo + n][~np.isnan(of[lo:lo + n])])
+
+
 def test_ffa_empty_mask_is_nan():
     """0/0 -> NaN like feat[mask].mean(0) on an empty selection (extract_retrieval_features.py:59)"""
     from freepose_amd import ops

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __rest
 //   bin kernel  : one wave per chunk of 64 slots.  Per (view, slot) the tile range of the triangle's clipped pixel bbox as four
 //                 nibbles (16 bit), and per chunk the OR of its triangles' tile masks (64 bit, tiles <= 8 x 8) by a wave reduction.
 //   tile kernel : one workgroup per (view, tile), all tiles of a view on one XCD (its screen-space vertices stay in that L2).
-//                 The chunk masks are read 1024 at a time (coalesced) and the chunks that touch the tile compacted into an LDS hit
+//                 The chunk masks are read 2048 at a time (coalesced) and the chunks that touch the tile compacted into an LDS hit
 //                 list; each WAVE then takes hit chunks on its own (one triangle per lane, the next chunks' reads in flight): the
 //                 candidate pixels of the chunk's triangles are flattened over the wave's lanes and depth-tested into LDS with
 //                 ds_min_u64 — 32-bit edge functions for triangles below 128 px (all of a dense mesh's), a whole-wave loop for the
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void raster_resolve_kernel(const SVert* __rest
 // an order-independent minimum: the output is bit-identical to the global-buffer path and to the oracle.
 constexpr int BIN_CHUNK = 64;
 constexpr int BIG_TILE_AREA = 32;       // candidate pixels in the tile above which a triangle is handed to the whole wave
-constexpr int HITS_ROUND = 1024;         // chunk masks examined per round of the tile kernel (4 per thread)
+constexpr int HITS_ROUND = 2048;         // chunk masks examined per round of the tile kernel (8 per thread; 16-bit ids relative to the round's base)
 constexpr uint16_t TBOX_NONE = 0x000f;   // tx0 = 15 > tx1 = 0: overlaps nothing
 constexpr int PART_N = 10;               // doubles per (view, tile) extents record
 
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
 #endif
     extern __shared__ unsigned long long tile[];   // [T*T] visibility keys | DEC/THR tables (512 floats) | hit list | column / row factors
     float* tab = (float*)(tile + T * T);
-    int* hits = (int*)(tab + 512);
+    unsigned short* hits = (unsigned short*)(tab + 512);
     double* ax = (double*)(hits + HITS_ROUND);
     double* ay = ax + T;
     __shared__ int nhit_s, total_s;
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
     const unsigned long long* cm = cmask + (size_t)h * nchunk;
     const uint16_t* tb = tbox + (size_t)h * nchunk * BIN_CHUNK;
     for (int base = 0; base < ((dbg & 8) ? 0 : nchunk); base += HITS_ROUND) {
-        // ---- which of the next 1024 chunks touch this tile: coalesced mask reads, wave-compacted into the hit list
+        // ---- which of the next 2048 chunks touch this tile: coalesced mask reads, wave-compacted into the hit list
         unsigned long long mk[HITS_ROUND / 256];
 #pragma unroll
         for (int k = 0; k < HITS_ROUND / 256; ++k) {                      // the round's four mask loads in flight together
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
                 int wbase = 0;
                 if (lane == 0) wbase = atomicAdd(&nhit_s, __popcll(bm));
                 wbase = __shfl(wbase, 0, 64);
-                if (hit) hits[wbase + __popcll(bm & ((1ull << lane) - 1ull))] = c;
+                if (hit) hits[wbase + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)(c - base);
             }
         }
         __syncthreads();
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
         auto level1 = [&](int i, ChunkL1& c) {
             c.box = TBOX_NONE; c.i0 = c.i1 = c.i2 = 0; c.f = 0;
             if (i < n) {
-                const int slot = hits[i] * BIN_CHUNK + lane;
+                const int slot = (base + (int)hits[i]) * BIN_CHUNK + lane;
                 c.box = tb[slot];                                        // (TBOX_NONE for slots >= F)
                 if (slot < F) { c.i0 = fsort[3 * slot]; c.i1 = fsort[3 * slot + 1]; c.i2 = fsort[3 * slot + 2]; c.f = perm[slot]; }
             }
@@ -818,9 +818,9 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
             const int bx0 = box & 15, by0 = (box >> 4) & 15, bx1 = (box >> 8) & 15, by1 = (box >> 12) & 15;
             return bx0 <= tx && tx <= bx1 && by0 <= ty && ty <= by1;
         };
-        auto level2 = [&](const ChunkL1& c, ChunkL2& g) {
-            if (overlaps(c.box)) { g.a = sv[c.i0]; g.b = sv[c.i1]; g.c = sv[c.i2]; }
-            else { g.a = g.b = g.c = SVert{0, 0, 0.f, 0.f}; }
+        auto level2 = [&](const ChunkL1& c, ChunkL2& g) {   // (lanes whose triangle misses the tile read vertex 0: one cached line, no branch, no zero fill)
+            const bool o = overlaps(c.box);
+            g.a = sv[o ? c.i0 : 0]; g.b = sv[o ? c.i1 : 0]; g.c = sv[o ? c.i2 : 0];
         };
         ChunkL1 c0, c1, c2;
         ChunkL2 g0, g1;
@@ -830,17 +830,13 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
         for (int i = wave; i < n; i += 4) {
             level1(i + 8, c2);
             level2(c1, g1);
-            bool mine = false, big = false;
-            TriSetup t = {};
+            // set-up on every lane (a wave executes it once whatever the number of live lanes; a branch only added register traffic)
             const int f = c0.f;
-            int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
-            if (overlaps(c0.box)) {
-                t = tri_setup_v(g0.a, g0.b, g0.c, c0.i0, c0.i1, c0.i2, W, Hh);
-                x0 = max(t.bx0, X0); y0 = max(t.by0, Y0); x1 = min(t.bx1, X1); y1 = min(t.by1, Y1);
-                mine = t.ok && x0 <= x1 && y0 <= y1;
-                // the wave loop: many candidate pixels, edge functions beyond 32 bits, near-plane straddlers
-                big = mine && ((x1 - x0 + 1) * (y1 - y0 + 1) > big_area || !t.small || t.strad);
-            }
+            const TriSetup t = tri_setup_v(g0.a, g0.b, g0.c, c0.i0, c0.i1, c0.i2, W, Hh);
+            const int x0 = max(t.bx0, X0), y0 = max(t.by0, Y0), x1 = min(t.bx1, X1), y1 = min(t.by1, Y1);
+            const bool mine = overlaps(c0.box) && t.ok && x0 <= x1 && y0 <= y1;
+            // the wave loop: many candidate pixels, edge functions beyond 32 bits, near-plane straddlers
+            const bool big = mine && ((x1 - x0 + 1) * (y1 - y0 + 1) > big_area || !t.small || t.strad);
             if (mine && !big) tile_tri_small(t, f, x0, y0, x1, y1, tile, X0, Y0, T);
             // triangles with many candidate pixels in this tile, and near-plane straddlers: the whole wave strides over them, one triangle
             // at a time, the owner lane's set-up broadcast by v_readlane.  (Round 6 also measured the candidates of a chunk FLATTENED over
@@ -1293,8 +1289,8 @@ static int rasterize_impl(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses
 #else
         const int raster_dbg = 0;
 #endif
-        const size_t lds = (size_t)T * T * 8 + 2048 + HITS_ROUND * 4 + (size_t)2 * T * 8;   // keys + DEC/THR tables + hit list + column / row factors
-        FP_DYN_LDS_ONCE(raster_tile_kernel, 88 * 88 * 8 + 2048 + HITS_ROUND * 4 + 2 * 88 * 8);
+        const size_t lds = (size_t)T * T * 8 + 2048 + HITS_ROUND * 2 + (size_t)2 * T * 8;   // keys + DEC/THR tables + hit list + column / row factors
+        FP_DYN_LDS_ONCE(raster_tile_kernel, 88 * 88 * 8 + 2048 + HITS_ROUND * 2 + 2 * 88 * 8);
         hipLaunchKernelGGL(raster_tile_kernel, dim3(ntile, Hn), dim3(256), lds, s, sv, mesh->faces, mesh->perm, mesh->fsort, shade_args(mesh), mesh->tables,
                            V, F, W, Hh, T, ntx, Hn, tbox, cmask, nchunk, d_rgb, d_depth, part, (double)fx, (double)fy, (double)cx, (double)cy, raster_dbg & ~(1 << 30), dbg_buf);
         FP_LAUNCH_CHECK();

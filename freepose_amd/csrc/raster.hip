@@ -451,17 +451,19 @@ __device__ __forceinline__ void resolve_pixel_v(const SVert* __restrict__ sv, co
         shade_fragment(s, t, at, b0, b1, b2, 1.0f, tab, out, true);
         return;
     }
-    float dd;
+    // the winner's weights again (three IEEE quotients: per PIXEL that is cheaper than the fp64 reciprocal the raster pass amortises
+    // over a triangle); its depth is the key's — the same bits the raster pass computed from the same weights
+    const float fa = (float)t.area2;
     if (t.small) {
         int w0, w1, w2;
         tri_cover32(t, px, py, w0, w1, w2);
-        dd = tri_depth32(t, tri_rcp_area(t), w0, w1, w2, b0, b1, b2);
+        b0 = (float)w0 / fa; b1 = (float)w1 / fa; b2 = (float)w2 / fa;
     } else {
         long long w0, w1, w2;
         tri_cover(t, px, py, w0, w1, w2);
-        dd = tri_depth(t, w0, w1, w2, b0, b1, b2);
+        b0 = (float)w0 / fa; b1 = (float)w1 / fa; b2 = (float)w2 / fa;
     }
-    shade_fragment(s, t, at, b0 * t.iz0, b1 * t.iz1, b2 * t.iz2, dd, tab, out);
+    shade_fragment(s, t, at, b0 * t.iz0, b1 * t.iz1, b2 * t.iz2, d, tab, out);
 }
 __device__ __forceinline__ void resolve_pixel(const SVert* __restrict__ sv, const int32_t* __restrict__ faces, const ShadeArgs& s,
                                               const float* tab, unsigned long long key, int px, int py, int W, int Hh, float& d,
@@ -638,7 +640,7 @@ __device__ __forceinline__ void tile_pixel(const TriSetup& t, int f, int px, int
     if (t.small) {
         int w0, w1, w2;
         if (!tri_cover32(t, px, py, w0, w1, w2)) return;
-        d = tri_depth32(t, tri_rcp_area(t), w0, w1, w2, b0, b1, b2);
+        d = tri_depth32(t, tri_rcp_area(t), w0, w1, w2, b0, b1, b2);   // (three IEEE quotients instead: measured 5 % slower at 1 280 triangles)
     } else {
         long long w0, w1, w2;
         if (!tri_cover(t, px, py, w0, w1, w2)) return;
@@ -1011,18 +1013,26 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const SVert* __restric
 
 // folds the per-tile records of a view into fp_depth_extents' row (and the int32 box CropResizePad takes): same rule for views with
 // fewer than 100 mask pixels (renderer.py:116-117, template.py:75-77)
-__global__ void raster_extents_kernel(const double* __restrict__ part, int Hn, int ntile, int W, int Hh, double* __restrict__ ext,
-                                      int32_t* __restrict__ boxes) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= Hn) return;
+__global__ __launch_bounds__(64) void raster_extents_kernel(const double* __restrict__ part, int Hn, int ntile, int W, int Hh,
+                                                            double* __restrict__ ext, int32_t* __restrict__ boxes) {
+    const int v = blockIdx.x, lane = threadIdx.x;        // one wave per view, one tile record per lane (<= 64 tiles), butterfly reduction
     int c = 0, bx0 = 1 << 30, by0 = 1 << 30, bx1 = -1, by1 = -1;
     double Xmin = 1e300, Xmax = -1e300, Ymin = 1e300, Ymax = -1e300;
-    for (int t = 0; t < ntile; ++t) {
+    for (int t = lane; t < ntile; t += 64) {
         const double* p = part + ((size_t)v * ntile + t) * PART_N;
         c += (int)p[0];
         bx0 = min(bx0, (int)p[1]); by0 = min(by0, (int)p[2]); bx1 = max(bx1, (int)p[3]); by1 = max(by1, (int)p[4]);
         Xmin = fmin(Xmin, p[5]); Xmax = fmax(Xmax, p[6]); Ymin = fmin(Ymin, p[7]); Ymax = fmax(Ymax, p[8]);
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        c += __shfl_xor(c, off, 64);
+        bx0 = min(bx0, __shfl_xor(bx0, off, 64)); by0 = min(by0, __shfl_xor(by0, off, 64));
+        bx1 = max(bx1, __shfl_xor(bx1, off, 64)); by1 = max(by1, __shfl_xor(by1, off, 64));
+        Xmin = fmin(Xmin, shfl_xor_f64(Xmin, off)); Xmax = fmax(Xmax, shfl_xor_f64(Xmax, off));
+        Ymin = fmin(Ymin, shfl_xor_f64(Ymin, off)); Ymax = fmax(Ymax, shfl_xor_f64(Ymax, off));
+    }
+    if (lane != 0) return;
     if (c < 100) {
         const int lo = 105, hx = min(315, W) - 1, hy = min(315, Hh) - 1;
         if (c == 0) { bx0 = lo; by0 = lo; bx1 = hx; by1 = hy; }
@@ -1295,7 +1305,7 @@ static int rasterize_impl(fp_ctx* ctx, const fp_mesh* mesh, const float* d_poses
                            V, F, W, Hh, T, ntx, Hn, tbox, cmask, nchunk, d_rgb, d_depth, part, (double)fx, (double)fy, (double)cx, (double)cy, raster_dbg & ~(1 << 30), dbg_buf);
         FP_LAUNCH_CHECK();
         if (want_ext) {
-            hipLaunchKernelGGL(raster_extents_kernel, dim3(cdiv(Hn, 64)), dim3(64), 0, s, part, Hn, ntile, W, Hh, d_ext, d_boxes);
+            hipLaunchKernelGGL(raster_extents_kernel, dim3(Hn), dim3(64), 0, s, part, Hn, ntile, W, Hh, d_ext, d_boxes);
             FP_LAUNCH_CHECK();
         }
         return FP_OK;

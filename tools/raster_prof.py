@@ -13,5 +13,5 @@ v, f, c = bench.synthetic_mesh(sub)
 m = ops.Mesh(v, f, c)
 ops.set_option("raster_tiled", tiled)
 for _ in range(5):
-    ops.rasterize(m, poses, 0.25, 600, 600, 210, 210, 420, 420)
+    ops.rasterize_extents(m, poses, 0.25, 600, 600, 210, 210, 420, 420)
 torch.cuda.synchronize()

@@ -801,7 +801,8 @@ def stage_table(args, prof, stage_ms, n_tri, n_vert, n_prop):
         "resident: profiles/r03_scan_cold_warm.log (18.2 us = 5.2 TB/s after a clean 1 GiB read sweep, 15.7 us = 6.0 TB/s resident in the "
         "Infinity Cache; in this pipeline, behind the ViT's dirty activations: see the bank_scan_kernel row of profiles/r04_bench_kernel_stats.csv)")
     add("rasterize", stage_ms.get("rasterize", 0), "hbm", (H * 420 * 420 * 3.0 + n_vert * 32.0 + n_tri * 12.0) * n_prop,
-        f"mandatory rgb writes (the depth image is not written: boxes + cloud extents come from the tile epilogue, fp_rasterize_extents); "
+        f"mandatory rgb writes (the depth image is not written: boxes + cloud extents come from the tile epilogue, fp_rasterize_extents); the kernels "
+        f"are bound by vector instructions (triangle set-up, coverage, depth test, shading), not by these bytes: profiles/r06_ab.md §1; "
         f"{H * n_tri * n_prop / max(stage_ms.get('rasterize', 1e9), 1e-9) / 1e6:.1f} G triangle set-ups/s")
     add("depth_extents", stage_ms.get("depth_extents", 0), "hbm", H * 420 * 420 * 4.0 * n_prop, "depth read")
     add("crop_resize", stage_ms.get("crop_resize", 0), "hbm", H * 3.0 * args.res * args.res * 2 * n_prop, "bf16 crop writes (reads are a subset of the renders)")

@@ -142,6 +142,30 @@ def test_dense_mesh_any_face_order_on_the_tiled_path():
         ops.set_option("raster_tiled", -1)
 
 
+def test_million_triangle_mesh_both_strategies():
+    """1 310 720 triangles (icosphere level 8: most triangles cover no pixel centre at all; 20 480 chunks = ten rounds of the tile kernel's
+    mask scan, 16-bit hit ids relative to the round): the tiled strategy forced on, the global one and the oracle agree bit for bit, and so
+    do the fused extents"""
+    from freepose_amd import ops
+    from oracle import fp_oracle as fo
+    import bench
+    v, f, col = bench.synthetic_mesh(8)
+    assert len(f) == 1310720
+    f = f.astype(np.int32)
+    poses = _poses(2)
+    rgb_o, d_o = fo.rasterize(v, f, col, poses, 0.25, 600, 600, 210, 210, 420, 420)
+    ext_o = fo.depth_extents(d_o, 600, 600, 210, 210)
+    mesh = ops.Mesh(v, f, col)
+    try:
+        for mode in (1, 0):
+            ops.set_option("raster_tiled", mode)
+            rgb_g, d_g, ext_g, box_g = ops.rasterize_extents(mesh, torch.from_numpy(poses), 0.25, 600, 600, 210, 210, 420, 420, want_depth=True)
+            assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32)) and np.array_equal(rgb_g.cpu().numpy(), rgb_o), mode
+            assert np.array_equal(ext_g.cpu().numpy(), ext_o) and np.array_equal(box_g.cpu().numpy(), ext_o[:, :4].astype(np.int32))
+    finally:
+        ops.set_option("raster_tiled", -1)
+
+
 def test_texel_pattern_known_answer_on_device():
     """same construction as the oracle's CPU known-answer test: texel centres land on pixel centres -> exact texels"""
     from freepose_amd import ops

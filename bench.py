@@ -123,11 +123,11 @@ def cpu_baseline(args, mesh_arrays, bank_f32):
         if dtp < best[0]:
             best = (dtp, nt)
     ncores = best[1]
-    # SURVEY 8(d) asks for torch.set_num_threads(os.cpu_count()): reported beside the fastest count (one warm-up, one timed forward)
+    # SURVEY 8(d) asks for torch.set_num_threads(os.cpu_count()): reported beside the fastest count (one timed forward)
     all_cores = None
     if avail != ncores:
         torch.set_num_threads(avail)
-        t_all = _median_time(lambda: vit_ref.vit_forward(sd_bf, x, layer=22, feature_type="patch", dtype=torch.bfloat16), 1, 1)
+        t_all = _median_time(lambda: vit_ref.vit_forward(sd_bf, x, layer=22, feature_type="patch", dtype=torch.bfloat16), 0, 1)   # one forward, no warm-up: ~45 s on the pool's hosts
         all_cores = {"cores": avail, "vit_per_crop_bf16": t_all}
     torch.set_num_threads(ncores)
     feats = [None]
